@@ -1,0 +1,390 @@
+"""CPU oracle for the OFQ fake-quantised ViT hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a *restatement* (not a copy) of the reference algorithm (nbasyl/OFQ, /root/reference) as flat
+functions over explicit parameter dicts, written with eager torch-CPU ops in the reference's op order
+so that values and autograd gradients are bit-comparable with the reference's own PyTorch-CPU path.
+Every function cites the reference file:line it follows.
+
+Who may import this file: tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg, and only
+as the checker / the timed CPU baseline.  The product (ofq_amd/) never imports it and has no CPU
+fallback: it raises when the HIP library or a HIP device tensor is missing.
+
+Pinning: the reference has no tests or golden vectors of its own.  This oracle is
+pinned against outputs of the reference itself, generated in the build container by importing
+/root/reference (tests/golden/make_golden.py -> tests/golden/*.npz, checked by tests/test_oracle_golden.py).
+
+Parameter dicts use the reference's state-dict key names, e.g. for a QLinear:
+  weight, bias, input_quant_fn.s, move_b4.bias, move_aft.bias
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# small STE helpers (reference: quantizer/lsq.py:6-18)
+# ----------------------------------------------------------------------------------------------
+
+
+def _grad_scale(x, scale):
+    # lsq.py:6-9 : value x, gradient scaled by `scale`
+    yg = x * scale
+    return (x - yg).detach() + yg
+
+
+def _round_pass(x):
+    # lsq.py:11-14 : value round(x) (RNE), gradient identity
+    return (x.round() - x).detach() + x
+
+
+def _clip_eps(x, eps=1e-5):
+    # lsq.py:16-18 : value max(x, eps), gradient 1 everywhere
+    x_clip = torch.where(x > eps, x, torch.tensor(eps, dtype=x.dtype))
+    return x - x.detach() + x_clip.detach()
+
+
+def lsq_bounds(bits, unsigned):
+    # lsq.py:519-534
+    if unsigned:
+        return (0, 1) if bits == 1 else (0, 2 ** bits - 1)
+    return (-1, 1) if bits == 1 else (-(2 ** (bits - 1)), 2 ** (bits - 1) - 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# StatsQ weight quantiser (statsq.py:133-150)
+# ----------------------------------------------------------------------------------------------
+
+
+def statsq(W, bits):
+    """Returns (W_hat with STE gradient, integer levels L, scale s[rows,1]).  statsq.py:138-148."""
+    assert W.dim() == 2
+    s = (2 * torch.mean(W.abs(), dim=1, keepdim=True)).detach()          # :138, :142
+    v = W / s                                                            # :144
+    c = torch.clamp(v, min=-(2.0 / 2), max=(2.0 / 2) - 1e-6)             # :145  clip_val = 2.0 (:126-128)
+    n = float(2 ** (bits - 1))                                           # :146
+    L = torch.round(c * n - 0.5)                                         # :147
+    Wq = s * ((L + 0.5) / n)                                             # :147
+    out = Wq.detach() - W.detach() + W                                   # :148  STE: dW = g everywhere
+    return out, L.detach().to(torch.int32), s
+
+
+# ----------------------------------------------------------------------------------------------
+# LSQ family.  One generic body (lsq.py:571-602 and the identical bodies at :72-101, :336-373,
+# :419-437, :489-505, :757-792); the variants differ only in where `s` broadcasts and in M.
+# ----------------------------------------------------------------------------------------------
+
+
+def _lsq_core(x, alpha, lo, hi, gscale):
+    s_scale = _grad_scale(_clip_eps(alpha), gscale)                      # lsq.py:593
+    v = x / s_scale                                                      # :595
+    u = torch.clamp(v, lo, hi)                                           # :599
+    q = _round_pass(u)                                                   # :600
+    return q * s_scale                                                   # :601
+
+
+def lsq_token(x, s, bits, unsigned):
+    """LsqQuantizer (lsq.py:515-610): s has length x.shape[-2], broadcast as s.unsqueeze(-1) (:575)."""
+    lo, hi = lsq_bounds(bits, unsigned)
+    if x.dim() == 3:
+        M = x.shape[0] * x.shape[-1]                                     # :584
+    elif x.dim() == 2:
+        M = x.shape[-1]                                                  # :586
+    else:
+        M = x.shape[0] * x.shape[1] * x.shape[-1]                        # :588
+    return _lsq_core(x, s.unsqueeze(-1), lo, hi, 1.0 / math.sqrt(hi * M))
+
+
+def lsq_token_init(x, bits, unsigned):
+    """init_from (lsq.py:544-551): nested means, k = 2 signed / 4 unsigned."""
+    lo, hi = lsq_bounds(bits, unsigned)
+    k = 4 if unsigned else 2
+    a = x.detach().abs().mean(dim=-1)
+    if x.dim() == 3:
+        a = a.mean(dim=0)
+    elif x.dim() == 4:
+        a = a.mean(dim=0).mean(dim=0)
+    return k * a / (hi ** 0.5)
+
+
+def lsq_channel(x, s, bits, unsigned=False):
+    """LsqQuantizer4v (lsq.py:701-800): s per last dim; M = product of leading dims (:775-778)."""
+    lo, hi = lsq_bounds(bits, unsigned)
+    M = x.numel() // x.shape[-1]
+    return _lsq_core(x, s, lo, hi, 1.0 / math.sqrt(hi * M))
+
+
+def lsq_channel_init(x, bits, unsigned=False):
+    lo, hi = lsq_bounds(bits, unsigned)                                  # lsq.py:732-737
+    k = 4 if unsigned else 2
+    a = x.detach().abs()
+    while a.dim() > 1:
+        a = a.mean(dim=0)
+    return k * a / (hi ** 0.5)
+
+
+def lsq_img(x, s, signed, bits=8):
+    """LsqQuantizer4img (lsq.py:306-382): s per input channel (dim 1) of (B,C,H,W); signedness latched."""
+    lo, hi = lsq_bounds(bits, not signed)                                # :341-355
+    M = x.shape[0] * x.shape[2] * x.shape[3]                             # :363
+    return _lsq_core(x, s.view(1, -1, 1, 1), lo, hi, 1.0 / math.sqrt(hi * M))
+
+
+def lsq_img_init(x, signed, bits=8):
+    lo, hi = lsq_bounds(bits, not signed)
+    k = 2 if signed else 2                                               # all_positive is False at the call site (qlinear.py:154) -> factor 2
+    return k * x.detach().abs().mean(dim=-1).mean(dim=-1).mean(dim=0) / (hi ** 0.5)   # :322
+
+
+def lsq_convw(W, s, bits=8):
+    """LsqQuantizer4Conv2d (lsq.py:384-446): signed, s per out-channel of (O,I,kh,kw)."""
+    lo, hi = lsq_bounds(bits, False)
+    M = W.shape[1] * W.shape[2] * W.shape[3]                             # :427
+    return _lsq_core(W, s.view(-1, 1, 1, 1), lo, hi, 1.0 / math.sqrt(hi * M))
+
+
+def lsq_convw_init(W, bits=8):
+    lo, hi = lsq_bounds(bits, False)
+    return 2 * W.detach().abs().mean(dim=-1).mean(dim=-1).mean(dim=-1) / (hi ** 0.5)  # :405
+
+
+def lsq_roww(W, s, bits=8):
+    """LsqQuantizerWeight (lsq.py:20-109), per_channel: s per row of a 2-D weight; M = in_features (:87)."""
+    lo, hi = lsq_bounds(bits, False)
+    return _lsq_core(W, s.unsqueeze(-1), lo, hi, 1.0 / math.sqrt(hi * W.shape[-1]))
+
+
+def lsq_roww_init(W, bits=8):
+    lo, hi = lsq_bounds(bits, False)
+    return 2 * W.detach().abs().mean(dim=-1) / (hi ** 0.5)               # :54
+
+
+def lsq_tensor(x, s, bits=8):
+    """LsqQuantizer4head_input (lsq.py:448-513): one scalar s; M = numel (:494)."""
+    lo, hi = lsq_bounds(bits, False)
+    return _lsq_core(x, s, lo, hi, 1.0 / math.sqrt(hi * x.numel()))
+
+
+def lsq_tensor_init(x, bits=8):
+    lo, hi = lsq_bounds(bits, False)
+    return (x.detach().abs().mean() * 2 / (hi ** 0.5)).reshape(1)        # :480
+
+
+def lsq_effective_scale(alpha, gscale):
+    """The scale VALUE the reference divides by (lsq.py:593): clip() returns exactly max(alpha,1e-5), but
+    grad_scale() returns (a - a*g) + a*g evaluated in fp32 (lsq.py:6-9), which can differ from `a` in
+    the last ulp.  Integer levels are defined with this effective scale; the HIP kernels reproduce it."""
+    a = torch.where(alpha > 1e-5, alpha, torch.tensor(1e-5, dtype=alpha.dtype))
+    t = a * gscale
+    return (a - t) + t
+
+
+def lsq_levels(x, alpha, lo, hi, gscale):
+    """Integer codes q = RNE(clamp(x / a_eff, lo, hi)); alpha already broadcastable."""
+    a = lsq_effective_scale(alpha, gscale)
+    return torch.clamp(x / a, lo, hi).round().to(torch.int32)
+
+
+def lsq_backward_closed_form(g, x, alpha, lo, hi, gscale):
+    """Closed-form gradients of _lsq_core wrt x and the broadcast alpha.
+
+    dx = (g*a)/a * 1[lo <= v <= hi]  (autograd's op order: mul-by-scale backward, then div backward, so dx
+    equals g only up to one ulp);  d(alpha) elementwise = gscale * g * (q - v if in-range else clamp(v)).
+    The caller sums the elementwise d(alpha) over the broadcast axes."""
+    a = lsq_effective_scale(alpha, gscale)
+    v = x / a
+    inr = (v >= lo) & (v <= hi)
+    u = torch.clamp(v, lo, hi)
+    q = u.round()
+    dx = torch.where(inr, (g * a) / a, torch.zeros_like(g))
+    dalpha = gscale * g * torch.where(inr, q - v, u)
+    return dx, dalpha
+
+
+# ----------------------------------------------------------------------------------------------
+# Q-modules
+# ----------------------------------------------------------------------------------------------
+
+
+def _bias_add(x, b):
+    return x + b.expand_as(x)                                            # qbias.py:10
+
+
+def qlinear(x, p, wbits, abits, unsigned=False):
+    """QLinear.forward (qlinear.py:58-73)."""
+    W, _, _ = statsq(p["weight"], wbits)                                 # :62
+    x = _bias_add(x, p["move_b4.bias"])                                  # :66
+    x = lsq_token(x, p["input_quant_fn.s"], abits, unsigned)             # :67
+    x = _bias_add(x, p["move_aft.bias"])                                 # :68
+    out = F.linear(x, W)                                                 # :69
+    out = out + p["bias"].view(1, -1).expand_as(out)                     # :71
+    return out
+
+
+def qmlp(x, p, wbits, abits):
+    """QMLP.forward (qlinear.py:123-136): fc1 signed, exact-erf GELU, fc2 unsigned (:118-120)."""
+    h = qlinear(x, _sub(p, "fc1."), wbits, abits, unsigned=False)
+    h = F.gelu(h)
+    return qlinear(h, _sub(p, "fc2."), wbits, abits, unsigned=True)
+
+
+def _sub(p, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def qattention(x, p, num_heads, wbits, abits):
+    """QAttention.forward, the plain (non-QKR) path (attention.py:67-105)."""
+    B, N, C = x.shape
+    d = C // num_heads
+    qkv = qlinear(x, _sub(p, "qkv."), wbits, abits)                      # :69
+    qkv = _bias_add(qkv, p["move_qkv_b4.bias"])                          # :71
+    qkv = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)      # :72-74
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = lsq_token(q, p["quan_a_q_fn.s"], abits, False)                   # :77
+    k = lsq_token(k, p["quan_a_k_fn.s"], abits, False)                   # :78
+    v = v.permute(0, 2, 1, 3).reshape(B, N, C)                           # :80
+    v = lsq_channel(v, p["quan_a_v_fn.s"], abits)                        # :81
+    q = q.permute(0, 2, 1, 3).reshape(B, N, C)                           # :85-87
+    k = k.permute(0, 2, 1, 3).reshape(B, N, C)
+    q = _bias_add(q, p["move_q_aft.bias"])                               # :88-90
+    k = _bias_add(k, p["move_k_aft.bias"])
+    v = _bias_add(v, p["move_v_aft.bias"])
+    q = q.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)                # :92-94
+    k = k.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
+    v = v.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
+    attn = (q @ k.transpose(-2, -1).contiguous()) * (d ** -0.5)          # :96
+    prob = F.softmax(attn, dim=-1)                                       # :97
+    prob = lsq_token(prob, p["quan_a_softmax_fn.s"], abits, True)        # :99
+    out = (prob @ v).transpose(1, 2).reshape(B, N, C)                    # :102
+    return qlinear(out, _sub(p, "proj."), wbits, abits)                  # :103
+
+
+def qattention_qkr(x, p, num_heads, wbits, abits):
+    """QAttention_qkreparam.forward (attention.py:174-222); the `_4_cga` twin (:291-339) is
+    numerically identical in value and gradient (SURVEY.md §7 hard part 9)."""
+    B, N, C = x.shape
+    H = num_heads
+    d = C // H
+    xq = _bias_add(x, p["quant_x_4_qkv.move_b4.bias"])                   # :177 -> qlinear.py:21-26
+    xq = lsq_token(xq, p["quant_x_4_qkv.input_quant_fn.s"], abits, False)
+    xq = _bias_add(xq, p["quant_x_4_qkv.move_aft.bias"])
+    Wv, _, _ = statsq(p["v.weight"], wbits)                              # :179
+    v = F.linear(xq, Wv)                                                 # :180
+    v = v + p["v.bias"].view(1, -1).expand_as(v)                         # :181
+    v = _bias_add(v, p["move_v_b4.bias"])                                # :184
+    v = lsq_channel(v, p["quan_a_v_fn.s"], abits)                        # :185
+    v = _bias_add(v, p["move_v_aft.bias"])                               # :186
+    v = v.reshape(B, N, H, d).permute(0, 2, 1, 3)                        # :187
+    Wq = p["q.weight"].reshape(H, d, C)                                  # :190
+    Wk = p["k.weight"].reshape(H, d, C)                                  # :191
+    Wqk = Wq.transpose(-2, -1).contiguous() @ Wk                         # :193  (H, C, C)
+    Wqk = Wqk.reshape(H * C, C)                                          # :194
+    Wqk_q, _, _ = statsq(Wqk, wbits)                                     # :195
+    Wqk_q = Wqk_q.reshape(H, C, C)                                       # :196
+    qkx = torch.einsum("HDC,BCN->BHDN", Wqk_q, xq.transpose(-2, -1).contiguous())  # :200
+    qkx = qkx.permute(0, 3, 1, 2).reshape(B, N, H * C)                   # :201
+    qkx = _bias_add(qkx, p["move_qkx_b4.bias"])                          # :202
+    qkx = qkx.reshape(B, N * H, C)                                       # :203
+    qkx = lsq_token(qkx, p["quan_a_qkx_fn.s"], abits, False)             # :204  s per (token, head)
+    qkx = qkx.reshape(B, N, H * C)                                       # :205
+    qkx = _bias_add(qkx, p["move_qkx_aft.bias"])                         # :206
+    qkx = qkx.reshape(B, N, H, -1).permute(0, 2, 3, 1)                   # :207  (B,H,C,N)
+    attn = torch.einsum("BNC,BHCD->BHND", xq, qkx)                       # :210
+    attn = attn * (d ** -0.5)                                            # :213
+    prob = F.softmax(attn, dim=-1)                                       # :214
+    prob = lsq_token(prob, p["quan_a_softmax_fn.s"], abits, True)        # :216
+    out = (prob @ v).transpose(1, 2).reshape(B, N, C)                    # :219
+    return qlinear(out, _sub(p, "proj."), wbits, abits)                  # :220
+
+
+def qconv_patch_embed(img, p, patch):
+    """LSQ_QConv2d.forward (qlinear.py:166-177) + timm PatchEmbed flatten/transpose; W8A8."""
+    signed = bool(p["input_quant_fn.signed"].item() != 0)
+    W = lsq_convw(p["weight"], p["lsqw_fn.s"])                           # :168
+    hh, ww = img.shape[-2], img.shape[-1]
+    x = img + p["move_b4.bias"].reshape(ww, hh).expand_as(img)           # :171, qbias.py:21
+    x = lsq_img(x, p["input_quant_fn.s"], signed)                        # :172
+    x = x + p["move_aft.bias"].reshape(ww, hh).expand_as(x)              # :173
+    y = F.conv2d(x, W, p["bias"], stride=patch)                          # :174
+    return y.flatten(2).transpose(1, 2)
+
+
+def qhead(x, p):
+    """LSQ_QLinear4head.forward (qlinear.py:223-238); W8A8, per-tensor input scale."""
+    W = lsq_roww(p["weight"], p["lsqw_fn.s"])                            # :227
+    x = _bias_add(x, p["move_b4.bias"])                                  # :231
+    x = lsq_tensor(x, p["input_quant_fn.s"])                             # :232
+    x = _bias_add(x, p["move_aft.bias"])                                 # :233
+    out = F.linear(x, W)                                                 # :234
+    return out + p["bias"].view(1, -1).expand_as(out)                    # :236
+
+
+# ----------------------------------------------------------------------------------------------
+# DeiT (distilled) forward (deit.py:32-67; deit_vision_transformer.py:154-164)
+# ----------------------------------------------------------------------------------------------
+
+
+def deit_forward(img, sd, cfg, training=True):
+    """cfg: dict(depth, num_heads, patch, wbits, abits, qkr: bool, ln_eps).  sd: flat state dict with the
+    reference key names.  Returns (cls_logits, dist_logits) in training mode, their mean otherwise."""
+    H = cfg["num_heads"]
+    wb, ab = cfg["wbits"], cfg["abits"]
+    eps = cfg.get("ln_eps", 1e-6)                                        # deit.py:76
+    x = qconv_patch_embed(img, _sub(sd, "patch_embed.proj."), cfg["patch"])
+    B = x.shape[0]
+    cls = sd["cls_token"].expand(B, -1, -1)                              # deit.py:34
+    dist = sd["dist_token"].expand(B, -1, -1)
+    x = torch.cat((cls, dist, x), dim=1)                                 # :38
+    x = x + sd["pos_embed"]                                              # :39
+    C = x.shape[-1]
+    attn_fn = qattention_qkr if cfg["qkr"] else qattention
+    for i in range(cfg["depth"]):
+        pre = "blocks.%d." % i
+        h = F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps)
+        x = x + attn_fn(h, _sub(sd, pre + "attn."), H, wb, ab)          # dvt.py:161-162
+        h = F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], eps)
+        x = x + qmlp(h, _sub(sd, pre + "mlp."), wb, ab)                  # dvt.py:163
+    x = F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], eps)   # deit.py:47
+    cls_x = qhead(x[:, 0], _sub(sd, "head."))                            # deit.py:60
+    dist_x = qhead(x[:, 1], _sub(sd, "head_dist."))
+    if training:
+        return cls_x, dist_x
+    return (cls_x + dist_x) / 2                                          # deit.py:64
+
+
+def kd_loss_soft_and_hard(cls_out, dist_out, hard_target, soft_target):
+    """KDLossSoftandHard.forward (quantization/utils.py:59-77) with KLLossSoft (:44-57), T = 1."""
+    tp = F.softmax(soft_target, dim=1)
+    lp = F.log_softmax(dist_out, dim=1)
+    soft = (-torch.sum(tp * lp, dim=1)).mean()
+    hard = F.cross_entropy(cls_out, hard_target)
+    return soft + hard
+
+
+# ----------------------------------------------------------------------------------------------
+# CGA (cga.py:450-469, :953-1013)
+# ----------------------------------------------------------------------------------------------
+
+
+def cga_freeze_idx(W, bits, boundary_range=0.005):
+    """freeze_outside_boundary_weight_idx (cga.py:450-469): 1.0 where the weight is frozen."""
+    W = W.detach()
+    s = 2 * torch.mean(W.abs(), dim=1, keepdim=True)                     # :462
+    c = torch.clamp(W / s, min=-1.0, max=1.0 - 1e-6)                     # :456
+    n = float(2 ** (bits - 1))
+    b4 = c * n - 0.5                                                     # :458
+    r = torch.round(b4)
+    lo_i, hi_i = int(r.min().item()), int(r.max().item())                # :460, :465
+    notfrozen = torch.zeros_like(W)
+    for i in range(lo_i, hi_i):                                          # np.arange(min, max) :465
+        within = ((b4 - i) <= (0.5 + boundary_range)) & ((b4 - i) >= (0.5 - boundary_range))  # :466
+        notfrozen = notfrozen + within.float()
+    return 1.0 - notfrozen                                               # :469
+
+
+def cga_mask_grad(grad, frz):
+    return grad * frz * 0.0 + grad * (1 - frz)                           # cga.py:962
+
+
+def cga_restore(W_new, W_old, frz):
+    return W_new * (1 - frz) + (W_old * frz)                             # cga.py:964, :994-997
