@@ -1,0 +1,123 @@
+/* ofq_hip.h — C ABI of libofq_hip.so, the MI355X (gfx950) kernels behind the OFQ QAT hot path.
+ *
+ * The reference (nbasyl/OFQ) has no FFI layer: its boundary is the Python nn.Module API
+ * (SURVEY.md §8b).  Each entry point below replaces a chain of eager ATen ops inside one reference
+ * module method; the citation gives that method (file:line under /root/reference).  The Python
+ * host (ofq_amd/) binds these with ctypes and wraps them in torch.autograd.Function objects; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers to contiguous fp32 unless stated; sizes are element counts
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *  - no allocation, no host synchronisation, no global state  => hipGraph-capturable
+ *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative OFQ_E* code
+ *  - workspaces are caller-provided; the *_ws_bytes() functions are pure host arithmetic
+ */
+#ifndef OFQ_HIP_H
+#define OFQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFQ_ABI_VERSION 1
+#define OFQ_EINVAL (-1)  /* bad argument (shape, alignment, null pointer) */
+#define OFQ_ENOWS  (-2)  /* workspace too small */
+
+typedef void* ofq_stream_t;
+
+int ofq_abi_version(void);
+
+/* ---- K1  StatsQ weight quantiser: StatsQuantizer.forward, src/quantization/quantizer/statsq.py:133-150
+ *  s_r = 2*mean_c|W_rc| ; L = rne(clamp(W/s,-1,1-1e-6)*n - 0.5) ; Wq = s*(L+0.5)/n ; out = (Wq - W) + W
+ *  scale_given != 0: `scale` is an INPUT (used by tests to check levels bit-exactly for a given s).
+ *  levels (int8, optional): L in [-n, n-1].  Backward is the identity (STE, statsq.py:148): no kernel. */
+int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
+                   int8_t* levels, int scale_given, ofq_stream_t stream);
+
+/* ---- K3/K5  LSQ activation quantiser with its LearnableBias sandwich:
+ *  LsqQuantizer.forward lsq.py:571-602 (+ :72-101, :336-373, :419-437, :489-505), LsqQuantizer4v.forward
+ *  lsq.py:757-792, LearnableBias.forward qbias.py:9-13, QLinear.forward qlinear.py:66-68,
+ *  QMLP.forward qlinear.py:127 (exact-erf GELU prologue).
+ *  x is viewed as [outer][S][inner] (row r = o*S + j, inner contiguous).
+ *    scale_mode 0: scale index = r % S  (per "token": the reference's x.shape[-2] axis), s has S entries
+ *    scale_mode 1: scale index = column (per channel, LsqQuantizer4v), s has `inner` entries, S must be 1
+ *  b4 / baft (optional, may be NULL) have bias_len = k*inner entries, bias index = (r % k)*inner + c.
+ *  y = ((rne(u) - u) + u) * a_eff + baft,  u = clamp((pre(x) + b4) / a_eff, lo, hi),
+ *  a_eff = (a - a*g) + a*g with a = max(s, 1e-5), g = gscale  (fp32, lsq.py:6-18, :593).
+ *  prologue: 0 none, 1 exact GELU.   codes (optional, contiguous, 1 byte/elt) receives rne(u): int8 for signed
+ *  ranges, uint8 for unsigned ones.
+ *  ldx / ldy: row strides of x (and dx) / of y (and g), so column slices of a wider matrix (the q,k,v
+ *  thirds of the qkv projection, attention.py:72-75) are quantised in place.  inner, ldx, ldy % 4 == 0. */
+int ofq_lsq_fwd(const float* x, const float* s, const float* b4, const float* baft, float* y, int8_t* codes,
+                int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy, int64_t bias_len, int scale_mode,
+                int lo, int hi, float gscale, int prologue, ofq_stream_t stream);
+
+/* ---- K4  LSQ backward (closed form of the autograd graph of the ops above):
+ *  dx_q = (g*a_eff)/a_eff * 1[lo<=v<=hi];  dx = dx_q * pre'(x);  db4 = sum dx_q;  dbaft = sum g;
+ *  ds_j = gscale * sum g * (rne(v)-v if in range else clamp(v)).
+ *  ds/db4/dbaft are OVERWRITTEN (any may be NULL).  ws: ofq_lsq_bwd_ws_bytes() bytes of scratch. */
+size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, int64_t bias_len, int scale_mode);
+int ofq_lsq_bwd(const float* g, const float* x, const float* s, const float* b4, float* dx, float* ds,
+                float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
+                int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue, void* ws,
+                size_t ws_bytes, ofq_stream_t stream);
+
+/* ---- K10  scale + softmax + unsigned LSQ on attention scores:
+ *  QAttention*.forward attention.py:96-99 / :213-216.  scores [rows][ld] (ld >= n, row r belongs to
+ *  query token r % S); prob (saved for backward) and y are written with the same ld, pad columns = 0.
+ *  y = LSQ_unsigned(softmax(scores * alpha)); s has S entries. */
+int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
+                        int64_t ld, int64_t S, float alpha, int hi, float gscale, ofq_stream_t stream);
+size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows);
+/*  backward: g = dL/dy -> dscores (may alias g), ds[S] overwritten. */
+int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
+                        int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
+                        void* ws, size_t ws_bytes, ofq_stream_t stream);
+
+/* ---- K6-K9, K11  fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chain):
+ *  F.linear qlinear.py:69, torch.einsum attention.py:200/:210, `@` attention.py:96/:102/:193/:219 and
+ *  their autograd backward.   C[b0,b1] = alpha * sum_kb opA(A[b0,b1,kb]) * opB(B[b0,b1,kb]) + bias[n]
+ *    transA 0: A is [M][K] (lda),  1: A is [K][M];   transB 0: B is [K][N] (ldb),  1: B is [N][K]
+ *  split_k > 1 needs ws of ofq_gemm_ws_bytes(); the partials are reduced deterministically. */
+typedef struct ofq_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias; /* optional, N entries, added to every row */
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int32_t transA, transB;
+  int32_t nb0, nb1;  /* batch grid (>=1) */
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  int32_t nkb;       /* extra contraction batches accumulated into one C (>=1) */
+  int64_t sAk, sBk;
+  int32_t split_k;   /* >=1 */
+  float alpha;
+  int32_t accumulate; /* C += result (beta = 1) when non-zero */
+} ofq_gemm_desc;
+size_t ofq_gemm_ws_bytes(const ofq_gemm_desc* d);
+int ofq_gemm_f32(const ofq_gemm_desc* d, void* ws, size_t ws_bytes, ofq_stream_t stream);
+
+/* ---- column sum (bias gradients of F.linear: autograd of qlinear.py:71):  out[c] = sum_r x[r][c] */
+size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols);
+int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* ws, size_t ws_bytes,
+               ofq_stream_t stream);
+
+/* ---- K16  CGA: freeze_outside_boundary_weight_idx cga.py:450-469 and the step hooks cga.py:962-964,
+ *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */
+int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, int bits, float boundary_range,
+                        float* frozen, int32_t* range_ws, ofq_stream_t stream);
+/*  grad *= (1-frozen); saved = W*frozen   (before optimizer.step) */
+int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, float* saved, int64_t n,
+                           ofq_stream_t stream);
+/*  W = W*(1-frozen) + saved               (after optimizer.step) */
+int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n, ofq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFQ_HIP_H */

@@ -1,0 +1,68 @@
+"""ctypes binding of libofq_hip.so (the C ABI declared in include/ofq_hip.h).
+
+There is no CPU fallback: if the library is missing or a symbol is absent, importing the ops raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libofq_hip.so")
+
+i64, i32, f32, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp),
+                ("M", i64), ("N", i64), ("K", i64),
+                ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("transA", C.c_int32), ("transB", C.c_int32),
+                ("nb0", C.c_int32), ("nb1", C.c_int32),
+                ("sA0", i64), ("sA1", i64), ("sB0", i64), ("sB1", i64), ("sC0", i64), ("sC1", i64),
+                ("nkb", C.c_int32), ("sAk", i64), ("sBk", i64),
+                ("split_k", C.c_int32), ("alpha", f32), ("accumulate", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "ofq_abi_version": (i32, []),
+    "ofq_statsq_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, i32, vp]),
+    "ofq_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
+    "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
+    "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
+                          vp, sz, vp]),
+    "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp]),
+    "ofq_softmax_lsq_bwd_ws_bytes": (sz, [i64]),
+    "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, sz, vp]),
+    "ofq_gemm_ws_bytes": (sz, [C.POINTER(GemmDesc)]),
+    "ofq_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
+    "ofq_colsum_ws_bytes": (sz, [i64, i64]),
+    "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
+    "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
+    "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
+    "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building it first if the sources are newer and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            from . import build as _b
+            _b.build()
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError("ofq_amd: %s is missing and could not be built (%s). "
+                               "Run `python -m ofq_amd.build`; there is no CPU fallback." % (LIB_PATH, e))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ofq_abi_version() != 1:
+        raise RuntimeError("ofq_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib

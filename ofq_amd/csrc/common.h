@@ -1,0 +1,91 @@
+// Shared device helpers for the OFQ gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ofq_hip.h"
+
+#define OFQ_WAVE 64
+
+#define OFQ_LAUNCH_CHECK()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+// fp32 ops that must keep the reference's rounding sequence are written with the _rn intrinsics so
+// that no fma contraction can merge them (the library is also built with -ffp-contract=off).
+__device__ __forceinline__ float ofq_div(float a, float b) { return __fdiv_rn(a, b); }
+
+// Effective LSQ scale value: clip(s,1e-5) then grad_scale():  (a - a*g) + a*g   (lsq.py:6-18, :593)
+__device__ __forceinline__ float ofq_lsq_eff_scale(float s, float g) {
+  float a = (s > 1e-5f) ? s : 1e-5f;
+  float t = __fmul_rn(a, g);
+  return __fadd_rn(__fsub_rn(a, t), t);
+}
+
+// One LSQ element.  Returns y_int = (q - u) + u (round_pass value, lsq.py:11-14); q is the level.
+__device__ __forceinline__ float ofq_lsq_quant(float xin, float a, float lo, float hi, float& q, float& v) {
+  v = ofq_div(xin, a);
+  float u = fminf(fmaxf(v, lo), hi);
+  q = rintf(u);  // RNE == torch.round
+  return __fadd_rn(__fsub_rn(q, u), u);
+}
+
+__device__ __forceinline__ float ofq_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float ofq_gelu_grad(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <typename T>
+__device__ __forceinline__ T ofq_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum inside aligned groups of W lanes (W power of two <= 64)
+template <int W>
+__device__ __forceinline__ float ofq_group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ofq_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// second stage: dst[c] = scale * sum_{r<nrows} sum_{t<cnt} src[r*row_stride + c*cnt + t], fixed order.
+// Up to three independent jobs (ds, db4, dbaft) in one launch: blockIdx.y selects the job.
+struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; };
+struct SumJobs { SumJob j[3]; };
+
+__global__ __launch_bounds__(256) void strided_sum_kernel(SumJobs jobs) {
+  const SumJob jb = jobs.j[blockIdx.y];
+  __shared__ float part[16][17];
+  const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const int64_t c = (int64_t)blockIdx.x * 16 + cx;
+  float acc = 0.f;
+  if (jb.dst && c < jb.ncols) {
+    for (int64_t r = py; r < jb.nrows; r += 16) {
+      const float* p = jb.src + r * jb.row_stride + c * jb.cnt;
+      for (int t = 0; t < jb.cnt; ++t) acc += p[t];
+    }
+  }
+  part[py][cx] = acc;
+  __syncthreads();
+  if (py == 0 && jb.dst && c < jb.ncols) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += part[t][cx];
+    jb.dst[c] = s * jb.scale;
+  }
+}
+

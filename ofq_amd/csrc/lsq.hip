@@ -1,0 +1,281 @@
+// K3/K4/K5  LSQ activation quantiser fused with its LearnableBias sandwich (and the optional exact-GELU
+// prologue of QMLP): reference lsq.py:571-602 / :757-792, qbias.py:9-13, qlinear.py:66-68, :127.
+//
+// Geometry.  x is [R = outer*S rows][inner]; a workgroup is TY row-groups of TX lanes, every lane owns J
+// float4 column groups (TX*J*4 >= the column tile), so a lane's bias columns never change while it walks
+// rows with stride gridDim.x*TY.  That makes the three backward reductions register-resident:
+//   - per-scale ds (row mode): lane partial -> TX-lane shuffle reduction -> one float per (row, slot)
+//   - db4 / dbaft (and ds in channel mode): J*4 accumulators per lane across all of its rows ->
+//     one LDS pass per workgroup -> partial[gridDim.x][bias_len]
+// and a tiny second kernel finishes them in a fixed order (deterministic, no atomics).
+// HBM traffic: fwd 4 B read + 4 B write per element; bwd 8 B read + 4 B write per element.
+#include "common.h"
+
+struct LsqGeom {
+  int TX, TY, J, gx, gy, k, nslot;
+};
+
+static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g) {
+  if (inner <= 0 || (inner & 3) || R <= 0) return OFQ_EINVAL;
+  int64_t k = (bias_len > 0) ? bias_len / inner : 1;
+  if (bias_len > 0 && k * inner != bias_len) return OFQ_EINVAL;
+  int64_t w4 = inner / 4;
+  int TX = 16;
+  while (TX < 256 && ceil_div(w4, TX) > 4) TX <<= 1;
+  int J = (int)ceil_div(w4, TX);
+  int gy = 1;
+  if (J > 4) {  // very wide rows (the 224x224 image planes): tile the columns
+    J = 4;
+    gy = (int)ceil_div(w4, (int64_t)TX * J);
+  }
+  int TY = 256 / TX;
+  if (k > 1) {
+    if (k > TY) return OFQ_EINVAL;
+    TY = (TY / (int)k) * (int)k;
+  }
+  int64_t gx = ceil_div(R, TY);
+  int64_t cap = 1024 / gy;
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  g->TX = TX; g->TY = TY; g->J = J; g->gx = (int)gx; g->gy = gy; g->k = (int)k;
+  g->nslot = TX >= 64 ? TX / 64 : 1;
+  return 0;
+}
+
+struct LsqArgs {
+  const float* x; const float* g; const float* s; const float* b4; const float* baft;
+  float* y; float* dx; int8_t* codes;
+  float* rowpart;   // [R][gy*nslot]
+  float* colpart;   // [gx][nacc][k*inner]
+  int64_t R, S, inner, ldx, ldy;
+  int k, TX, TY, colmode, prologue, nacc;
+  float lo, hi, gscale;
+};
+
+template <int J, bool BWD>
+__global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int TX = a.TX, TY = a.TY;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int64_t w4 = a.inner / 4;
+  const int64_t c4base = (int64_t)blockIdx.y * TX * J;
+  const int ph = (a.k > 1) ? (ty % a.k) : 0;
+  const bool active_row_group = ty < TY;
+
+  // per-lane column state
+  float4 b4v[J], bav[J], sv[J];
+  bool cok[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    int64_t c4 = c4base + tx + (int64_t)j * TX;
+    cok[j] = c4 < w4;
+    b4v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bav[j] = b4v[j];
+    sv[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (cok[j]) {
+      int64_t bo = (int64_t)ph * a.inner + c4 * 4;
+      if (a.b4) b4v[j] = *reinterpret_cast<const float4*>(a.b4 + bo);
+      if (!BWD && a.baft) bav[j] = *reinterpret_cast<const float4*>(a.baft + bo);
+      if (a.colmode) {
+        float4 t = *reinterpret_cast<const float4*>(a.s + c4 * 4);
+        sv[j] = make_float4(ofq_lsq_eff_scale(t.x, a.gscale), ofq_lsq_eff_scale(t.y, a.gscale),
+                            ofq_lsq_eff_scale(t.z, a.gscale), ofq_lsq_eff_scale(t.w, a.gscale));
+      }
+    }
+  }
+  float acc_b4[J][4], acc_ba[J][4], acc_ds[J][4];
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc_b4[j][e] = acc_ba[j][e] = acc_ds[j][e] = 0.f;
+  }
+  const float lo = a.lo, hi = a.hi;
+  const int nslot = TX >= 64 ? TX / 64 : 1;
+
+  if (active_row_group) {
+    for (int64_t r = (int64_t)blockIdx.x * TY + ty; r < a.R; r += (int64_t)gridDim.x * TY) {
+      float arow = 1.f;
+      if (!a.colmode) arow = ofq_lsq_eff_scale(a.s[r % a.S], a.gscale);
+      float4 xv[J], gv[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (cok[j]) {
+          int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
+          xv[j] = *reinterpret_cast<const float4*>(a.x + r * a.ldx + col);
+          if (BWD) gv[j] = *reinterpret_cast<const float4*>(a.g + r * a.ldy + col);
+        }
+      }
+      float rowds = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (!cok[j]) continue;
+        const int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
+        float xin[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+        float bb[4] = {b4v[j].x, b4v[j].y, b4v[j].z, b4v[j].w};
+        float sc[4] = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+        if (!BWD) {
+          float ba[4] = {bav[j].x, bav[j].y, bav[j].z, bav[j].w};
+          float out[4];
+          signed char cd[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float xe = a.prologue == 1 ? ofq_gelu(xin[e]) : xin[e];
+            float al = a.colmode ? sc[e] : arow;
+            float q, v;
+            float yi = ofq_lsq_quant(__fadd_rn(xe, bb[e]), al, lo, hi, q, v);
+            out[e] = __fadd_rn(__fmul_rn(yi, al), ba[e]);
+            cd[e] = (signed char)(int)q;   // low 8 bits: int8 for signed ranges, uint8 for unsigned
+          }
+          *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = make_float4(out[0], out[1], out[2], out[3]);
+          if (a.codes) *reinterpret_cast<char4*>(a.codes + r * a.inner + col) = make_char4(cd[0], cd[1], cd[2], cd[3]);
+        } else {
+          float ge[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+          float dxo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float xe = a.prologue == 1 ? ofq_gelu(xin[e]) : xin[e];
+            float al = a.colmode ? sc[e] : arow;
+            float q, v;
+            ofq_lsq_quant(__fadd_rn(xe, bb[e]), al, lo, hi, q, v);
+            bool inr = (v >= lo) && (v <= hi);
+            float dq = inr ? ofq_div(__fmul_rn(ge[e], al), al) : 0.f;   // autograd order: (g*a)/a
+            float dsc = ge[e] * (inr ? (q - v) : q);                    // q == clamp(v) when out of range
+            acc_b4[j][e] += dq;
+            acc_ba[j][e] += ge[e];
+            if (a.colmode) acc_ds[j][e] += dsc; else rowds += dsc;
+            dxo[e] = a.prologue == 1 ? dq * ofq_gelu_grad(xin[e]) : dq;
+          }
+          *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
+        }
+      }
+      if (BWD && !a.colmode) {
+        int w = TX < 64 ? TX : 64;
+        for (int o = w / 2; o > 0; o >>= 1) rowds += __shfl_xor(rowds, o, 64);
+        if ((tx & 63) == 0 || (TX < 64 && tx == 0))
+          a.rowpart[(r * gridDim.y + blockIdx.y) * nslot + (tx >> 6)] = rowds;
+      }
+    }
+  }
+  if (!BWD) return;
+
+  // ---- column partials: one LDS pass per workgroup, reduced over the row-groups of equal phase ----
+  const int ncol = TX * J * 4;                 // columns of this column tile (incl. masked ones)
+  const int nacc = a.nacc;
+  float* base = red + ((size_t)ty * nacc) * ncol;
+  if (active_row_group) {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int c = (tx + j * TX) * 4 + e;
+        base[c] = acc_b4[j][e];
+        base[ncol + c] = acc_ba[j][e];
+        if (nacc == 3) base[2 * ncol + c] = acc_ds[j][e];
+      }
+  }
+  __syncthreads();
+  const int kk = a.k;
+  const int64_t blen = (int64_t)kk * a.inner;
+  for (int idx = threadIdx.x; idx < kk * nacc * ncol; idx += blockDim.x) {
+    int c = idx % ncol;
+    int ac = (idx / ncol) % nacc;
+    int p = idx / (ncol * nacc);
+    int64_t col = c4base * 4 + c;
+    if (col >= a.inner) continue;
+    float sum = 0.f;
+    for (int t = p; t < TY; t += kk) sum += red[((size_t)t * nacc + ac) * ncol + c];
+    a.colpart[((int64_t)blockIdx.x * nacc + ac) * blen + (int64_t)p * a.inner + col] = sum;
+  }
+}
+
+static size_t lsq_lds_bytes(const LsqGeom& g, int nacc) {
+  return (size_t)g.TY * nacc * g.TX * g.J * 4 * sizeof(float);
+}
+
+template <bool BWD>
+static int lsq_launch(const LsqGeom& g, const LsqArgs& a, hipStream_t st) {
+  dim3 grid(g.gx, g.gy), block(g.TX * g.TY);
+  size_t lds = BWD ? lsq_lds_bytes(g, a.nacc) : 0;
+  switch (g.J) {
+    case 1: hipLaunchKernelGGL((lsq_kernel<1, BWD>), grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((lsq_kernel<2, BWD>), grid, block, lds, st, a); break;
+    case 3: hipLaunchKernelGGL((lsq_kernel<3, BWD>), grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL((lsq_kernel<4, BWD>), grid, block, lds, st, a); break;
+  }
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, const float* baft, float* y,
+                           int8_t* codes, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
+                           int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
+                           ofq_stream_t stream) {
+  if (!x || !s || !y || outer <= 0 || S <= 0) return OFQ_EINVAL;
+  if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
+  if ((b4 || baft) && bias_len <= 0) return OFQ_EINVAL;
+  if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
+  LsqGeom g;
+  int rc = lsq_geom(outer * S, inner, (b4 || baft) ? bias_len : 0, &g);
+  if (rc) return rc;
+  LsqArgs a = {};
+  a.x = x; a.s = s; a.b4 = b4; a.baft = baft; a.y = y; a.codes = codes;
+  a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
+  a.colmode = scale_mode; a.prologue = prologue; a.nacc = 0;
+  a.lo = (float)lo; a.hi = (float)hi; a.gscale = gscale;
+  return lsq_launch<false>(g, a, (hipStream_t)stream);
+}
+
+static void lsq_ws_layout(const LsqGeom& g, int64_t R, int64_t inner, int nacc, size_t* row_floats,
+                          size_t* col_floats) {
+  *row_floats = (size_t)R * g.gy * g.nslot;
+  *col_floats = (size_t)g.gx * nacc * g.k * inner;
+}
+
+extern "C" size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, int64_t bias_len, int scale_mode) {
+  LsqGeom g;
+  if (lsq_geom(outer * S, inner, bias_len, &g)) return 0;
+  size_t rf, cf;
+  lsq_ws_layout(g, outer * S, inner, scale_mode ? 3 : 2, &rf, &cf);
+  return (rf + cf) * sizeof(float) + 256;
+}
+
+extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds,
+                           float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx,
+                           int64_t ldy, int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
+                           void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!gy || !x || !s || !dx || !ws || outer <= 0 || S <= 0) return OFQ_EINVAL;
+  if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
+  if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
+  LsqGeom g;
+  int rc = lsq_geom(outer * S, inner, bias_len, &g);
+  if (rc) return rc;
+  const int nacc = scale_mode ? 3 : 2;
+  size_t rf, cf;
+  lsq_ws_layout(g, outer * S, inner, nacc, &rf, &cf);
+  if (ws_bytes < (rf + cf) * sizeof(float)) return OFQ_ENOWS;
+  LsqArgs a = {};
+  a.x = x; a.g = gy; a.s = s; a.b4 = b4; a.dx = dx;
+  a.rowpart = (float*)ws; a.colpart = (float*)ws + rf;
+  a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
+  a.colmode = scale_mode; a.prologue = prologue; a.nacc = nacc;
+  a.lo = (float)lo; a.hi = (float)hi; a.gscale = gscale;
+  hipStream_t st = (hipStream_t)stream;
+  rc = lsq_launch<true>(g, a, st);
+  if (rc) return rc;
+  const int64_t blen = (int64_t)g.k * inner;
+  SumJobs jobs = {};
+  int64_t maxc = 0;
+  if (ds) {
+    if (scale_mode) jobs.j[0] = {a.colpart + 2 * blen, ds, inner, g.gx, (int64_t)nacc * blen, 1, gscale};
+    else jobs.j[0] = {a.rowpart, ds, S, outer, S * (int64_t)g.gy * g.nslot, g.gy * g.nslot, gscale};
+    maxc = jobs.j[0].ncols;
+  }
+  if (db4) { jobs.j[1] = {a.colpart, db4, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f}; if (blen > maxc) maxc = blen; }
+  if (dbaft) { jobs.j[2] = {a.colpart + blen, dbaft, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f}; if (blen > maxc) maxc = blen; }
+  if (maxc > 0) {
+    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(maxc, 16), 3), dim3(256), 0, st, jobs);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,135 @@
+// Column sums (bias gradients) and the CGA step hooks.
+//  - ofq_colsum: db = sum over rows of dY, the autograd of `out += bias` (qlinear.py:71).  HBM-bound, 4 B/elt.
+//  - ofq_cga_*: freeze_outside_boundary_weight_idx (cga.py:450-469) and the grad-mask / restore hooks around
+//    optimizer.step() (cga.py:962-964, :994-997).  The reference needs two .cpu() syncs per tensor for the
+//    loop bounds (cga.py:465); here the global min/max level stays on the device.
+#include "common.h"
+
+#define CS_GY 64
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                             int64_t rows, int64_t cols, int64_t ld) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  const int64_t chunk = ceil_div(rows, (int64_t)gridDim.y);
+  const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) acc += x[r * ld + c];
+  __shared__ float sh[4][64];
+  sh[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+}
+
+extern "C" size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols) { return (size_t)CS_GY * cols * sizeof(float); }
+
+extern "C" int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* ws, size_t ws_bytes,
+                          ofq_stream_t stream) {
+  if (!x || !out || !ws || rows <= 0 || cols <= 0 || ld < cols) return OFQ_EINVAL;
+  if (ws_bytes < ofq_colsum_ws_bytes(rows, cols)) return OFQ_ENOWS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)ceil_div(cols, 64), CS_GY), dim3(256), 0, st, x, (float*)ws,
+                     rows, cols, ld);
+  OFQ_LAUNCH_CHECK();
+  SumJobs jobs = {};
+  jobs.j[0] = {(const float*)ws, out, cols, CS_GY, cols, 1, 1.0f};
+  hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(cols, 16), 1), dim3(256), 0, st, jobs);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- CGA
+__device__ __forceinline__ float cga_row_scale(const float* w, int64_t cols, int lane) {
+  double acc = 0.0;
+  for (int64_t i = lane; i < cols; i += 64) acc += (double)fabsf(w[i]);
+  acc = ofq_wave_sum(acc);
+  return 2.0f * ofq_div((float)acc, (float)cols);                       // cga.py:462
+}
+__device__ __forceinline__ float cga_b4(float wv, float s, float n) {
+  float c = fminf(fmaxf(ofq_div(wv, s), -1.0f), 1.0f - 1e-6f);          // cga.py:455-456
+  return __fsub_rn(__fmul_rn(c, n), 0.5f);                              // cga.py:458
+}
+
+__global__ void cga_range_init_kernel(int32_t* range) { range[0] = 0x7fffffff; range[1] = -0x7fffffff; }
+
+__global__ __launch_bounds__(256) void cga_range_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, float n,
+                                                        int32_t* range) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* w = W + row * cols;
+  const float s = cga_row_scale(w, cols, lane);
+  int lo = 0x7fffffff, hi = -0x7fffffff;
+  for (int64_t i = lane; i < cols; i += 64) {
+    int L = (int)rintf(cga_b4(w[i], s, n));
+    lo = min(lo, L); hi = max(hi, L);
+  }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+  if (lane == 0) { atomicMin(&range[0], lo); atomicMax(&range[1], hi); }
+}
+
+__global__ __launch_bounds__(256) void cga_mask_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, float n,
+                                                       float th_hi, float th_lo, const int32_t* __restrict__ range,
+                                                       float* __restrict__ frozen) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* w = W + row * cols;
+  const float s = cga_row_scale(w, cols, lane);
+  const int imin = range[0], imax = range[1];
+  for (int64_t i = lane; i < cols; i += 64) {
+    const float b4 = cga_b4(w[i], s, n);
+    float notfrozen = 0.f;
+    for (int k = imin; k < imax; ++k) {                                 // np.arange(min, max)  cga.py:465
+      const float d = __fsub_rn(b4, (float)k);
+      notfrozen += (d <= th_hi && d >= th_lo) ? 1.f : 0.f;              // cga.py:466-467
+    }
+    frozen[row * cols + i] = 1.0f - notfrozen;                          // cga.py:469
+  }
+}
+
+extern "C" int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, int bits, float boundary_range,
+                                   float* frozen, int32_t* range_ws, ofq_stream_t stream) {
+  if (!W || !frozen || !range_ws || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float n = (float)(1 << (bits - 1));
+  hipLaunchKernelGGL(cga_range_init_kernel, dim3(1), dim3(1), 0, st, range_ws);
+  hipLaunchKernelGGL(cga_range_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, W, rows, cols, n, range_ws);
+  // python-float thresholds compared against an fp32 tensor are rounded to fp32 first
+  const float th_hi = (float)(0.5 + (double)boundary_range), th_lo = (float)(0.5 - (double)boundary_range);
+  hipLaunchKernelGGL(cga_mask_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, W, rows, cols, n, th_hi,
+                     th_lo, range_ws, frozen);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void cga_mask_grad_save_kernel(float* __restrict__ grad, const float* __restrict__ W,
+                                          const float* __restrict__ frozen, float* __restrict__ saved, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float f = frozen[i], g = grad[i];
+    grad[i] = __fadd_rn(__fmul_rn(__fmul_rn(g, f), 0.0f), __fmul_rn(g, __fsub_rn(1.0f, f)));   // cga.py:962
+    saved[i] = __fmul_rn(W[i], f);                                                             // cga.py:964
+  }
+}
+__global__ void cga_restore_kernel(float* __restrict__ W, const float* __restrict__ frozen,
+                                   const float* __restrict__ saved, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    W[i] = __fadd_rn(__fmul_rn(W[i], __fsub_rn(1.0f, frozen[i])), saved[i]);                   // cga.py:994-997
+}
+
+extern "C" int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, float* saved, int64_t n,
+                                      ofq_stream_t stream) {
+  if (!grad || !W || !frozen || !saved || n <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(cga_mask_grad_save_kernel, dim3((unsigned)min((int64_t)2048, ceil_div(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, grad, W, frozen, saved, n);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n, ofq_stream_t stream) {
+  if (!W || !frozen || !saved || n <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(cga_restore_kernel, dim3((unsigned)min((int64_t)2048, ceil_div(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, W, frozen, saved, n);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

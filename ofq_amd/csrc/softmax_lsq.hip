@@ -1,0 +1,119 @@
+// K10  scale + softmax + unsigned LSQ over attention rows (reference attention.py:96-99, :213-216 and
+// lsq.py:571-602 with all_positive=True).  One wave per row (n <= 256: four strided elements per lane,
+// consecutive lanes on consecutive addresses), 4 rows per workgroup; max / sum / dot products are wave
+// butterflies.  fwd: 4 B read + 8 B written per score (prob is kept for backward); bwd: 8 B read + 4 B
+// written.  Pad columns [n, ld) are written as zeros so the P*V GEMM may read whole float4 groups.
+#include "common.h"
+
+#define SM_MAXE 4
+
+__global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ s,
+                                                              float* __restrict__ prob, float* __restrict__ y,
+                                                              int64_t rows, int n, int64_t ld, int64_t S, float alpha,
+                                                              float hi, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* src = sc + r * ld;
+  float t[SM_MAXE];
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    int c = lane + 64 * e;
+    t[e] = (c < n) ? __fmul_rn(src[c], alpha) : -INFINITY;
+    m = fmaxf(m, t[e]);
+  }
+  m = ofq_wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    int c = lane + 64 * e;
+    t[e] = (c < n) ? expf(t[e] - m) : 0.f;
+    sum += t[e];
+  }
+  sum = ofq_wave_sum(sum);
+  const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    int c = lane + 64 * e;
+    if (c < ld) {
+      float p = 0.f, out = 0.f;
+      if (c < n) {
+        p = ofq_div(t[e], sum);
+        float q, v;
+        float yi = ofq_lsq_quant(p, a, 0.f, hi, q, v);
+        out = __fmul_rn(yi, a);
+      }
+      prob[r * ld + c] = p;
+      y[r * ld + c] = out;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __restrict__ g, const float* __restrict__ prob,
+                                                              const float* __restrict__ s, float* __restrict__ dsc,
+                                                              float* __restrict__ rowpart, int64_t rows, int n,
+                                                              int64_t ld, int64_t S, float alpha, float hi,
+                                                              float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+  float p[SM_MAXE], dq[SM_MAXE];
+  float rowds = 0.f, dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    int c = lane + 64 * e;
+    p[e] = 0.f; dq[e] = 0.f;
+    if (c < n) {
+      p[e] = prob[r * ld + c];
+      float ge = g[r * ld + c];
+      float q, v;
+      ofq_lsq_quant(p[e], a, 0.f, hi, q, v);
+      bool inr = (v >= 0.f) && (v <= hi);
+      dq[e] = inr ? ofq_div(__fmul_rn(ge, a), a) : 0.f;
+      rowds += ge * (inr ? (q - v) : q);
+      dot += dq[e] * p[e];
+    }
+  }
+  rowds = ofq_wave_sum(rowds);
+  dot = ofq_wave_sum(dot);
+  if (lane == 0) rowpart[r] = rowds;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    int c = lane + 64 * e;
+    if (c < ld) dsc[r * ld + c] = (c < n) ? (dq[e] - dot) * p[e] * alpha : 0.f;
+  }
+}
+
+extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
+                                   int64_t ld, int64_t S, float alpha, int hi, float gscale, ofq_stream_t stream) {
+  if (!scores || !s || !prob || !y || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
+    return OFQ_EINVAL;
+  hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows) { return (size_t)rows * sizeof(float) + 256; }
+
+extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
+                                   int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
+                                   void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!g || !prob || !s || !dscores || !ws || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE ||
+      S <= 0 || rows % S)
+    return OFQ_EINVAL;
+  if (ws_bytes < (size_t)rows * sizeof(float)) return OFQ_ENOWS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
+                     (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale);
+  OFQ_LAUNCH_CHECK();
+  if (ds) {
+    SumJobs jobs = {};
+    jobs.j[0] = {(const float*)ws, ds, S, rows / S, S, 1, gscale};
+    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(S, 16), 1), dim3(256), 0, st, jobs);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,78 @@
+// K1  StatsQ weight quantiser (reference: src/quantization/quantizer/statsq.py:133-150).
+// One wave per weight row, 4 rows per workgroup: float4 coalesced loads, fp64 wave reduction of
+// sum|w| (so the fp32 scale is the correctly rounded row mean, independent of lane order), then a
+// second pass over the (L1/L2-resident) row that quantises and writes W_hat, the scale and int8 levels.
+// HBM-bound: 4 B read + 4 B written per weight (+1 B for the optional level).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict__ W, int64_t rows, int64_t cols,
+                                                         float n, float* __restrict__ out,
+                                                         float* __restrict__ scale, int8_t* __restrict__ levels,
+                                                         int scale_given) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* w = W + row * cols;
+  const bool vec = ((cols & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  float s;
+  if (scale_given) {
+    s = scale[row];
+  } else {
+    double acc = 0.0;
+    if (vec) {
+      const float4* w4 = reinterpret_cast<const float4*>(w);
+      for (int64_t i = lane; i < cols / 4; i += 64) {
+        float4 t = w4[i];
+        acc += (double)fabsf(t.x) + (double)fabsf(t.y) + (double)fabsf(t.z) + (double)fabsf(t.w);
+      }
+    } else {
+      for (int64_t i = lane; i < cols; i += 64) acc += (double)fabsf(w[i]);
+    }
+    acc = ofq_wave_sum(acc);
+    float sum = (float)acc;                         // torch.mean: fp32 sum ...
+    float mean = ofq_div(sum, (float)cols);         // ... divided by the count          statsq.py:138
+    s = 2.0f * mean;
+    if (lane == 0) scale[row] = s;
+  }
+  const float cmax = 1.0f - 1e-6f;                  // (clip_val/2) - 1e-6 in fp32      statsq.py:145
+  float* o = out + row * cols;
+  int8_t* lv = levels ? levels + row * cols : nullptr;
+  auto q1 = [&](float wv, float& L) -> float {
+    float v = ofq_div(wv, s);                       // statsq.py:144
+    float c = fminf(fmaxf(v, -1.0f), cmax);         // :145
+    L = rintf(__fsub_rn(__fmul_rn(c, n), 0.5f));    // :147 round(c*n - 0.5), RNE
+    float wq = __fmul_rn(s, ofq_div(__fadd_rn(L, 0.5f), n));
+    return __fadd_rn(__fsub_rn(wq, wv), wv);        // :148 value of Wq.detach() - W.detach() + W
+  };
+  if (vec) {
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    for (int64_t i = lane; i < cols / 4; i += 64) {
+      float4 t = w4[i], r;
+      float L0, L1, L2, L3;
+      r.x = q1(t.x, L0); r.y = q1(t.y, L1); r.z = q1(t.z, L2); r.w = q1(t.w, L3);
+      o4[i] = r;
+      if (lv) {
+        char4 c4 = make_char4((signed char)L0, (signed char)L1, (signed char)L2, (signed char)L3);
+        reinterpret_cast<char4*>(lv)[i] = c4;
+      }
+    }
+  } else {
+    for (int64_t i = lane; i < cols; i += 64) {
+      float L;
+      o[i] = q1(w[i], L);
+      if (lv) lv[i] = (int8_t)L;
+    }
+  }
+}
+
+extern "C" int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
+                              int8_t* levels, int scale_given, ofq_stream_t stream) {
+  if (!W || !out || !scale || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
+  float n = (float)(1 << (bits - 1));
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipLaunchKernelGGL(statsq_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, rows, cols, n, out, scale,
+                     levels, scale_given);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

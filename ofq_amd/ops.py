@@ -1,0 +1,220 @@
+"""Thin Python launchers over the C ABI (include/ofq_hip.h).  No arithmetic happens here: each function
+checks shapes, allocates outputs through torch's caching allocator, and enqueues HIP kernels on
+torch's current stream.  CPU tensors are rejected: the product path has no CPU fallback.
+"""
+import math
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+_lib_handle = None
+_ws = {}
+
+
+def lib():
+    global _lib_handle
+    if _lib_handle is None:
+        _lib_handle = _lib.load()
+    return _lib_handle
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("ofq_amd: %s failed with code %d" % (what, rc))
+
+
+def _dev(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("ofq_amd: %s must live on a HIP device (got %s); the MI355X path has no CPU fallback"
+                           % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("ofq_amd: %s must be float32 (got %s)" % (name, t.dtype))
+    return t
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device):
+    """Per-device scratch, grown on demand.  Kernels that use it are serialised on one stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------ StatsQ
+def statsq_fwd(W, bits, want_levels=False, scale=None):
+    _dev(W, "weight")
+    W = W.contiguous()
+    rows, cols = W.shape
+    out = torch.empty_like(W)
+    given = scale is not None
+    s = scale.contiguous() if given else torch.empty(rows, dtype=torch.float32, device=W.device)
+    lv = torch.empty((rows, cols), dtype=torch.int8, device=W.device) if want_levels else None
+    _chk(lib().ofq_statsq_fwd(W.data_ptr(), rows, cols, bits, out.data_ptr(), s.data_ptr(), _p(lv), int(given),
+                              _stream()), "ofq_statsq_fwd")
+    return out, s, lv
+
+
+# ------------------------------------------------------------------------------------------------ LSQ
+class LsqGeom:
+    """How a tensor maps onto the kernel's [outer][S][inner] view (include/ofq_hip.h, ofq_lsq_fwd)."""
+    __slots__ = ("outer", "S", "inner", "ldx", "ldy", "bias_len", "mode", "lo", "hi", "gscale", "prologue")
+
+    def __init__(self, outer, S, inner, bias_len, mode, lo, hi, M, prologue=0, ldx=None, ldy=None):
+        self.outer, self.S, self.inner = int(outer), int(S), int(inner)
+        self.ldx = int(ldx if ldx is not None else inner)
+        self.ldy = int(ldy if ldy is not None else inner)
+        self.bias_len = int(bias_len)
+        self.mode, self.lo, self.hi = int(mode), int(lo), int(hi)
+        self.gscale = 1.0 / math.sqrt(hi * M)          # lsq.py:582-591: 1/sqrt(thd_pos * M), python double
+        self.prologue = int(prologue)
+
+
+def lsq_fwd(x, s, b4, baft, g, y=None, want_codes=False):
+    _dev(x, "x")
+    if y is None:
+        y = torch.empty((g.outer * g.S, g.ldy), dtype=torch.float32, device=x.device)
+    codes = torch.empty((g.outer * g.S, g.inner), dtype=torch.int8, device=x.device) if want_codes else None
+    _chk(lib().ofq_lsq_fwd(x.data_ptr(), s.data_ptr(), _p(b4), _p(baft), y.data_ptr(), _p(codes), g.outer, g.S,
+                           g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale, g.prologue, _stream()),
+         "ofq_lsq_fwd")
+    return y, codes
+
+
+def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
+    _dev(gy, "grad")
+    dev = x.device
+    if dx is None:
+        dx = torch.empty((g.outer * g.S, g.ldx), dtype=torch.float32, device=dev)
+    ds = torch.empty_like(s)
+    has_bias = g.bias_len > 0 and want_bias_grads
+    db4 = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
+    dbaft = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
+    nbytes = lib().ofq_lsq_bwd_ws_bytes(g.outer, g.S, g.inner, g.bias_len, g.mode)
+    ws = workspace(nbytes, dev)
+    _chk(lib().ofq_lsq_bwd(gy.data_ptr(), x.data_ptr(), s.data_ptr(), _p(b4), dx.data_ptr(), ds.data_ptr(), _p(db4),
+                           _p(dbaft), g.outer, g.S, g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale,
+                           g.prologue, ws.data_ptr(), ws.numel(), _stream()), "ofq_lsq_bwd")
+    return dx, ds, db4, dbaft
+
+
+# ------------------------------------------------------------------------------------------------ softmax + LSQ
+def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M):
+    prob = torch.empty_like(scores)
+    y = torch.empty_like(scores)
+    gscale = 1.0 / math.sqrt(hi * M)
+    _chk(lib().ofq_softmax_lsq_fwd(scores.data_ptr(), s.data_ptr(), prob.data_ptr(), y.data_ptr(), rows, n, ld, S,
+                                   alpha, hi, gscale, _stream()), "ofq_softmax_lsq_fwd")
+    return prob, y
+
+
+def softmax_lsq_bwd(g, prob, s, rows, n, ld, S, alpha, hi, M, inplace=True):
+    dsc = g if inplace else torch.empty_like(g)
+    ds = torch.empty_like(s)
+    gscale = 1.0 / math.sqrt(hi * M)
+    ws = workspace(lib().ofq_softmax_lsq_bwd_ws_bytes(rows), g.device)
+    _chk(lib().ofq_softmax_lsq_bwd(g.data_ptr(), prob.data_ptr(), s.data_ptr(), dsc.data_ptr(), ds.data_ptr(), rows, n,
+                                   ld, S, alpha, hi, gscale, ws.data_ptr(), ws.numel(), _stream()),
+         "ofq_softmax_lsq_bwd")
+    return dsc, ds
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, nb0=1, nb1=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), nkb=1, sAk=0, sBk=0, split_k=1, alpha=1.0, accumulate=False,
+         offA=0, offB=0, offC=0):
+    """Raw launcher; A/B/Cout are base tensors, off* are element offsets into them."""
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * offA
+    d.B = B.data_ptr() + 4 * offB
+    d.C = Cout.data_ptr() + 4 * offC
+    d.bias = _p(bias)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.transA, d.transB = int(transA), int(transB)
+    d.nb0, d.nb1 = nb0, nb1
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.nkb, d.sAk, d.sBk = nkb, sAk, sBk
+    d.split_k, d.alpha, d.accumulate = split_k, alpha, int(accumulate)
+    wsb = lib().ofq_gemm_ws_bytes(C.byref(d))
+    ws = workspace(wsb, A.device) if wsb else None
+    _chk(lib().ofq_gemm_f32(C.byref(d), _p(ws), ws.numel() if ws is not None else 0, _stream()), "ofq_gemm_f32")
+    return Cout
+
+
+def _pick_split(M, N, K, target_wgs=512, bk=32):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128 if N > 64 else 1)
+    split = max(1, min(target_wgs // max(tiles, 1), (K + bk - 1) // bk // 4))
+    return int(split)
+
+
+def linear_fwd(x2d, W, bias=None):
+    """y[M,N] = x2d[M,K] @ W[N,K]^T + bias   (F.linear, qlinear.py:69-71)"""
+    M, K = x2d.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    return gemm(x2d, W, y, M, N, K, x2d.stride(0), W.stride(0), N, transB=True, bias=bias)
+
+
+def linear_bwd_input(dy, W, out=None, accumulate=False):
+    """dx[M,K] = dy[M,N] @ W[N,K]"""
+    M, N = dy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    return gemm(dy, W, out, M, K, N, dy.stride(0), W.stride(0), out.stride(0), accumulate=accumulate)
+
+
+def linear_bwd_weight(dy, x2d):
+    """dW[N,K] = dy[M,N]^T @ x2d[M,K]   (split-K over the token dimension)"""
+    M, N = dy.shape
+    K = x2d.shape[1]
+    dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    return gemm(dy, x2d, dW, N, K, M, dy.stride(0), x2d.stride(0), K, transA=True, split_k=_pick_split(N, K, M))
+
+
+def colsum(x2d):
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    ws = workspace(lib().ofq_colsum_ws_bytes(rows, cols), x2d.device)
+    _chk(lib().ofq_colsum(x2d.data_ptr(), out.data_ptr(), rows, cols, x2d.stride(0), ws.data_ptr(), ws.numel(),
+                          _stream()), "ofq_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CGA
+def cga_freeze_mask(W, bits, boundary_range):
+    _dev(W, "weight")
+    W = W.contiguous()
+    rows, cols = W.shape
+    frozen = torch.empty_like(W)
+    rng = torch.empty(2, dtype=torch.int32, device=W.device)
+    _chk(lib().ofq_cga_freeze_mask(W.data_ptr(), rows, cols, bits, float(boundary_range), frozen.data_ptr(),
+                                   rng.data_ptr(), _stream()), "ofq_cga_freeze_mask")
+    return frozen
+
+
+def cga_mask_grad_save(grad, W, frozen):
+    saved = torch.empty_like(W)
+    _chk(lib().ofq_cga_mask_grad_save(grad.data_ptr(), W.data_ptr(), frozen.data_ptr(), saved.data_ptr(), W.numel(),
+                                      _stream()), "ofq_cga_mask_grad_save")
+    return saved
+
+
+def cga_restore(W, frozen, saved):
+    _chk(lib().ofq_cga_restore(W.data_ptr(), frozen.data_ptr(), saved.data_ptr(), W.numel(), _stream()),
+         "ofq_cga_restore")

@@ -1,0 +1,222 @@
+"""LSQ quantisers — drop-ins for src/quantization/quantizer/lsq.py (LsqQuantizer :515, LsqQuantizer4v :701,
+LsqQuantizer4img :306, LsqQuantizer4Conv2d :384, LsqQuantizer4head_input :448, LsqQuantizerWeight :20).
+
+All six share one fused HIP kernel pair (ofq_lsq_fwd / ofq_lsq_bwd); they differ in how the tensor maps onto
+the kernel's [outer][S][inner] view and in M (the count in the 1/sqrt(hi*M) gradient scale).  The Q-modules
+call `.quant(x, b4, baft, ...)` to fuse the LearnableBias pair (and QMLP's GELU) into the same kernel;
+`.forward(x)` is the reference's plain signature.
+
+The learnable step `s` is created lazily from the first batch exactly like the reference (init_from), so
+`setup_alpha` must run before the optimizer is built (train.py:656-662)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+def _bounds(bit, all_positive):
+    if all_positive:                                                   # lsq.py:519-526
+        return (0, 1) if bit == 1 else (0, 2 ** bit - 1)
+    return (-1, 1) if bit == 1 else (-(2 ** (bit - 1)), 2 ** (bit - 1) - 1)
+
+
+class _LsqFn(torch.autograd.Function):
+    """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
+
+    @staticmethod
+    def forward(ctx, x, s, b4, baft, geom):
+        y, _ = ops.lsq_fwd(x, s, b4, baft, geom)
+        ctx.save_for_backward(x, s, b4)
+        ctx.geom = geom
+        ctx.has_bias = b4 is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, s, b4 = ctx.saved_tensors
+        g = ctx.geom
+        gy = gy.contiguous()
+        dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
+        return dx, ds, db4, dbaft, None
+
+
+class _LsqBase(nn.Module):
+    def __init__(self, bit, all_positive=False, per_channel=True, learnable=True, **kwargs):
+        super().__init__()
+        if bit == 1:
+            raise ValueError("1-bit LSQ (sign) is not on the OFQ hot path")
+        self.bit = bit
+        self.per_channel = per_channel
+        self.all_positive = all_positive
+        self.learnable = learnable
+        self.thd_neg, self.thd_pos = _bounds(bit, all_positive)
+        self.register_parameter("s", None)                              # lsq.py:541
+        self.initialized_alpha = False
+
+    # -- geometry: subclasses say how x maps onto [outer][S][inner] and what M is
+    def _geom(self, x, bias_len, prologue, ldx, ldy):
+        raise NotImplementedError
+
+    def _init_value(self, xin):
+        raise NotImplementedError
+
+    def init_from(self, xin):
+        init_val = self._init_value(xin.detach())
+        self.s = nn.Parameter(init_val.to(xin.device).float().contiguous().clone(), requires_grad=bool(self.learnable))
+        self.initialized_alpha = True
+
+    def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None):
+        """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
+        is a strided column slice)."""
+        if not x.is_cuda:
+            raise RuntimeError("ofq_amd LSQ: input must be on a HIP device; there is no CPU fallback")
+        if ldx is None:
+            x = x.contiguous()
+        shp = tuple(shape) if shape is not None else tuple(x.shape)
+        if not self.initialized_alpha or self.s is None:
+            xin = x.detach().reshape(shp) if ldx is None else x.detach()
+            if prologue == 1:
+                xin = torch.nn.functional.gelu(xin)
+            if b4 is not None:
+                xin = self._add_bias_for_init(xin, b4.detach())
+            self.init_from(xin)
+        geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
+        y = _LsqFn.apply(x, self.s, b4, baft, geom)
+        return y.view(out_shape if out_shape is not None else shp)
+
+    def _add_bias_for_init(self, xin, b4):
+        return xin + b4
+
+    def forward(self, x):
+        return self.quant(x)
+
+    def extra_repr(self):
+        return "bit=%d, all_positive=%s, s_learnable=%s, per_channel=%s" % (self.bit, self.all_positive,
+                                                                           self.learnable, self.per_channel)
+
+
+class LsqQuantizer(_LsqBase):
+    """Per-"token" step: s indexed by x.shape[-2] (lsq.py:556, :575).  x is (..., S, inner)."""
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        S, inner = shp[-2], shp[-1]
+        n = 1
+        for d in shp:
+            n *= d
+        outer = n // (S * inner)
+        M = n // S                                                       # lsq.py:583-588
+        return ops.LsqGeom(outer, S, inner, bias_len, 0, self.thd_neg, self.thd_pos, M, prologue, ldx, ldy)
+
+    def _init_value(self, x):
+        k = 4 if self.all_positive else 2                                # lsq.py:547-554
+        a = x.abs().mean(dim=-1)
+        while a.dim() > 1:
+            a = a.mean(dim=0)
+        return k * a / (self.thd_pos ** 0.5)
+
+    def _add_bias_for_init(self, xin, b4):
+        # bias over the flattened trailing axes: b4 has k*inner entries, row r uses block r % k
+        inner = xin.shape[-1]
+        k = b4.numel() // inner
+        if k == 1:
+            return xin + b4
+        S = xin.shape[-2]
+        return (xin.reshape(-1, S // k, k, inner) + b4.view(k, inner)).reshape(xin.shape)
+
+
+class LsqQuantizer4v(_LsqBase):
+    """Per-channel step: s indexed by the last dim (lsq.py:742, :761-766); M = product of leading dims."""
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        inner = shp[-1]
+        n = 1
+        for d in shp:
+            n *= d
+        rows = n // inner
+        return ops.LsqGeom(rows, 1, inner, bias_len, 1, self.thd_neg, self.thd_pos, rows, prologue, ldx, ldy)
+
+    def _init_value(self, x):
+        k = 4 if self.all_positive else 2                                # lsq.py:732-737
+        a = x.abs()
+        while a.dim() > 1:
+            a = a.mean(dim=0)
+        return k * a / (self.thd_pos ** 0.5)
+
+    def _add_bias_for_init(self, xin, b4):
+        return xin + b4
+
+
+class LsqQuantizer4img(_LsqBase):
+    """8-bit image quantiser, step per input channel, signedness latched from the data (lsq.py:306-382)."""
+
+    def __init__(self, bit=8, all_positive=False, per_channel=True, learnable=True, **kwargs):
+        super().__init__(bit, all_positive, per_channel, learnable)
+        self.register_buffer("signed", torch.zeros(1))                   # lsq.py:310
+
+    def _latch(self, xin):
+        # lsq.py:338-355 (one host sync per call in the reference as well; the stem runs once per step)
+        if float(self.signed) == 0 and bool((xin.min() < -1e-5).item()):
+            self.signed.data.fill_(1)
+        self.thd_neg, self.thd_pos = _bounds(self.bit, float(self.signed) == 0)
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        B, Cc, Hh, Ww = shp
+        return ops.LsqGeom(B, Cc, Hh * Ww, bias_len, 0, self.thd_neg, self.thd_pos, B * Hh * Ww, prologue)
+
+    def _init_value(self, x):
+        return 2 * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=0) / (self.thd_pos ** 0.5)    # lsq.py:322
+
+    def _add_bias_for_init(self, xin, b4):
+        return xin + b4.view(xin.shape[-1], xin.shape[-2])               # qbias.py:21
+
+    def quant(self, x, b4=None, baft=None, **kw):
+        xin = x.detach() if b4 is None else x.detach() + b4.detach().view(x.shape[-1], x.shape[-2])
+        self._latch(xin)
+        return super().quant(x, b4, baft, **kw)
+
+
+class LsqQuantizer4Conv2d(_LsqBase):
+    """Conv weight (O,I,kh,kw), step per out-channel, M = I*kh*kw (lsq.py:384-446)."""
+
+    def __init__(self, bit=8, all_positive=False, per_channel=True, learnable=True, **kwargs):
+        super().__init__(bit, False, per_channel, learnable)
+        self.all_positive = all_positive
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        O = shp[0]
+        inner = 1
+        for d in shp[1:]:
+            inner *= d
+        return ops.LsqGeom(1, O, inner, 0, 0, self.thd_neg, self.thd_pos, inner)
+
+    def _init_value(self, x):
+        return 2 * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=-1) / (self.thd_pos ** 0.5)   # lsq.py:405
+
+
+class LsqQuantizerWeight(_LsqBase):
+    """2-D weight, step per row, M = in_features (lsq.py:20-109)."""
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        return ops.LsqGeom(1, shp[0], shp[1], 0, 0, self.thd_neg, self.thd_pos, shp[1])
+
+    def _init_value(self, x):
+        return 2 * x.abs().mean(dim=-1) / (self.thd_pos ** 0.5)          # lsq.py:54
+
+
+class LsqQuantizer4head_input(_LsqBase):
+    """Per-tensor scalar step, M = numel (lsq.py:448-513)."""
+
+    def _geom(self, shp, bias_len, prologue, ldx, ldy):
+        n = 1
+        for d in shp:
+            n *= d
+        inner = shp[-1]
+        return ops.LsqGeom(n // inner, 1, inner, bias_len, 0, self.thd_neg, self.thd_pos, n, prologue)
+
+    def _init_value(self, x):
+        return (x.abs().mean() * 2 / (self.thd_pos ** 0.5)).reshape(1)   # lsq.py:480
+
+    def _add_bias_for_init(self, xin, b4):
+        return xin + b4

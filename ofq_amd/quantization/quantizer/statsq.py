@@ -1,0 +1,50 @@
+"""StatsQuantizer — drop-in for src/quantization/quantizer/statsq.py:122-150 (and its CGA twin :154-193,
+which is numerically identical in value and gradient).  Forward is one HIP kernel
+(ofq_statsq_fwd); backward is the straight-through identity, so no kernel runs."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+class _StatsQFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, bits, holder):
+        out, s, _ = ops.statsq_fwd(weight, bits)
+        holder._s_dev = s
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None          # statsq.py:148: Wq.detach() - W.detach() + W  => dW = g
+
+
+class StatsQuantizer(nn.Module):
+    def __init__(self, num_bits, clip_learnable):
+        super().__init__()
+        self.num_bits = num_bits
+        self.clip_val = nn.Parameter(torch.Tensor([2.0]), requires_grad=False)     # statsq.py:126-128
+        self._s_dev = None
+
+    @property
+    def s(self):
+        """Per-row scale of the last forward as a CPU tensor (the reference copies it to the host on every
+        call, statsq.py:143; here the copy happens only when somebody reads it)."""
+        return None if self._s_dev is None else self._s_dev.detach().cpu()
+
+    def forward(self, weight):
+        if weight.dim() != 2:
+            raise ValueError("StatsQuantizer: only 2-D weights are on the hot path (statsq.py:137-138)")
+        return _StatsQFn.apply(weight, self.num_bits, self)
+
+    def extra_repr(self):
+        return "num_bits=%d" % self.num_bits
+
+
+class StatsQuantizer_specific_4_qkreparam_cga(StatsQuantizer):
+    """statsq.py:154-193.  Its training-time boundary loop only touches a detached branch, so values and
+    gradients equal StatsQuantizer bit for bit (pinned by tests/golden g1 'G10')."""
+
+    def __init__(self, num_bits, clip_learnable, boundaryRange=0.005):
+        super().__init__(num_bits, clip_learnable)
+        self.boundaryRange = boundaryRange

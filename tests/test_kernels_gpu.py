@@ -1,0 +1,331 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the oracle / the reference goldens.
+Integer levels and everything that is pure elementwise fp32 are compared BIT-EXACTLY; reductions and GEMMs
+within 1e-5 (the tier's bound is 1e-3).  Run on the MI355X box:  pytest -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import ofq_oracle as O
+from detgen import det_uniform, det_normalish
+from util import load_golden, group, case_names, T, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "the -m gpu tests need a HIP device"
+    from ofq_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def G(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ StatsQ
+def test_statsq_golden_bit_exact_given_scale(ops):
+    d = load_golden("g1_statsq")
+    for c in range(int(d["ncases"])):
+        g = group(d, "c%d" % c)
+        bits = int(g["shape"][2])
+        out, s, lv = ops.statsq_fwd(G(g["W"]), bits, want_levels=True, scale=G(g["s"]))
+        assert torch.equal(lv.cpu(), T(g["L"])), c
+        assert torch.equal(out.cpu(), T(g["y"])), c
+
+
+def test_statsq_golden_own_scale(ops):
+    d = load_golden("g1_statsq")
+    for c in range(int(d["ncases"])):
+        g = group(d, "c%d" % c)
+        bits = int(g["shape"][2])
+        out, s, lv = ops.statsq_fwd(G(g["W"]), bits, want_levels=True)
+        assert rel_err(s.cpu(), g["s"]) < 5e-7
+        # a level may only differ where c*n-0.5 sits within an ulp of a rounding tie
+        bad = (lv.cpu() != T(g["L"]))
+        assert bad.float().mean() < 1e-4
+        assert rel_err(out.cpu(), g["y"]) < 1e-6 or bad.any()
+
+
+def test_statsq_real_shapes_vs_oracle(ops):
+    for (r, c, bits, seed) in [(384, 384, 2, 1), (1536, 384, 2, 2), (384, 1536, 3, 3), (2304, 384, 2, 4), (576, 192, 4, 5)]:
+        W = T(det_normalish((r, c), seed, 0.02))
+        y, L, s = O.statsq(W, bits)
+        out, sg, lv = ops.statsq_fwd(W.cuda(), bits, want_levels=True)
+        assert rel_err(sg.cpu(), s.squeeze()) < 5e-7
+        mism = (lv.cpu().int() != L).float().mean().item()
+        assert mism < 1e-5, (r, c, mism)
+        out2, _, lv2 = ops.statsq_fwd(W.cuda(), bits, want_levels=True, scale=s.squeeze().cuda())
+        assert torch.equal(lv2.cpu().int(), L)
+        assert torch.equal(out2.cpu(), y.detach())
+
+
+# ------------------------------------------------------------------------------------------------ LSQ
+def _golden_geom(ops, name, g):
+    x = g["x"]
+    lo, hi = int(g["lohi"][0]), int(g["lohi"][1])
+    ns = g["s"].size
+    M = x.size // ns
+    if name.startswith("token"):
+        S, inner = x.shape[-2], x.shape[-1]
+        return ops.LsqGeom(x.size // (S * inner), S, inner, 0, 0, lo, hi, M)
+    if name.startswith("chan"):
+        return ops.LsqGeom(x.size // x.shape[-1], 1, x.shape[-1], 0, 1, lo, hi, M)
+    if name.startswith("img"):
+        return ops.LsqGeom(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], 0, 0, lo, hi, M)
+    if name == "convw":
+        return ops.LsqGeom(1, x.shape[0], x.size // x.shape[0], 0, 0, lo, hi, M)
+    if name == "roww":
+        return ops.LsqGeom(1, x.shape[0], x.shape[1], 0, 0, lo, hi, M)
+    if name == "tensor":
+        return ops.LsqGeom(x.shape[0], 1, x.shape[1], 0, 0, lo, hi, M)
+    raise AssertionError(name)
+
+
+def test_lsq_golden_all_variants_bit_exact(ops):
+    d = load_golden("g2_lsq")
+    n = 0
+    for nme in case_names(d):
+        g = group(d, nme)
+        geom = _golden_geom(ops, nme, g)
+        x, s, gy = G(g["x"]), G(g["s"]).reshape(-1), G(g["g"])
+        y, codes = ops.lsq_fwd(x, s, None, None, geom, want_codes=True)
+        assert torch.equal(y.cpu().reshape(g["y"].shape), T(g["y"])), nme
+        dx, ds, _, _ = ops.lsq_bwd(gy, x, s, None, geom)
+        assert torch.equal(dx.cpu().reshape(g["dx"].shape), T(g["dx"])), nme
+        assert rel_err(ds.cpu().reshape(-1), g["ds"].reshape(-1)) < 1e-5, nme
+        # integer levels == oracle levels, and inside [lo, hi]
+        lo, hi = geom.lo, geom.hi
+        cview = codes.view(torch.uint8) if lo == 0 else codes       # unsigned ranges are stored as uint8
+        assert int(cview.min()) >= lo and int(cview.max()) <= hi
+        n += 1
+    assert n >= 25
+
+
+def _oracle_lsq_sandwich(x, s, b4, baft, mode, bits, unsigned, gelu, H=1):
+    xx = torch.nn.functional.gelu(x) if gelu else x
+    xx = xx + b4
+    if mode == "token":
+        B, N, Cw = xx.shape
+        y = O.lsq_token(xx.reshape(B, N * H, Cw // H), s, bits, unsigned).reshape(B, N, Cw)
+    else:
+        y = O.lsq_channel(xx, s, bits, unsigned)
+    return y + baft
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=4, N=198, C=384, H=1, mode="token", bits=2, unsigned=False, gelu=False),
+    dict(B=3, N=198, C=1536, H=1, mode="token", bits=2, unsigned=True, gelu=True),
+    dict(B=2, N=198, C=2304, H=6, mode="token", bits=2, unsigned=False, gelu=False),     # qkx: s per (token, head)
+    dict(B=4, N=198, C=384, H=1, mode="channel", bits=2, unsigned=False, gelu=False),
+    dict(B=5, N=198, C=192, H=1, mode="token", bits=4, unsigned=False, gelu=False),
+    dict(B=2, N=198, C=576, H=3, mode="token", bits=4, unsigned=False, gelu=False),
+    dict(B=2, N=198, C=768, H=1, mode="token", bits=3, unsigned=True, gelu=True),
+    dict(B=3, N=50, C=24, H=1, mode="channel", bits=3, unsigned=False, gelu=False),
+])
+def test_lsq_sandwich_vs_oracle(ops, case):
+    B, N, C, H = case["B"], case["N"], case["C"], case["H"]
+    bits, unsigned, gelu = case["bits"], case["unsigned"], case["gelu"]
+    lo, hi = O.lsq_bounds(bits, unsigned)
+    x = T(det_normalish((B, N, C), 11, 1.0))
+    b4 = T(det_uniform((C,), 12, -0.05, 0.05))
+    baft = T(det_uniform((C,), 13, -0.05, 0.05))
+    if case["mode"] == "token":
+        ns = N * H
+        s0 = O.lsq_token_init((torch.nn.functional.gelu(x) if gelu else x).reshape(B, N * H, C // H), bits, unsigned)
+        geom = ops.LsqGeom(B, N * H, C // H, C, 0, lo, hi, B * C // H, prologue=int(gelu))
+    else:
+        ns = C
+        s0 = O.lsq_channel_init(x, bits)
+        geom = ops.LsqGeom(B * N, 1, C, C, 1, lo, hi, B * N, prologue=int(gelu))
+    s = (s0 * T(det_uniform((ns,), 14, 0.7, 1.1))).contiguous()
+    xr = x.clone().requires_grad_(True)
+    sr, b4r, baftr = s.clone().requires_grad_(True), b4.clone().requires_grad_(True), baft.clone().requires_grad_(True)
+    y = _oracle_lsq_sandwich(xr, sr, b4r, baftr, case["mode"], bits, unsigned, gelu, H)
+    gy = T(det_uniform((B, N, C), 15, -1.0, 1.0))
+    (y * gy).sum().backward()
+
+    yg, codes = ops.lsq_fwd(x.cuda(), s.cuda(), b4.cuda(), baft.cuda(), geom, want_codes=True)
+    dx, ds, db4, dbaft = ops.lsq_bwd(gy.cuda(), x.cuda(), s.cuda(), b4.cuda(), geom)
+    yg, dx = yg.cpu().reshape(B, N, C), dx.cpu().reshape(B, N, C)
+    if not gelu:
+        assert torch.equal(yg, y.detach())
+        assert torch.equal(dx, xr.grad)
+    else:
+        # erf differs in the last ulp between libm and the device: levels may flip on exact ties only
+        flips = (yg != y.detach()).float().mean().item()
+        assert flips < 1e-4
+        assert rel_err(dx, xr.grad) < 1e-3 or flips > 0
+    assert rel_err(ds.cpu(), sr.grad) < 2e-4 if gelu else rel_err(ds.cpu(), sr.grad) < 1e-5
+    assert rel_err(db4.cpu(), b4r.grad) < 1e-5 or gelu
+    assert rel_err(dbaft.cpu(), baftr.grad) < 1e-5
+    assert int(codes.min()) >= lo and int(codes.max()) <= hi
+
+
+def test_lsq_strided_slices_of_qkv(ops):
+    # q/k/v thirds of a [B*N, 3C] projection quantised in place (attention.py:72-81)
+    B, N, C, bits = 3, 198, 192, 4
+    lo, hi = O.lsq_bounds(bits, False)
+    qkv = T(det_normalish((B, N, 3 * C), 21, 1.0))
+    b4 = T(det_uniform((3 * C,), 22, -0.05, 0.05))
+    s = O.lsq_token_init(qkv[..., :C], bits, False) * 0.9
+    for part in range(2):
+        xs = qkv[..., part * C:(part + 1) * C]
+        ref = O.lsq_token(xs + b4[part * C:(part + 1) * C], s, bits, False)
+        geom = ops.LsqGeom(B, N, C, C, 0, lo, hi, B * C, ldx=3 * C, ldy=C)
+        xg = qkv.cuda()
+        view = xg.view(-1)[part * C:]
+        y, _ = ops.lsq_fwd(view, s.cuda(), b4[part * C:(part + 1) * C].cuda().contiguous(), None, geom)
+        assert torch.equal(y.cpu().reshape(B, N, C), ref)
+
+
+# ------------------------------------------------------------------------------------------------ softmax + LSQ
+@pytest.mark.parametrize("shape", [(2, 6, 198, 2), (3, 3, 198, 4), (2, 2, 7, 2), (1, 2, 49, 3)])
+def test_softmax_lsq_vs_oracle(ops, shape):
+    B, H, N, bits = shape
+    ld = (N + 3) // 4 * 4
+    lo, hi = O.lsq_bounds(bits, True)
+    sc = T(det_normalish((B, H, N, N), 31, 3.0))
+    alpha = 0.125
+    p0 = torch.softmax(sc * alpha, -1)
+    s = (O.lsq_token_init(p0, bits, True) * T(det_uniform((N,), 32, 0.5, 1.0))).contiguous()
+    scr = sc.clone().requires_grad_(True)
+    sr = s.clone().requires_grad_(True)
+    prob = torch.softmax(scr * alpha, -1)
+    y = O.lsq_token(prob, sr, bits, True)
+    gy = T(det_uniform((B, H, N, N), 33, -1.0, 1.0))
+    (y * gy).sum().backward()
+
+    pad = torch.zeros(B, H, N, ld)
+    pad[..., :N] = sc
+    probg, yg = ops.softmax_lsq_fwd(pad.cuda(), s.cuda(), B * H * N, N, ld, N, alpha, hi, B * H * N)
+    assert rel_err(probg.cpu()[..., :N], prob.detach()) < 1e-6
+    assert float(probg.cpu()[..., N:].abs().max() if ld > N else 0.0) == 0.0
+    flips = (yg.cpu()[..., :N] != y.detach()).float().mean().item()
+    assert flips < 2e-4, flips
+    gpad = torch.zeros(B, H, N, ld)
+    gpad[..., :N] = gy
+    dsc, ds = ops.softmax_lsq_bwd(gpad.cuda(), probg, s.cuda(), B * H * N, N, ld, N, alpha, hi, B * H * N, inplace=False)
+    assert rel_err(dsc.cpu()[..., :N], scr.grad) < 2e-3 if flips > 0 else rel_err(dsc.cpu()[..., :N], scr.grad) < 1e-5
+    assert rel_err(ds.cpu(), sr.grad) < 2e-3 if flips > 0 else rel_err(ds.cpu(), sr.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _ref_mm(a, b):
+    return (a.double() @ b.double()).float()
+
+
+@pytest.mark.parametrize("mnk", [(256, 384, 384), (396, 1536, 384), (200, 384, 1536), (198, 198, 384), (198, 64, 198),
+                                 (37, 29, 50), (130, 70, 33), (64, 2304, 384)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_all_layouts(ops, mnk, ta, tb):
+    M, N, K = mnk
+    A = T(det_normalish((K, M) if ta else (M, K), 41, 1.0))
+    Bm = T(det_normalish((N, K) if tb else (K, N), 42, 1.0))
+    bias = T(det_uniform((N,), 43))
+    ref = _ref_mm(A.t() if ta else A, Bm.t() if tb else Bm) + bias
+    Cg = torch.empty(M, N, device="cuda")
+    ops.gemm(A.cuda(), Bm.cuda(), Cg, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb, bias=bias.cuda())
+    assert rel_err(Cg.cpu(), ref) < 1e-5
+
+
+def test_gemm_is_an_exact_fmaf_chain_on_integers(ops):
+    # small-integer operands: every partial sum is exact in fp32, so the result must be exact
+    M, N, K = 256, 128, 384
+    A = torch.from_numpy(np.random.RandomState(0).randint(-2, 2, (M, K)).astype(np.float32))
+    Bm = torch.from_numpy(np.random.RandomState(1).randint(-3, 4, (N, K)).astype(np.float32))
+    Cg = torch.empty(M, N, device="cuda")
+    ops.gemm(A.cuda(), Bm.cuda(), Cg, M, N, K, K, K, N, transB=True)
+    assert torch.equal(Cg.cpu(), (A.double() @ Bm.double().t()).float())
+
+
+def test_gemm_asymmetric_identity_detects_transposes(ops):
+    M = N = K = 64
+    A = torch.eye(64)
+    Bm = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64)     # asymmetric
+    Cg = torch.empty(M, N, device="cuda")
+    ops.gemm(A.cuda(), Bm.cuda(), Cg, M, N, K, K, N, N)
+    assert torch.equal(Cg.cpu(), Bm)
+
+
+def test_gemm_splitk_and_linear_helpers(ops):
+    M, N, K = 4 * 198, 384, 1536
+    x = T(det_normalish((M, K), 51, 1.0))
+    W = T(det_normalish((N, K), 52, 0.05))
+    b = T(det_uniform((N,), 53))
+    dy = T(det_normalish((M, N), 54, 1.0))
+    y = ops.linear_fwd(x.cuda(), W.cuda(), b.cuda())
+    assert rel_err(y.cpu(), _ref_mm(x, W.t()) + b) < 1e-5
+    dx = ops.linear_bwd_input(dy.cuda(), W.cuda())
+    assert rel_err(dx.cpu(), _ref_mm(dy, W)) < 1e-5
+    dW = ops.linear_bwd_weight(dy.cuda(), x.cuda())
+    assert rel_err(dW.cpu(), _ref_mm(dy.t(), x)) < 1e-5
+    dW2 = torch.empty(N, K, device="cuda")
+    ops.gemm(dy.cuda(), x.cuda(), dW2, N, K, M, N, K, K, transA=True, split_k=7)
+    assert rel_err(dW2.cpu(), _ref_mm(dy.t(), x)) < 1e-5
+    assert rel_err(ops.colsum(dy.cuda()).cpu(), dy.double().sum(0).float()) < 1e-5
+
+
+def test_gemm_batched_attention_shapes(ops):
+    B, H, N, C = 2, 3, 198, 96
+    d = C // H
+    Np = 200
+    xq = T(det_normalish((B, N, C), 61, 1.0))
+    qkx = T(det_normalish((B, N, H, C), 62, 1.0))
+    # S[b,h,n,m] = sum_c xq[b,n,c] qkx[b,m,h,c]                      (attention.py:210)
+    S = torch.zeros(B, H, N, Np, device="cuda")
+    ops.gemm(xq.cuda(), qkx.cuda(), S, N, N, C, C, H * C, Np, transB=True, nb0=B, nb1=H, sA=(N * C, 0),
+             sB=(N * H * C, C), sC=(H * N * Np, N * Np))
+    ref = torch.einsum("bnc,bmhc->bhnm", xq.double(), qkx.double()).float()
+    assert rel_err(S.cpu()[..., :N], ref) < 1e-5
+    # O[b,n,h*d+j] = sum_m P[b,h,n,m] v[b,m,h*d+j]                   (attention.py:219)
+    P = torch.zeros(B, H, N, Np)
+    P[..., :N] = T(det_uniform((B, H, N, N), 63, 0.0, 1.0))
+    v = T(det_normalish((B, N, C), 64, 1.0))
+    Og = torch.empty(B, N, C, device="cuda")
+    ops.gemm(P.cuda(), v.cuda(), Og, N, d, N, Np, C, C, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * C, d),
+             sC=(N * C, d))
+    refO = (P[..., :N].double() @ v.double().reshape(B, N, H, d).permute(0, 2, 1, 3)).transpose(1, 2).reshape(B, N, C)
+    assert rel_err(Og.cpu(), refO.float()) < 1e-5
+    # dxq[b,n,c] = sum_h sum_m dS[b,h,n,m] qkx[b,m,h,c]   (k-batched accumulation over heads)
+    dS = torch.zeros(B, H, N, Np)
+    dS[..., :N] = T(det_normalish((B, H, N, N), 65, 1.0))
+    dxq = torch.empty(B, N, C, device="cuda")
+    ops.gemm(dS.cuda(), qkx.cuda(), dxq, N, C, N, Np, H * C, C, nb0=B, sA=(H * N * Np, 0), sB=(N * H * C, 0),
+             sC=(N * C, 0), nkb=H, sAk=N * Np, sBk=C)
+    refdx = torch.einsum("bhnm,bmhc->bnc", dS[..., :N].double(), qkx.double()).float()
+    assert rel_err(dxq.cpu(), refdx) < 1e-5
+    # accumulate flag
+    ops.gemm(dS.cuda(), qkx.cuda(), dxq, N, C, N, Np, H * C, C, nb0=B, sA=(H * N * Np, 0), sB=(N * H * C, 0),
+             sC=(N * C, 0), nkb=H, sAk=N * Np, sBk=C, accumulate=True)
+    assert rel_err(dxq.cpu(), 2 * refdx) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ CGA
+def test_cga_golden_bit_exact(ops):
+    d = load_golden("g8_cga")
+    for c in range(int(d["ncases"])):
+        g = group(d, "c%d" % c)
+        bits, br = int(g["meta"][2]), float(g["br"])
+        W = G(g["W"])
+        frz = ops.cga_freeze_mask(W, bits, br)
+        assert torch.equal(frz.cpu(), T(g["frz"])), c
+        grad = G(g["g"]).clone()
+        saved = ops.cga_mask_grad_save(grad, W, frz)
+        assert torch.equal(grad.cpu(), T(g["gm"]))
+        Wp = torch.nn.Parameter(W.clone())
+        opt = torch.optim.AdamW([Wp], lr=1e-3, weight_decay=0.05)
+        Wp.grad = grad
+        opt.step()
+        ops.cga_restore(Wp.data, frz, saved)
+        assert rel_err(Wp.detach().cpu(), g["W_after"]) < 1e-6
+        fm = T(g["frz"]) == 1
+        assert torch.equal(Wp.detach().cpu()[fm], T(g["W"])[fm])      # frozen weights are restored exactly
+
+
+def test_cpu_tensors_are_rejected_loudly(ops):
+    with pytest.raises(RuntimeError):
+        ops.statsq_fwd(torch.zeros(4, 8), 2)
