@@ -1,0 +1,188 @@
+"""fp32 ViT skeleton that the quantised modules are grafted onto — the host-side counterpart of
+src/deit_vision_transformer.py (Mlp :53, Attention :85, Block :132, VisionTransformer :168) with the same
+attribute / state-dict names, so checkpoints and `replace_module_by_qmodule_deit` name lists carry over.
+timm is not a dependency: PatchEmbed / to_2tuple / trunc_normal_ are the few lines needed from it.
+LayerNorm, residual adds, token concat and the un-quantised teacher run on stock PyTorch-ROCm ops."""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class PatchEmbed(nn.Module):
+    """Image -> (B, num_patches, embed_dim): conv(k = s = patch) then flatten/transpose (timm 0.5.4)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True):
+        super().__init__()
+        self.img_size = to_2tuple(img_size)
+        self.patch_size = to_2tuple(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        x = self.proj(x)
+        if self.flatten:
+            x = x.flatten(2).transpose(1, 2)
+        return self.norm(x)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.in_features = in_features
+        self.hidden_features = hidden_features
+        self.out_features = out_features
+        self.drop = drop
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        p1, p2 = to_2tuple(drop)
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.drop1 = nn.Dropout(p1)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop2 = nn.Dropout(p2)
+
+    def forward(self, x):
+        return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0., qqkkvv=False):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.qqkkvv = qqkkvv
+        if qqkkvv:
+            raise ValueError("qqkkvv score outputs belong to the unused kd_hard_and_soft 2/3 losses (out of scope)")
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        attn = ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        x = (self.attn_drop(attn) @ v).transpose(1, 2).reshape(B, N, C)
+        return self.proj_drop(self.proj(x)), None
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, qqkkvv=False, LN_affine=True, **_):
+        super().__init__()
+        if drop_path > 0.:
+            raise ValueError("stochastic depth is 0 in every OFQ recipe; DropPath is not built")
+        self.norm1 = norm_layer(dim, elementwise_affine=LN_affine) if norm_layer is not None else nn.Identity()
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop,
+                              qqkkvv=qqkkvv)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim, elementwise_affine=LN_affine) if norm_layer is not None else nn.Identity()
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.qqkkvv = qqkkvv
+
+    def forward(self, x):
+        y, info = self.attn(self.norm1(x))
+        x = x + y
+        x = x + self.mlp(self.norm2(x))
+        return x, info
+
+
+def _init_vit_weights(module):
+    if isinstance(module, nn.Linear):
+        trunc_normal_(module.weight, std=.02)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.LayerNorm) and module.elementwise_affine:
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., embed_layer=PatchEmbed, norm_layer=None, act_layer=None,
+                 weight_init='', qqkkvv=False, LN_affine=True):
+        super().__init__()
+        if representation_size:
+            raise ValueError("pre_logits representation layer is not used by DeiT")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 2 if distilled else 1
+        self.qqkkvv = qqkkvv
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if distilled else None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer, act_layer=act_layer,
+                  qqkkvv=qqkkvv, LN_affine=LN_affine) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else nn.Identity()
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        if distilled:
+            self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
+        self.init_weights()
+
+    def init_weights(self):
+        trunc_normal_(self.pos_embed, std=.02)
+        if self.dist_token is not None:
+            trunc_normal_(self.dist_token, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit_weights)
+
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    def _tokens(self, x):
+        x = self.patch_embed(x)
+        B = x.shape[0]
+        parts = [self.cls_token.expand(B, -1, -1)]
+        if self.dist_token is not None:
+            parts.append(self.dist_token.expand(B, -1, -1))
+        parts.append(x)
+        return self.pos_drop(torch.cat(parts, dim=1) + self.pos_embed)
+
+    def forward_features(self, x):
+        x = self._tokens(x)
+        attn_matrixs, feats = [], []
+        for blk in self.blocks:
+            x, a = blk(x)
+            attn_matrixs.append(a)
+            feats.append(x)
+        x = self.norm(x)
+        if self.dist_token is None:
+            return self.pre_logits(x[:, 0]), attn_matrixs, feats
+        return x[:, 0], x[:, 1], attn_matrixs, feats
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        if self.head_dist is not None:
+            cls_x, x_dist = self.head(x[0]), self.head_dist(x[1])
+            if self.training and not torch.jit.is_scripting():
+                return (cls_x, x_dist), x[2]
+            return (cls_x + x_dist) / 2, x[2]
+        return self.head(x[0]), x[1]

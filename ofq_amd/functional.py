@@ -1,0 +1,220 @@
+"""Module-granularity autograd Functions over the HIP kernels (ofq_amd/ops.py).
+
+The reference's autograd graph has ~18 000 ATen nodes per step; here a transformer block is
+about twenty Function nodes, each one or two kernel launches, with hand-derived backward products.
+Shapes: B batch, N tokens, C channels, H heads, d = C/H, Np = N rounded up to a multiple of 4 (row stride
+of the attention matrices, so that their rows stay 16-byte aligned for float4 loads).
+"""
+import torch
+
+from . import ops
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x_hat @ W_hat^T + bias (qlinear.py:69-71) on already fake-quantised operands."""
+
+    @staticmethod
+    def forward(ctx, xq, Wq, bias):
+        shp = xq.shape
+        x2d = xq.reshape(-1, shp[-1])
+        y = ops.linear_fwd(x2d, Wq, bias)
+        ctx.save_for_backward(x2d, Wq)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = shp
+        return y.view(*shp[:-1], Wq.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, Wq = ctx.saved_tensors
+        dy2d = dy.reshape(-1, dy.shape[-1])
+        if not dy2d.is_contiguous():
+            dy2d = dy2d.contiguous()
+        dx = ops.linear_bwd_input(dy2d, Wq) if ctx.needs_input_grad[0] else None
+        dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy2d) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return (dx.view(ctx.in_shape) if dx is not None else None), dW, db
+
+
+class WqkFn(torch.autograd.Function):
+    """W_qk[h] = W_q[h]^T @ W_k[h]  ->  (H*C, C)   (attention.py:190-194)."""
+
+    @staticmethod
+    def forward(ctx, Wq, Wk, H):
+        C = Wq.shape[1]
+        d = Wq.shape[0] // H
+        out = torch.empty((H * C, C), dtype=torch.float32, device=Wq.device)
+        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0))
+        ctx.save_for_backward(Wq, Wk)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Wq, Wk = ctx.saved_tensors
+        H = ctx.H
+        C = Wq.shape[1]
+        d = Wq.shape[0] // H
+        g = g.contiguous()
+        dWq = torch.empty_like(Wq)
+        dWk = torch.empty_like(Wk)
+        # dWq[h][j,c] = sum_c' Wk[h][j,c'] g[h][c,c']      (NT)
+        ops.gemm(Wk, g, dWq, d, C, C, C, C, C, transB=True, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0))
+        # dWk[h][j,c'] = sum_c Wq[h][j,c] g[h][c,c']       (NN)
+        ops.gemm(Wq, g, dWk, d, C, C, C, C, C, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0))
+        return dWq, dWk, None
+
+
+class QKRScoresFn(torch.autograd.Function):
+    """S[b,h,n,m] = sum_c xq[b,n,c] * qkx[b,m,h,c]   (attention.py:207-210), S stored (B,H,N,Np)."""
+
+    @staticmethod
+    def forward(ctx, xq, qkx, H):
+        B, N, C = xq.shape
+        Np = pad4(N)
+        S = torch.empty((B, H, N, Np), dtype=torch.float32, device=xq.device)
+        ops.gemm(xq, qkx, S, N, N, C, C, H * C, Np, transB=True, nb0=B, nb1=H, sA=(N * C, 0), sB=(N * H * C, C),
+                 sC=(H * N * Np, N * Np))
+        ctx.save_for_backward(xq, qkx)
+        ctx.H = H
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        xq, qkx = ctx.saved_tensors
+        H = ctx.H
+        B, N, C = xq.shape
+        Np = pad4(N)
+        dS = dS.contiguous()
+        dxq = torch.empty_like(xq)
+        dqkx = torch.empty_like(qkx)
+        # dxq[b,n,c] = sum_h sum_m dS[b,h,n,m] qkx[b,m,h,c]
+        ops.gemm(dS, qkx, dxq, N, C, N, Np, H * C, C, nb0=B, sA=(H * N * Np, 0), sB=(N * H * C, 0), sC=(N * C, 0),
+                 nkb=H, sAk=N * Np, sBk=C)
+        # dqkx[b,m,h,c] = sum_n dS[b,h,n,m] xq[b,n,c]
+        ops.gemm(dS, xq, dqkx, N, C, N, Np, C, H * C, transA=True, nb0=B, nb1=H, sA=(H * N * Np, N * Np),
+                 sB=(N * C, 0), sC=(N * H * C, C))
+        return dxq, dqkx, None
+
+
+class QKScoresFn(torch.autograd.Function):
+    """Plain attention scores S[b,h,n,m] = sum_j q[b,n,h*d+j] k[b,m,h*d+j]  (attention.py:96, before *scale)."""
+
+    @staticmethod
+    def forward(ctx, q, k, H):
+        B, N, C = q.shape
+        d = C // H
+        Np = pad4(N)
+        S = torch.empty((B, H, N, Np), dtype=torch.float32, device=q.device)
+        ops.gemm(q, k, S, N, N, d, C, C, Np, transB=True, nb0=B, nb1=H, sA=(N * C, d), sB=(N * C, d),
+                 sC=(H * N * Np, N * Np))
+        ctx.save_for_backward(q, k)
+        ctx.H = H
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        q, k = ctx.saved_tensors
+        H = ctx.H
+        B, N, C = q.shape
+        d = C // H
+        Np = pad4(N)
+        dS = dS.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        # dq[b,n,hd+j] = sum_m dS[b,h,n,m] k[b,m,hd+j]           (NN)
+        ops.gemm(dS, k, dq, N, d, N, Np, C, C, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * C, d), sC=(N * C, d))
+        # dk[b,m,hd+j] = sum_n dS[b,h,n,m] q[b,n,hd+j]           (TN)
+        ops.gemm(dS, q, dk, N, d, N, Np, C, C, transA=True, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * C, d),
+                 sC=(N * C, d))
+        return dq, dk, None
+
+
+class SoftmaxLsqFn(torch.autograd.Function):
+    """P_hat = LSQ_unsigned(softmax(S * alpha))   (attention.py:96-99 / :213-216).  s per query token."""
+
+    @staticmethod
+    def forward(ctx, S, s, N, alpha, hi):
+        B, H = S.shape[0], S.shape[1]
+        Np = S.shape[3]
+        rows = B * H * N
+        prob, y = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N)
+        ctx.save_for_backward(prob, s)
+        ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, s = ctx.saved_tensors
+        rows, N, Np, alpha, hi, M = ctx.meta
+        g = g.contiguous()
+        dS, ds = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True)
+        return dS, ds, None, None, None
+
+
+class PVFn(torch.autograd.Function):
+    """O[b,n,h*d+j] = sum_m P[b,h,n,m] v[b,m,h*d+j]   ((attn @ v).transpose(1,2).reshape, attention.py:102/:219)."""
+
+    @staticmethod
+    def forward(ctx, P, v, N):
+        B, H = P.shape[0], P.shape[1]
+        Np = P.shape[3]
+        C = v.shape[2]
+        d = C // H
+        O = torch.empty((B, N, C), dtype=torch.float32, device=v.device)
+        ops.gemm(P, v, O, N, d, N, Np, C, C, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * C, d), sC=(N * C, d))
+        ctx.save_for_backward(P, v)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        P, v = ctx.saved_tensors
+        B, H, N, Np = P.shape
+        C = v.shape[2]
+        d = C // H
+        dO = dO.contiguous()
+        dP = torch.empty_like(P)
+        dv = torch.empty_like(v)
+        # dP[b,h,n,m] = sum_j dO[b,n,hd+j] v[b,m,hd+j]            (NT); pad columns are never read downstream
+        ops.gemm(dO, v, dP, N, N, d, C, C, Np, transB=True, nb0=B, nb1=H, sA=(N * C, d), sB=(N * C, d),
+                 sC=(H * N * Np, N * Np))
+        # dv[b,m,hd+j] = sum_n P[b,h,n,m] dO[b,n,hd+j]            (TN)
+        ops.gemm(P, dO, dv, N, d, N, Np, C, C, transA=True, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * C, d),
+                 sC=(N * C, d))
+        return dP, dv, None
+
+
+class QKVSplitLsqFn(torch.autograd.Function):
+    """Plain path: qkv (+ move_qkv_b4) split into q,k,v thirds, q/k per-token LSQ, v per-channel LSQ, then the
+    per-third post offsets (attention.py:71-90), done in place on column slices of the (B*N, 3C) projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, b4, sq, sk, sv, baq, bak, bav, gq, gk, gv):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        qkv2 = qkv.reshape(B * N, C3)
+        outs = []
+        for i, (s, ba, g) in enumerate(((sq, baq, gq), (sk, bak, gk), (sv, bav, gv))):
+            y, _ = ops.lsq_fwd(qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], ba, g)
+            outs.append(y.view(B, N, C))
+        ctx.save_for_backward(qkv2, b4, sq, sk, sv)
+        ctx.geoms = (gq, gk, gv)
+        ctx.shape = (B, N, C)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        qkv2, b4, sq, sk, sv = ctx.saved_tensors
+        B, N, C = ctx.shape
+        dqkv = torch.empty_like(qkv2)
+        db4s, res = [], []
+        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):
+            dy = dy.contiguous()
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:])
+            db4s.append(db4)
+            res.append((ds, dbaft))
+        return (dqkv.view(B, N, 3 * C), torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+                res[2][1], None, None, None)

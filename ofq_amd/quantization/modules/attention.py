@@ -1,0 +1,159 @@
+"""QAttention / QAttention_qkreparam / QAttention_qkreparam_4_cga — drop-ins for
+src/quantization/modules/attention.py (:12, :107, :224): same constructor signatures, parameter names
+and `forward(x[B,N,C]) -> (y[B,N,C], None)`.
+
+Data layout (MI355X-first, not the reference's permute/contiguous chain): activations stay token-major
+(B, N, C) end to end; heads are column slices addressed through GEMM strides; the attention matrices are
+(B, H, N, Np) with Np = N rounded to 4 so rows stay float4-aligned.  No transposes are materialised."""
+import torch
+import torch.nn as nn
+
+from .qbias import LearnableBias
+from .qlinear import QLinear, LSQ_input
+from ..quantizer.lsq import LsqQuantizer, LsqQuantizer4v
+from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkreparam_cga
+from ...deit_vision_transformer import Attention as deit_attention
+from ... import ops
+from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn)
+
+
+def _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise, weight_quant_method,
+                    input_quant_method, aq_learnable, wq_learnable, pretrained_initialized):
+    return dict(weight_bits=weight_bits, input_bits=input_bits, weight_channelwise=weight_channelwise,
+                input_channelwise=input_channelwise, weight_quant_method=weight_quant_method,
+                input_quant_method=input_quant_method, aq_learnable=aq_learnable, wq_learnable=wq_learnable,
+                symmetric=True, pretrained_initialized=pretrained_initialized)
+
+
+def _softmax_lsq(quant, S, N, alpha):
+    """unsigned per-query-token LSQ on softmax(S*alpha); lazily initialises quant.s like lsq.py:544-569."""
+    if not quant.initialized_alpha or quant.s is None:
+        with torch.no_grad():
+            p = torch.softmax(S[..., :N].detach() * alpha, dim=-1)
+            quant.init_from(p)
+    return SoftmaxLsqFn.apply(S, quant.s, N, alpha, quant.thd_pos)
+
+
+class QAttention(deit_attention):
+    """Plain (non-QKR) quantised attention, attention.py:12-105."""
+
+    def __init__(self, m: deit_attention, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
+                 input_quant_method="lsq", pretrained_initialized=False, **kwargs):
+        assert type(m) == deit_attention
+        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
+                         proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
+        self.weight_bits = weight_bits
+        self.input_bits = input_bits
+        self.input_channelwise = input_channelwise
+        if input_bits >= 32:
+            raise ValueError("QAttention: input_bits >= 32 (no activation quantisation) is not on the hot path")
+        kw = _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise, weight_quant_method,
+                             input_quant_method, aq_learnable, wq_learnable, pretrained_initialized)
+        self.qkv = QLinear(m=m.qkv, **kw)
+        self.proj = QLinear(m=m.proj, **kw)
+        self.quan_a_q_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
+        self.quan_a_k_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
+        self.quan_a_v_fn = LsqQuantizer4v(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
+        C = m.qkv.in_features
+        self.move_qkv_b4 = LearnableBias(C * 3)
+        self.move_q_aft = LearnableBias(C)
+        self.move_k_aft = LearnableBias(C)
+        self.move_v_aft = LearnableBias(C)
+        self.quan_a_softmax_fn = LsqQuantizer(bit=input_bits, all_positive=True, per_channel=True, learnable=aq_learnable)
+
+    def _lazy_init(self, qkv):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        with torch.no_grad():
+            t = qkv.detach() + self.move_qkv_b4.bias.detach()
+            for i, qz in enumerate((self.quan_a_q_fn, self.quan_a_k_fn, self.quan_a_v_fn)):
+                if not qz.initialized_alpha or qz.s is None:
+                    qz.init_from(t[..., i * C:(i + 1) * C])
+
+    def forward(self, x):
+        B, N, C = x.shape
+        H = self.num_heads
+        qkv = self.qkv(x)                                                        # attention.py:69
+        self._lazy_init(qkv)
+        lo, hi = self.quan_a_q_fn.thd_neg, self.quan_a_q_fn.thd_pos
+        gq = ops.LsqGeom(B, N, C, C, 0, lo, hi, B * C, ldx=3 * C, ldy=C)         # s per token, M = B*H*d
+        gv = ops.LsqGeom(B * N, 1, C, C, 1, lo, hi, B * N, ldx=3 * C, ldy=C)     # s per channel, M = B*N
+        q, k, v = QKVSplitLsqFn.apply(qkv, self.move_qkv_b4.bias, self.quan_a_q_fn.s, self.quan_a_k_fn.s,
+                                      self.quan_a_v_fn.s, self.move_q_aft.bias, self.move_k_aft.bias,
+                                      self.move_v_aft.bias, gq, gq, gv)          # :71-90
+        S = QKScoresFn.apply(q, k, H)                                            # :96 (scale folded into softmax)
+        P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)               # :97-99
+        out = PVFn.apply(P, v, N)                                                # :102
+        return self.proj_drop(self.proj(out)), None                              # :103-105
+
+
+class QAttention_qkreparam(deit_attention):
+    """Query-key reparameterised attention, attention.py:107-222: StatsQ acts on W_q^T W_k per head."""
+
+    _qk_quant_cls = StatsQuantizer
+
+    def __init__(self, m: deit_attention, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
+                 input_quant_method="lsq", pretrained_initialized=False, boundaryRange=0.005, **kwargs):
+        assert type(m) == deit_attention
+        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
+                         proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
+        self.weight_bits = weight_bits
+        self.input_bits = input_bits
+        self.input_channelwise = input_channelwise
+        C = m.qkv.in_features
+        self.quant_x_4_qkv = LSQ_input(bit=input_bits, all_positive=False, learnable=aq_learnable, learanbaleBiasdim=C)
+        self.q = nn.Linear(C, C, bias=False)
+        self.k = nn.Linear(C, C, bias=False)
+        self.v = nn.Linear(C, C)
+        if pretrained_initialized:
+            with torch.no_grad():
+                w, b = m.qkv.weight.detach(), m.qkv.bias.detach()
+                self.q.weight.copy_(w[:C])
+                self.k.weight.copy_(w[C:2 * C])
+                self.v.weight.copy_(w[2 * C:3 * C])
+                self.v.bias.copy_(b[2 * C:3 * C])
+        self.qk_quant = self._make_qk_quant(wq_learnable, boundaryRange)
+        self.v_quant = StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
+        self.proj = QLinear(m=m.proj, **_qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise,
+                                                        weight_quant_method, input_quant_method, aq_learnable,
+                                                        wq_learnable, pretrained_initialized))
+        self.quan_a_qkx_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
+        self.quan_a_v_fn = LsqQuantizer4v(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
+        self.move_qkx_b4 = LearnableBias(self.num_heads * C)
+        self.move_qkx_aft = LearnableBias(self.num_heads * C)
+        self.move_v_b4 = LearnableBias(C)
+        self.move_v_aft = LearnableBias(C)
+        self.quan_a_softmax_fn = LsqQuantizer(bit=input_bits, all_positive=True, per_channel=True, learnable=aq_learnable)
+        del self.qkv                                                             # attention.py:172
+
+    def _make_qk_quant(self, wq_learnable, boundaryRange):
+        return StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        H = self.num_heads
+        xq = self.quant_x_4_qkv(x)                                               # attention.py:177
+        # ---- V branch (:179-187)
+        Wv = self.v_quant(self.v.weight)
+        v = LinearFn.apply(xq, Wv, self.v.bias)
+        v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
+        # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
+        Wqk = self.qk_quant(WqkFn.apply(self.q.weight, self.k.weight, H))
+        qkx = LinearFn.apply(xq, Wqk, None)                                      # (B, N, H*C)   einsum :200
+        qkx = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
+                                       shape=(B, N * H, C), out_shape=(B, N, H, C))   # :201-206, s per (token, head)
+        S = QKRScoresFn.apply(xq, qkx, H)                                        # :210
+        P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)               # :213-216
+        out = PVFn.apply(P, v, N)                                                # :219
+        return self.proj_drop(self.proj(out)), None                              # :220-222
+
+
+class QAttention_qkreparam_4_cga(QAttention_qkreparam):
+    """attention.py:224-339.  Identical maths (its StatsQuantizer_specific_4_qkreparam_cga is value- and
+    gradient-equal to StatsQuantizer); kept as its own class for `qk_reparam_type=1` and checkpoints."""
+
+    def _make_qk_quant(self, wq_learnable, boundaryRange):
+        return StatsQuantizer_specific_4_qkreparam_cga(num_bits=self.weight_bits, clip_learnable=wq_learnable,
+                                                       boundaryRange=boundaryRange)

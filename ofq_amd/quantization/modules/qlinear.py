@@ -1,0 +1,194 @@
+"""QLinear / QMLP / LSQ_input / LSQ_QConv2d / LSQ_QLinear4head — drop-ins for
+src/quantization/modules/qlinear.py (:28, :89, :12, :138, :193): same class names, constructor
+signatures, parameter names and shapes (= checkpoint format), same error behaviour.
+Every forward is a short chain of HIP kernels: StatsQ / LSQ-weight -> fused offset+LSQ+offset -> MFMA GEMM."""
+import torch
+import torch.nn as nn
+
+from .qbias import LearnableBias, LearnableBias4img
+from ..quantizer.statsq import StatsQuantizer
+from ..quantizer.lsq import (LsqQuantizer, LsqQuantizerWeight, LsqQuantizer4img, LsqQuantizer4Conv2d,
+                             LsqQuantizer4head_input)
+from ...deit_vision_transformer import Mlp, to_2tuple
+from ...functional import LinearFn
+
+
+class LSQ_input(nn.Module):
+    """qlinear.py:12-26 — offset -> LSQ -> offset, shared by the V and QK branches of the QKR attention."""
+
+    def __init__(self, bit=2, all_positive=False, learnable=True, learanbaleBiasdim=192):
+        super().__init__()
+        self.input_bits = bit
+        self.all_positive = all_positive
+        self.learnable = learnable
+        self.input_quant_fn = LsqQuantizer(bit=bit, all_positive=all_positive, learnable=learnable)
+        self.move_b4 = LearnableBias(learanbaleBiasdim)
+        self.move_aft = LearnableBias(learanbaleBiasdim)
+
+    def forward(self, input):
+        return self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias)
+
+
+class QLinear(nn.Linear):
+    def __init__(self, *kargs, m: torch.nn.Linear, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 symmetric=True, weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
+                 input_quant_method="lsq", pretrained_initialized=False, **kwargs):
+        super().__init__(m.in_features, m.out_features, bias=True)              # always a bias (qlinear.py:34)
+        self.weight_bits = weight_bits
+        self.input_bits = input_bits
+        self.aq_learnable = aq_learnable
+        self.wq_learnable = wq_learnable
+        self.symmetric = symmetric
+        self.weight_channelwise = weight_channelwise
+        self.input_channelwise = input_channelwise
+        self.weight_quant_method = weight_quant_method
+        self.input_quant_method = input_quant_method
+        self.input_quant_fn = LsqQuantizer(bit=input_bits, all_positive=(symmetric == False), learnable=aq_learnable)  # noqa: E712
+        self.pretrained_initialized = pretrained_initialized
+        if pretrained_initialized != False:  # noqa: E712
+            self.weight = torch.nn.Parameter(m.weight.detach())
+            if m.bias is not None:
+                self.bias = torch.nn.Parameter(m.bias.detach())
+        if weight_quant_method == "statsq":
+            self.statsq_fn = StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable).to(m.weight.device)
+        else:
+            raise ValueError("Unknown quant_method")
+        self.move_b4 = LearnableBias(self.weight.shape[1])
+        self.move_aft = LearnableBias(self.weight.shape[1])
+        self._prologue = 0          # 1: exact GELU fused in front of the input quantiser (set by QMLP for fc2)
+
+    def forward(self, input):
+        if self.weight_quant_method == "statsq":
+            weight = self.statsq_fn(self.weight)                                 # qlinear.py:62
+        else:
+            raise ValueError("Unknown quant_method")
+        xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, prologue=self._prologue)
+        return LinearFn.apply(xq, weight, self.bias)                             # qlinear.py:69-71
+
+    def extra_repr(self):
+        return (f"act_bit={self.input_bits}, weight_bit={self.weight_bits}, act_all_positive={not self.symmetric}, "
+                f"wq_learnable={self.wq_learnable}, aq_learnable={self.aq_learnable}, "
+                f"weight_channelwise ={self.weight_channelwise}, input_channelwise ={self.input_channelwise}, "
+                f"weight_quant_method={self.weight_quant_method}, activation_quant_method={self.input_quant_method}, "
+                f"pretrained_initialized = {self.pretrained_initialized}")
+
+
+class QMLP(Mlp):
+    def __init__(self, *kargs, m: Mlp, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
+                 input_quant_method="lsq", act_layer=nn.GELU, pretrained_initialized=False, **kwargs):
+        super().__init__(in_features=m.in_features, hidden_features=m.hidden_features, out_features=m.out_features,
+                         drop=m.drop)
+        drop_probs = to_2tuple(self.drop)
+        common = dict(weight_bits=weight_bits, input_bits=input_bits, aq_learnable=aq_learnable,
+                      wq_learnable=wq_learnable, weight_channelwise=weight_channelwise,
+                      input_channelwise=input_channelwise, weight_quant_method=weight_quant_method,
+                      input_quant_method=input_quant_method, pretrained_initialized=pretrained_initialized)
+        self.fc1 = QLinear(m=m.fc1, symmetric=True, **common)
+        self.act_layer = act_layer
+        if act_layer == "rprelu":
+            raise ValueError("rprelu is not part of any shipped OFQ recipe")
+        self.act = act_layer() if act_layer != "None" else nn.Identity()
+        self.drop1 = nn.Dropout(drop_probs[0])
+        self.fc2 = QLinear(m=m.fc2, symmetric=False, **common)                   # unsigned input (qlinear.py:118-120)
+        self.drop2 = nn.Dropout(drop_probs[1])
+        # exact GELU followed by dropout(p=0) is folded into fc2's input-quantiser kernel
+        self._fuse_gelu = isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none" \
+            and drop_probs[0] == 0
+        self.fc2._prologue = 1 if self._fuse_gelu else 0
+
+    def forward(self, x):
+        x = self.fc1(x)
+        if not self._fuse_gelu:
+            x = self.drop1(self.act(x))
+        x = self.fc2(x)
+        return self.drop2(x)
+
+
+class LSQ_QConv2d(nn.Conv2d):
+    """W8A8 patch embedding (qlinear.py:138-191).  The stride==kernel conv is an im2col view + MFMA GEMM."""
+
+    def __init__(self, *kargs, m: torch.nn.Conv2d, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 symmetric=True, weight_channelwise=True, input_channelwise=True, weight_quant_method="lsq",
+                 input_quant_method="lsq", pretrained_initialized=False, **kwargs):
+        super().__init__(in_channels=m.in_channels, out_channels=m.out_channels, kernel_size=m.kernel_size,
+                         stride=m.stride, padding=m.padding, dilation=m.dilation, groups=m.groups, bias=True)
+        self.weight_bits = weight_bits
+        self.input_bits = input_bits
+        self.aq_learnable = aq_learnable
+        self.wq_learnable = wq_learnable
+        self.symmetric = symmetric
+        self.weight_channelwise = weight_channelwise
+        self.input_channelwise = input_channelwise
+        self.weight_quant_method = weight_quant_method
+        self.input_quant_method = input_quant_method
+        self.input_quant_fn = LsqQuantizer4img(bit=input_bits, all_positive=(symmetric == False), learnable=aq_learnable)  # noqa: E712
+        self.pretrained_initialized = pretrained_initialized
+        if pretrained_initialized != False:  # noqa: E712
+            self.weight = torch.nn.Parameter(m.weight.detach())
+            if m.bias is not None:
+                self.bias = torch.nn.Parameter(m.bias.detach())
+        self.lsqw_fn = LsqQuantizer4Conv2d(bit=self.weight_bits, learnable=aq_learnable).to(m.weight.device)
+        self.move_b4 = LearnableBias4img(224 * 224)                              # qlinear.py:163-164
+        self.move_aft = LearnableBias4img(224 * 224)
+        if tuple(self.stride) != tuple(self.kernel_size) or tuple(self.padding) != (0, 0) or self.groups != 1:
+            raise ValueError("LSQ_QConv2d: only the non-overlapping patch-embedding conv is on the hot path")
+
+    def forward(self, input):
+        weight = self.lsqw_fn(self.weight)                                       # qlinear.py:168
+        xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias)   # :171-173
+        B, Cin, Hh, Ww = xq.shape
+        kh, kw = self.kernel_size
+        gh, gw = Hh // kh, Ww // kw
+        # im2col of a stride==kernel conv is a pure permutation: (B, gh*gw, Cin*kh*kw)
+        cols = xq.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
+        out = LinearFn.apply(cols, weight.view(self.out_channels, -1), self.bias)      # :174
+        return out.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
+
+    def extra_repr(self):
+        return (f"act_bit={self.input_bits}, weight_bit={self.weight_bits}, act_all_positive={not self.symmetric}, "
+                f"wq_learnable={self.wq_learnable}, aq_learnable={self.aq_learnable}, "
+                f"weight_quant_method={self.weight_quant_method}, activation_quant_method={self.input_quant_method}, "
+                f"pretrained_initialized = {self.pretrained_initialized}")
+
+
+QConv2d = LSQ_QConv2d   # north_star's name; the reference only has a commented import of it (modules/utils.py:4)
+
+
+class LSQ_QLinear4head(nn.Linear):
+    """W8A8 classifier heads (qlinear.py:193-252)."""
+
+    def __init__(self, *kargs, m: torch.nn.Linear, weight_bits=8, input_bits=8, aq_learnable=True, wq_learnable=True,
+                 symmetric=True, weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
+                 input_quant_method="lsq", pretrained_initialized=False, **kwargs):
+        super().__init__(m.in_features, m.out_features, bias=True)
+        self.weight_bits = weight_bits
+        self.input_bits = input_bits
+        self.aq_learnable = aq_learnable
+        self.wq_learnable = wq_learnable
+        self.symmetric = symmetric
+        self.weight_channelwise = weight_channelwise
+        self.input_channelwise = input_channelwise
+        self.weight_quant_method = weight_quant_method
+        self.input_quant_method = input_quant_method
+        self.input_quant_fn = LsqQuantizer4head_input(bit=input_bits, all_positive=(symmetric == False), learnable=aq_learnable)  # noqa: E712
+        self.pretrained_initialized = pretrained_initialized
+        if pretrained_initialized != False:  # noqa: E712
+            self.weight = torch.nn.Parameter(m.weight.detach())
+            if m.bias is not None:
+                self.bias = torch.nn.Parameter(m.bias.detach())
+        if weight_quant_method == "lsq":
+            self.lsqw_fn = LsqQuantizerWeight(bit=self.weight_bits, per_channel=weight_channelwise,
+                                              learnable=wq_learnable).to(m.weight.device)
+        else:
+            raise ValueError("Unknown quant_method")
+        self.move_b4 = LearnableBias(self.weight.shape[1])
+        self.move_aft = LearnableBias(self.weight.shape[1])
+
+    def forward(self, input):
+        if self.weight_quant_method == "lsq":
+            weight = self.lsqw_fn(self.weight)                                   # qlinear.py:227
+        else:
+            raise ValueError("Unknown quant_method")
+        xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias)
+        return LinearFn.apply(xq, weight, self.bias)

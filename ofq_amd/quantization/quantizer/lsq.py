@@ -39,7 +39,7 @@ class _LsqFn(torch.autograd.Function):
         g = ctx.geom
         gy = gy.contiguous()
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx, ds, db4, dbaft, None
+        return dx.view(x.shape), ds, db4, dbaft, None
 
 
 class _LsqBase(nn.Module):

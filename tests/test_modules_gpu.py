@@ -1,0 +1,198 @@
+"""GPU parity tests, module level: the ofq_amd drop-in modules (HIP path) against goldens generated from the
+reference and against the oracle, forward and every parameter gradient.  Tolerance: BASELINE.json's 1e-3
+relative (normalised by the tensor's max magnitude); typical measured error is 1e-6..1e-5."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from detgen import det_uniform, det_normalish, det_int
+from util import load_golden, group, case_names, T, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rel_l2(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu().reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _offset_grad_err(grad, g, name):
+    """Gradients of the LearnableBias offsets around attention are compared on the common scale of the module's
+    offset gradients, not each on its own: d/d(move_k_aft) and d/d(move_qkx_aft) are identically zero in exact
+    arithmetic (they shift every score of a softmax row equally, and the rows of dS sum to zero), and
+    d/d(move_qkx_b4) vanishes too wherever nothing is clipped, so the reference's values for them are fp32
+    rounding noise (1e-7 next to O(1) siblings) and a self-relative error would be meaningless."""
+    ref = torch.as_tensor(g["grad:" + name], dtype=torch.float64)
+    scale = max(float(np.abs(v).max()) for k, v in g.items()
+                if k.startswith("grad:") and k.endswith(".bias") and "move_" in k)
+    return float((grad.detach().cpu().double() - ref).abs().max() / scale)
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available(), "the -m gpu tests need a HIP device"
+    import ofq_amd.ops as ops
+    ops.lib()
+    return ops
+
+
+def _load(mod, g):
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("p:")}
+    missing, unexpected = mod.load_state_dict(sd, strict=True), None
+    return mod
+
+
+def _run(mod, g, x, out_index=None, tol=TOL):
+    mod.cuda().train()
+    with torch.no_grad():
+        mod(x.cuda())                       # lazy LSQ init (creates every `s`), like setup_alpha
+    _load(mod, g)
+    xg = x.cuda().requires_grad_(True)
+    y = mod(xg)
+    if out_index is not None:
+        y = y[out_index]
+    gy = T(g["g"]).cuda()
+    if gy.shape != y.shape:
+        gy = gy.reshape(y.shape)
+    (y * gy).sum().backward()
+    errs = {"y": rel_err(y.detach(), T(g["y"]).reshape(y.shape)), "dx": rel_err(xg.grad, g["dx"])}
+    for n, p in mod.named_parameters():
+        if "grad:" + n in g:
+            assert p.grad is not None, n
+            if "move_" in n:
+                errs[n] = _offset_grad_err(p.grad, g, n)
+            else:
+                errs[n] = rel_err(p.grad, g["grad:" + n])
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, bad
+    return errs
+
+
+def _linear(i, o):
+    return nn.Linear(i, o)
+
+
+def test_qlinear_golden(env):
+    from ofq_amd.quantization.modules.qlinear import QLinear
+    d = load_golden("g3_qlinear")
+    for nme in case_names(d):
+        g = group(d, nme)
+        B, N, I, Oo, wb, ab, sym, seed = [int(v) for v in g["meta"]]
+        x = T(det_normalish((B, N, I), seed, 1.0))
+        if not sym:
+            x = x.abs()
+        q = QLinear(m=_linear(I, Oo), weight_bits=wb, input_bits=ab, symmetric=bool(sym), pretrained_initialized=True)
+        errs = _run(q, g, x)
+        assert max(errs.values()) < 1e-4, (nme, errs)
+
+
+def test_qmlp_golden(env):
+    from ofq_amd.quantization.modules.qlinear import QMLP
+    from ofq_amd.deit_vision_transformer import Mlp
+    d = load_golden("g5_qmlp")
+    for nme in case_names(d):
+        g = group(d, nme)
+        B, N, C, Hd, wb, ab, seed = [int(v) for v in g["meta"]]
+        q = QMLP(m=Mlp(in_features=C, hidden_features=Hd, act_layer=nn.GELU), weight_bits=wb, input_bits=ab,
+                 act_layer=nn.GELU, pretrained_initialized=True)
+        _run(q, g, T(det_normalish((B, N, C), seed, 1.0)))
+
+
+def test_attention_golden_plain_qkr_and_cga_twin(env):
+    from ofq_amd.quantization.modules.attention import QAttention, QAttention_qkreparam, QAttention_qkreparam_4_cga
+    from ofq_amd.deit_vision_transformer import Attention
+    d = load_golden("g4_attention")
+    kinds = {"plain": QAttention, "qkr": QAttention_qkreparam, "qkrcga": QAttention_qkreparam_4_cga}
+    seen = set()
+    for nme in case_names(d):
+        g = group(d, nme)
+        B, N, C, H, wb, ab, seed = [int(v) for v in g["meta"]]
+        kind = nme.split("_")[0]
+        q = kinds[kind](m=Attention(dim=C, num_heads=H, qkv_bias=True), weight_bits=wb, input_bits=ab,
+                        pretrained_initialized=True)
+        _run(q, g, T(det_normalish((B, N, C), seed, 1.0)), out_index=0)
+        seen.add(kind)
+    assert seen == set(kinds)
+
+
+def test_stem_and_head_golden(env):
+    from ofq_amd.quantization.modules.qlinear import LSQ_QConv2d, LSQ_QLinear4head
+    d = load_golden("g6_stem_head")
+    for nme in ("conv_signed", "conv_unsigned"):
+        g = group(d, nme)
+        lo, hi = float(g["img_lohi"][0]), float(g["img_lohi"][1])
+        img = T(det_uniform((1, 3, 224, 224), int(g["meta"][2]), lo, hi))
+        q = LSQ_QConv2d(m=nn.Conv2d(3, 8, kernel_size=16, stride=16), weight_bits=8, input_bits=8,
+                        weight_quant_method="lsq", input_quant_method="lsq", pretrained_initialized=True)
+        _run(q, g, img)
+        assert float(q.input_quant_fn.signed) == float(g["p:input_quant_fn.signed"][0])
+    g = group(d, "head")
+    B, I, Oo, seed = [int(v) for v in g["meta"]]
+    q = LSQ_QLinear4head(m=_linear(I, Oo), weight_bits=8, input_bits=8, weight_quant_method="lsq",
+                         input_quant_method="lsq", pretrained_initialized=True)
+    _run(q, g, T(det_normalish((B, I), seed, 1.0)))
+
+
+def _qconfigs(names, wb, ab):
+    return {n: {"weight": {"mode": "statsq", "bit": wb, "all_positive": False, "symmetric": True, "per_channel": True,
+                           "normalize_first": False, "learnable": True},
+                "act": {"enable": True, "mode": "lsq", "bit": ab, "per_channel": True, "normalize_first": False,
+                        "learnable": True}, "q_attn_dropout": False, "act_layer": nn.GELU} for n in names}
+
+
+def test_tiny_deit_full_step_golden(env):
+    """Whole model: surgery by name list, setup_alpha, training forward, KD loss, every gradient."""
+    from ofq_amd.deit import DistilledVisionTransformer
+    from ofq_amd.quantization.modules.utils import replace_module_by_qmodule_deit
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    d = load_golden("g7_tiny_deit")
+    for nme in case_names(d):
+        g = group(d, nme)
+        B, depth, dim, heads, wb, ab, qkr, seed, ncls, mlp_ratio = [int(v) for v in g["meta"]]
+        model = DistilledVisionTransformer(img_size=224, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads,
+                                           mlp_ratio=mlp_ratio, qkv_bias=True, num_classes=ncls,
+                                           norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU)
+        names = ["patch_embed.proj"] + sum([["blocks.%d.attn" % i, "blocks.%d.mlp" % i] for i in range(depth)], []) \
+            + ["head", "head_dist"]
+        model = replace_module_by_qmodule_deit(model, _qconfigs(names, wb, ab), pretrained_initialized=True,
+                                               qk_reparam=bool(qkr), qk_reparam_type=0)
+        model.cuda()
+        img = T(det_uniform((B, 3, 224, 224), seed, -2.0, 2.0)).cuda()
+        model.eval()
+        with torch.no_grad():
+            model(img)                                              # setup_alpha (train.py:997-1010)
+        _load(model, g)
+        model.train()
+        (cls_o, dist_o), _ = model(img)
+        loss = KDLossSoftandHard()((cls_o, dist_o), T(g["target"]).cuda(), T(g["soft"]).cuda())
+        loss.backward()
+        assert rel_err(cls_o.detach(), g["cls"]) < TOL
+        assert rel_err(dist_o.detach(), g["dist"]) < TOL
+        assert abs(float(loss.detach()) - float(g["loss"])) < TOL * abs(float(g["loss"]))
+        worst = {}
+        n = 0
+        for pn, p in model.named_parameters():
+            if "grad:" + pn in g:
+                assert p.grad is not None, pn
+                e = _offset_grad_err(p.grad, g, pn) if "move_" in pn else _rel_l2(p.grad, g["grad:" + pn])
+                worst[pn] = e
+                n += 1
+        assert n > 60
+        bad = {k: v for k, v in worst.items() if v > 5e-3}
+        assert not bad, bad
+        model.eval()
+        with torch.no_grad():
+            ev, _ = model(img)
+        assert rel_err(ev, g["eval_logits"]) < TOL
+
+
+def test_modules_reject_cpu_tensors(env):
+    from ofq_amd.quantization.modules.qlinear import QLinear
+    q = QLinear(m=_linear(16, 8), weight_bits=2, input_bits=2, pretrained_initialized=True)
+    with pytest.raises(RuntimeError):
+        q(torch.zeros(2, 3, 16))
