@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of one OFQ QAT training step on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+
+Workload (config C3 of BASELINE.json / SURVEY.md §8d): DeiT-S (C384, H6, 12 blocks, 198 tokens) W2A2 with
+QK-reparameterisation, 128 images per GPU (global batch 128*N, weak scaling), fp32, synthetic ImageNet-shaped
+batches (randn images, random labels, random teacher logits), random-init weights.  One step = student
+forward + KDLossSoftandHard + backward (+ bucketed RCCL all-reduce for N > 1) + AdamW step.
+
+Prints ONE JSON line on rank 0, with two extra objects:
+  roofline      — the dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs per launch / HIP-event time per launch,
+                  both measured live over the timed steps, against the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline  — oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path) timed on this box's
+                  host cores on a bounded sample (DeiT-S W2A2 QKR, batch 8, a few steps), rank 0 at N = 1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=128)
+    ap.add_argument("--model", default="deit_small_distilled_patch16_224")
+    ap.add_argument("--wbits", type=int, default=2)
+    ap.add_argument("--abits", type=int, default=2)
+    ap.add_argument("--no-qkr", action="store_true")
+    ap.add_argument("--cga", action="store_true", help="add the CGA mask/restore hooks (config C5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, args):
+    """Time the oracle (kind 'port': the CPU restatement pinned to the reference by tests/golden) on host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ofq_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))      # cores this process may actually use (cgroup / affinity aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "clip_val" not in k and "signed" not in k
+                  else v) for k, v in sd.items()}
+    m0 = model
+    cfg = dict(depth=len(m0.blocks), num_heads=m0.blocks[0].attn.num_heads, patch=16, wbits=args.wbits,
+               abits=args.abits, qkr=not args.no_qkr)
+    B = args.cpu_batch
+    g = torch.Generator().manual_seed(42)
+    img = torch.randn(B, 3, 224, 224, generator=g)
+    tgt = torch.randint(0, 1000, (B,), generator=g)
+    soft = torch.randn(B, 1000, generator=g)
+    params = [v for v in leaves.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=5.47e-4, weight_decay=0.05)
+    times = []
+    for it in range(args.cpu_steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        c, d = O.deit_forward(img, leaves, cfg, training=True)
+        loss = O.kd_loss_soft_and_hard(c, d, tgt, soft)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path), %s W%dA%d%s, batch %d, "
+                      "median of %d steps after 1 warm-up, fwd+bwd+AdamW, %d threads"
+                      % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR", B, args.cpu_steps, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the OFQ MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    from ofq_amd import engine, ops, parallel
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+
+    def say(msg):
+        if args.verbose and rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+    T0 = time.perf_counter()
+    B = args.batch_per_gpu
+    model = engine.build_student(args.model, args.wbits, args.abits, qk_reparam=not args.no_qkr,
+                                 qk_reparam_type=1 if args.cga else 0).to(dev)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)          # seed 42 + rank
+    images = torch.randn(B, 3, 224, 224, device=dev, generator=g)
+    target = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    soft = torch.randn(B, 1000, device=dev, generator=g)           # stands in for the fp32 teacher's logits
+    say("model built")
+    engine.setup_alpha(model, images)                               # creates every LSQ step (train.py:657)
+    torch.cuda.synchronize()
+    say("setup_alpha done")
+    model.train()
+    dp = parallel.DataParallel(model, bucket_mb=24.0) if world > 1 else None
+    opt = engine.make_optimizer(model, lr=5.47e-4, weight_decay=0.05)
+    cga = engine.CGAHooks(model, args.wbits, 0.005, qk_reparam=not args.no_qkr) if args.cga else None
+    loss_fn = KDLossSoftandHard()
+
+    def step():
+        return engine.train_step(model, opt, images, target, soft, loss_fn, dp=dp, cga=cga)
+
+    for i in range(args.warmup):
+        step()
+        if args.verbose:
+            torch.cuda.synchronize()
+            say("warmup step %d done" % i)
+    timer = None if args.no_roofline_events else ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    say("timed region done: %.1f ms/step" % (1000.0 * elapsed / args.steps))
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        roof = None
+        if timer is not None:
+            sm = timer.summary()
+            achieved = sm["total_units"] / (sm["total_ms"] * 1e-3) / 1e12 if sm["total_ms"] > 0 else 0.0
+            roof = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": sm["launches"] / args.steps,
+                    "avg_launch_ms": round(sm["avg_ms"], 4), "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
+                    "gemm_ms_per_step": round(sm["total_ms"] / args.steps, 3)}
+        out = {"metric": "images/sec QAT (DeiT-S W2A2, 224px synthetic)", "value": round(value, 2), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s W%dA%d%s%s QAT step (student fwd + KD loss + bwd + AdamW), %d img/GPU, "
+                                      "198 tokens, fp32, teacher logits synthetic"
+                                      % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
+                                         " + CGA hooks" if args.cga else "", B),
+                          "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss.detach())},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,7 @@ typedef struct ofq_gemm_desc {
   int32_t split_k;   /* >=1 */
   float alpha;
   int32_t accumulate; /* C += result (beta = 1) when non-zero */
+  int32_t tile_hint;  /* 0 = choose; 64 / 128 force the 64x64 / 128x128 workgroup tile (benchmarking) */
 } ofq_gemm_desc;
 size_t ofq_gemm_ws_bytes(const ofq_gemm_desc* d);
 int ofq_gemm_f32(const ofq_gemm_desc* d, void* ws, size_t ws_bytes, ofq_stream_t stream);

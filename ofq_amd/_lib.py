@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
                 ("nb0", C.c_int32), ("nb1", C.c_int32),
                 ("sA0", i64), ("sA1", i64), ("sB0", i64), ("sB1", i64), ("sC0", i64), ("sC1", i64),
                 ("nkb", C.c_int32), ("sAk", i64), ("sBk", i64),
-                ("split_k", C.c_int32), ("alpha", f32), ("accumulate", C.c_int32)]
+                ("split_k", C.c_int32), ("alpha", f32), ("accumulate", C.c_int32), ("tile_hint", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)

@@ -1,0 +1,145 @@
+"""Step driver shared by train.py / cga.py / bench.py: model construction + surgery (get_qat_model,
+train.py:386-426), setup_alpha (train.py:997-1010), optimizer with timm's no-weight-decay rule
+(create_optimizer_v2, train.py:662), one training step (train.py:893-933) and the CGA hooks (cga.py:953-1013)."""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .deit import create_model
+from .quantization.modules.utils import replace_module_by_qmodule_deit
+from .quantization.utils import KDLossSoftandHard
+from . import ops
+
+ACT_LAYER_MAPPINGS = {'relu': nn.ReLU, 'gelu': nn.GELU, 'prelu': nn.PReLU, 'rprelu': 'rprelu', 'None': 'None'}
+
+
+def default_qmodules(depth):
+    """The name list of configs/ours_imagenet_recipe.attn_q.yml:47-74."""
+    names = ["patch_embed.proj"]
+    for i in range(depth):
+        names += ["blocks.%d.attn" % i, "blocks.%d.mlp" % i]
+    return names + ["head", "head_dist"]
+
+
+def get_qat_model(model, args):
+    """train.py:386-426 — build per-module qconfigs from the flat args and swap the modules."""
+    qconfigs = {}
+    for m in args.qmodules:
+        wcfg = {"mode": args.wq_mode if args.wq_enable else "Identity",
+                "bit": args.wq_bitw if args.wq_bitw < 32 and args.aq_enable else "identity",
+                "all_positive": False, "symmetric": not getattr(args, "wq_asym", False),
+                "per_channel": args.wq_per_channel, "normalize_first": False,
+                "learnable": getattr(args, "wq_clip_learnable", False)}
+        acfg = {"enable": args.aq_enable if args.aq_enable else "Identity",
+                "mode": args.aq_mode if args.aq_bitw < 32 and args.aq_enable else "identity", "bit": args.aq_bitw,
+                "per_channel": args.aq_per_channel, "normalize_first": False,
+                "learnable": getattr(args, "aq_clip_learnable", True)}
+        qconfigs[m] = {"weight": wcfg, "act": acfg, "q_attn_dropout": getattr(args, "apply_q_attn_dropout", False),
+                       "act_layer": ACT_LAYER_MAPPINGS[getattr(args, "act_layer", "gelu")]}
+    if args.model_type != 'deit':
+        raise ValueError("model_type %r: only the DeiT family is built so far (Swin is the next §8 row)" % args.model_type)
+    return replace_module_by_qmodule_deit(model, qconfigs, pretrained_initialized=args.pretrained_initialized,
+                                          qk_reparam=args.qk_reparam, qk_reparam_type=args.qk_reparam_type,
+                                          boundaryRange=getattr(args, "boundaryRange", 0.005))
+
+
+def build_student(model_name="deit_small_distilled_patch16_224", wbits=2, abits=2, qk_reparam=True, qk_reparam_type=0,
+                  num_classes=1000, depth=None, boundary_range=0.005, seed=42):
+    torch.manual_seed(seed)                                     # train.py:258, :501
+    kw = {"num_classes": num_classes}
+    if depth is not None:
+        kw["depth"] = depth
+    model = create_model(model_name, **kw)
+    args = SimpleNamespace(qmodules=default_qmodules(len(model.blocks)), wq_mode="statsq", wq_enable=True,
+                           wq_bitw=wbits, aq_enable=True, aq_mode="lsq", aq_bitw=abits, wq_per_channel=True,
+                           aq_per_channel=True, aq_clip_learnable=True, wq_clip_learnable=False, act_layer="gelu",
+                           model_type="deit", pretrained_initialized=True, qk_reparam=qk_reparam,
+                           qk_reparam_type=qk_reparam_type, boundaryRange=boundary_range)
+    return get_qat_model(model, args)
+
+
+@torch.no_grad()
+def setup_alpha(model, images):
+    """train.py:997-1010: one eval-mode forward creates every lazily-initialised LSQ step size."""
+    was_training = model.training
+    model.eval()
+    model(images)
+    model.train(was_training)
+
+
+def param_groups_weight_decay(model, weight_decay, skip=()):
+    """timm optim_factory.param_groups_weight_decay (used by create_optimizer_v2): no decay for 1-D
+    parameters, biases and the model's no_weight_decay() names."""
+    skip = set(skip) | set(getattr(model, "no_weight_decay", lambda: set())())
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or name.endswith(".bias") or name in skip:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def make_optimizer(model, lr=5.47e-4, weight_decay=0.05, fused=None):
+    groups = param_groups_weight_decay(model, weight_decay)
+    if fused is None:
+        fused = next(model.parameters()).is_cuda
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused)
+
+
+# -------------------------------------------------------------------------------------------- CGA (cga.py)
+def cga_modules(model, qk_reparam=True):
+    """cga.py:966-979: blocks.* modules whose name ends with fc1 | fc2 | .v | proj  (QKR), or qkv (plain)."""
+    out = []
+    for k, v in model.named_modules():
+        if 'blocks' not in k:
+            continue
+        if k[-3:] == 'fc1' or k[-3:] == 'fc2' or k[-4:] == 'proj' or (k[-2:] == '.v' if qk_reparam else k[-3:] == 'qkv'):
+            out.append((k, v))
+    return out
+
+
+class CGAHooks:
+    """freeze-outside-boundary gradient mask + weight restore around optimizer.step() (cga.py:953-1013)."""
+
+    def __init__(self, model, wbits, boundary_range=0.005, qk_reparam=True):
+        self.mods = cga_modules(model, qk_reparam)
+        self.bits, self.br = wbits, boundary_range
+        self.state = {}
+
+    @torch.no_grad()
+    def before_step(self):
+        for k, m in self.mods:
+            frz = ops.cga_freeze_mask(m.weight.data, self.bits, self.br)           # cga.py:960
+            saved = ops.cga_mask_grad_save(m.weight.grad, m.weight.data, frz)      # :962-964
+            self.state[k] = (frz, saved)
+
+    @torch.no_grad()
+    def after_step(self):
+        for k, m in self.mods:
+            frz, saved = self.state[k]
+            ops.cga_restore(m.weight.data, frz, saved)                             # :994-997
+        self.state.clear()
+
+
+def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
+    """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
+    loss_fn = loss_fn or KDLossSoftandHard()
+    if dp is not None:
+        dp.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    out, _ = (dp or model)(images)
+    loss = loss_fn(out, target, soft_target)
+    loss.backward()
+    if dp is not None:
+        dp.finish_gradient_sync()
+    if cga is not None:
+        cga.before_step()
+    optimizer.step()
+    if cga is not None:
+        cga.after_step()
+    return loss

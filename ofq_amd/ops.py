@@ -14,6 +14,30 @@ _lib_handle = None
 _ws = {}
 
 
+class KernelTimer:
+    """Optional HIP-event instrumentation of one kernel class (used by bench.py for the roofline of the
+    dominant kernel).  Events are recorded on torch's current stream, which is the stream the C ABI launches on."""
+
+    def __init__(self):
+        self.records = []            # (start_event, end_event, work_units)
+
+    def bracket(self, units):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((s, e, units))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [s.elapsed_time(e) for s, e, _ in self.records]
+        units = [u for _, _, u in self.records]
+        n = len(ms)
+        return {"launches": n, "total_ms": sum(ms), "avg_ms": sum(ms) / max(n, 1), "total_units": float(sum(units)),
+                "avg_units": float(sum(units)) / max(n, 1)}
+
+
+GEMM_TIMER = None   # set to a KernelTimer to time every ofq_gemm_f32 launch
+
+
 def lib():
     global _lib_handle
     if _lib_handle is None:
@@ -134,7 +158,7 @@ def softmax_lsq_bwd(g, prob, s, rows, n, ld, S, alpha, hi, M, inplace=True):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, nb0=1, nb1=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), nkb=1, sAk=0, sBk=0, split_k=1, alpha=1.0, accumulate=False,
-         offA=0, offB=0, offC=0):
+         offA=0, offB=0, offC=0, tile_hint=0):
     """Raw launcher; A/B/Cout are base tensors, off* are element offsets into them."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * offA
@@ -150,9 +174,16 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     d.sC0, d.sC1 = sC
     d.nkb, d.sAk, d.sBk = nkb, sAk, sBk
     d.split_k, d.alpha, d.accumulate = split_k, alpha, int(accumulate)
+    d.tile_hint = tile_hint
     wsb = lib().ofq_gemm_ws_bytes(C.byref(d))
     ws = workspace(wsb, A.device) if wsb else None
+    timer = GEMM_TIMER
+    if timer is not None:
+        ev0, ev1 = timer.bracket(2.0 * M * N * K * nb0 * nb1 * nkb)
+        ev0.record()
     _chk(lib().ofq_gemm_f32(C.byref(d), _p(ws), ws.numel() if ws is not None else 0, _stream()), "ofq_gemm_f32")
+    if timer is not None:
+        ev1.record()
     return Cout
 
 

@@ -1,0 +1,152 @@
+"""Data-parallel QAT over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI, gradients all-reduced in a few large flat buckets that are launched while backward is still running.
+
+This replaces the reference's `NativeDDP(model, device_ids=[local_rank])` (train.py:727) and its constructor
+broadcast (which is what makes rank 0's data-dependent LSQ step sizes, created by setup_alpha at train.py:657,
+the global ones).  Design notes for MI355X:
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so few, large
+    messages beat many small ones.  DeiT-S QKR has 90.8 MB of fp32 gradients: 4 buckets of ~24 MB by default.
+  * gradients live in flat bucket buffers (p.grad are views), so a bucket is reduced in place with no pack /
+    unpack copies, and AdamW reads the averaged values straight from the views.
+  * buckets are filled in reverse parameter order (heads and last blocks finish first in backward) and each is
+    launched from an autograd post-accumulate hook as soon as its last gradient lands.
+StatsQ statistics need no collective: s = 2*mean|W| is a pure function of replica-identical weights
+(SURVEY.md §2.3); `check_statsq_consistency` verifies exactly that with one tiny all-reduce.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    __slots__ = ("flat", "params", "pending", "work")
+
+    def __init__(self, flat, params):
+        self.flat, self.params = flat, params
+        self.pending = 0
+        self.work = None
+
+
+class DataParallel(torch.nn.Module):
+    def __init__(self, module, process_group=None, bucket_mb=24.0, broadcast=True):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._hooks = []
+        if broadcast and self.world > 1:
+            self.broadcast_parameters()
+        self._build_buckets(bucket_mb)
+
+    # -- rank 0's parameters and buffers win (train.py:727: DDP's constructor broadcast)
+    @torch.no_grad()
+    def broadcast_parameters(self):
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
+        for dtype in {t.dtype for t in tensors}:
+            group = [t for t in tensors if t.dtype == dtype]
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src=0, group=self.group)
+            off = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+
+    def _build_buckets(self, bucket_mb):
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        groups, cur, cur_n = [], [], 0
+        for p in reversed(params):                      # backward produces gradients roughly in reverse order
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            groups.append(cur)
+        self.buckets = []
+        self._bucket_of = {}
+        for grp in groups:
+            n = sum(p.numel() for p in grp)
+            flat = torch.zeros(n, dtype=grp[0].dtype, device=grp[0].device)
+            off = 0
+            for p in grp:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            b = GradBucket(flat, grp)
+            self.buckets.append(b)
+            for p in grp:
+                self._bucket_of[p] = b
+        if self.world > 1:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._reset()
+
+    def _reset(self):
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.work = None
+
+    def _launch(self, b):
+        # async all-reduce: the collective's stream waits for the gradient kernels already queued on the
+        # current (backward) stream, then runs concurrently with the rest of backward
+        b.flat.div_(self.world)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        if p.grad.data_ptr() != b.flat.data_ptr() + 4 * self._offset(b, p):
+            # autograd replaced the view (first accumulation into an undefined grad): copy back into the bucket
+            view = b.flat[self._offset(b, p):self._offset(b, p) + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _offset(self, b, p):
+        off = 0
+        for q in b.params:
+            if q is p:
+                return off
+            off += q.numel()
+        raise KeyError
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b.flat.zero_()
+
+    def finish_gradient_sync(self):
+        """Call after loss.backward() and before optimizer.step()."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b.work is None:                      # bucket with parameters that got no gradient this step
+                    self._launch(b)
+            for b in self.buckets:
+                b.work.wait()
+        self._reset()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def gradient_bytes(self):
+        return sum(b.flat.numel() * 4 for b in self.buckets)
+
+
+@torch.no_grad()
+def check_statsq_consistency(model, group=None):
+    """All-reduce(max - min) of every StatsQ scale vector: must be exactly 0 when replicas are in sync."""
+    vecs = [m._s_dev.reshape(-1) for m in model.modules() if getattr(m, "_s_dev", None) is not None]
+    if not vecs or not dist.is_initialized():
+        return 0.0
+    flat = torch.cat(vecs)
+    hi, lo = flat.clone(), flat.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    return float((hi - lo).abs().max())
+
+
+def reduce_tensor(t, world):
+    """timm.utils.reduce_tensor (train.py:952): mean over ranks of a scalar metric."""
+    rt = t.clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    return rt / world
