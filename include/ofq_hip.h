@@ -34,9 +34,10 @@ int ofq_abi_version(void);
 /* ---- K1  StatsQ weight quantiser: StatsQuantizer.forward, src/quantization/quantizer/statsq.py:133-150
  *  s_r = 2*mean_c|W_rc| ; L = rne(clamp(W/s,-1,1-1e-6)*n - 0.5) ; Wq = s*(L+0.5)/n ; out = (Wq - W) + W
  *  scale_given != 0: `scale` is an INPUT (used by tests to check levels bit-exactly for a given s).
- *  levels (int8, optional): L in [-n, n-1].  Backward is the identity (STE, statsq.py:148): no kernel. */
+ *  levels (int8, optional): L in [-n, n-1], or with odd_codes != 0 the odd integer 2L+1 (W_hat = s*(2L+1)/(2n)),
+ *  the exact integer operand of ofq_qgemm_i8_nt.  Backward is the identity (STE, statsq.py:148): no kernel. */
 int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
-                   int8_t* levels, int scale_given, ofq_stream_t stream);
+                   int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream);
 
 /* ---- K3/K5  LSQ activation quantiser with its LearnableBias sandwich:
  *  LsqQuantizer.forward lsq.py:571-602 (+ :72-101, :336-373, :419-437, :489-505), LsqQuantizer4v.forward
@@ -102,6 +103,24 @@ typedef struct ofq_gemm_desc {
 } ofq_gemm_desc;
 size_t ofq_gemm_ws_bytes(const ofq_gemm_desc* d);
 int ofq_gemm_f32(const ofq_gemm_desc* d, void* ws, size_t ws_bytes, ofq_stream_t stream);
+
+/* ---- exact integer-code GEMMs for the fake-quantised linear layers (same maths as F.linear on the fake-quant
+ *  values, qlinear.py:69, with the scales factored out of the contraction; see ofq_amd/csrc/qgemm.hip)
+ *  forward:  y[m,n] = col_mult*col_scale[n] * (a_eff[m % S] * sum_k A[m,k]*B[n,k] + r[n]) + bias[n]
+ *            A = LSQ codes of the input [M][K] int8, B = weight codes [N][K] int8, a_eff from lsq_s/gscale as in
+ *            ofq_lsq_fwd, r[n] = sum_k baft[k]*B[n,k] (ofq_rowdot_i8).  K, lda, ldb % 16 == 0.  i8 MFMA, exact. */
+int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
+                    float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N,
+                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream);
+/*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
+ *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.
+ *            K % 8 == 0, lda % 4 == 0, ldb % 8 == 0. */
+int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha, int accumulate,
+                       int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                       ofq_stream_t stream);
+/*  int8 codes [rows][cols] -> bf16 [cols][rows];   out[r] = sum_k vec[k]*codes[r][k] */
+int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
+int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);
 
 /* ---- column sum (bias gradients of F.linear: autograd of qlinear.py:71):  out[c] = sum_r x[r][c] */
 size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols);

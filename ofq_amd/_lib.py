@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "ofq_abi_version": (i32, []),
-    "ofq_statsq_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, i32, vp]),
+    "ofq_statsq_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, i32, i32, vp]),
     "ofq_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
@@ -35,6 +35,10 @@ SIGNATURES = {
     "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, sz, vp]),
     "ofq_gemm_ws_bytes": (sz, [C.POINTER(GemmDesc)]),
     "ofq_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
+    "ofq_qgemm_i8_nt": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64, vp]),
+    "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
+    "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_colsum_ws_bytes": (sz, [i64, i64]),
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),

@@ -5,4 +5,5 @@ extern "C" int ofq_abi_version(void) { return OFQ_ABI_VERSION; }
 #include "lsq.hip"
 #include "softmax_lsq.hip"
 #include "gemm_f32.hip"
+#include "qgemm.hip"
 #include "misc.hip"

@@ -1,0 +1,393 @@
+// Exact low-precision GEMMs for the fake-quantised linear layers (reference: F.linear qlinear.py:69 and its
+// autograd products).  Fake-quant operands are scale x small integer (+ a per-channel offset), so the scales are
+// factored out of the contraction and the matrix cores run on the integer codes, which int8 / bf16 represent
+// exactly; accumulation (i32, or fp32 over integers < 2^24) is exact as well.
+//
+//  ofq_qgemm_i8_nt    forward   y[m,n] = cs[n] * (a_eff[m % S] * sum_k qa[m,k] * qw[n,k] + r[n]) + bias[n]
+//                     qa = LSQ codes of the input, qw = 2L+1 (StatsQ) or the LSQ level of the weight, a_eff the
+//                     effective LSQ step, cs[n] = s[n]/(2*nlev) (StatsQ) or the weight step, r[n] = sum_k baft[k] qw[n,k]
+//                     (the post-quantiser offset's contribution).  v_mfma_i32_32x32x32_i8, exact.
+//  ofq_qgemm_bf16s_nt backward  dx[m,n] = alpha * sum_k (dy[m,k] * ks[k]) * qwT[n,k]
+//                     dy fp32 is scaled along k by the weight scale and split into three bf16 pieces
+//                     (dy*ks = hi + mid + lo exactly: 3 x 8 significand bits), qwT are the weight codes as bf16;
+//                     three v_mfma_f32_32x32x16_bf16 per k-step give the fp32-exact product at 3/16 of the fp32-MFMA cost.
+// Both kernels: 256 threads = 2x2 waves, 128x128 tile, operands K-contiguous ("NT"), branch-free staging with
+// clamped addresses, LDS rows padded by 16 B so that ds_read_b128 fragments are conflict-free.
+#include "common.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct QGemmArgs {
+  const void* A; const void* B; float* C;
+  const float* bias;     // [N] optional
+  const float* cs;       // i8: column scale [N]
+  const float* r;        // i8: offset term [N] (optional)
+  const float* s;        // i8: LSQ step vector [S];  bf16s: k-scale ks[K] (optional)
+  int64_t lda, ldb, ldc;
+  int M, N, K, S;
+  int tiles_m, tiles_n, accumulate;
+  float gscale, alpha;
+};
+
+__device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& tn) {
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int tile = blockIdx.x;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int xcd = tile & 7, loc = tile >> 3;
+  tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  tm = tile / p.tiles_n;
+  tn = tile % p.tiles_n;
+}
+
+// ------------------------------------------------------------------------------------------------ int8 forward
+#define QI8_BK 64                 // bytes of k per LDS stage (two 32x32x32 MFMA steps)
+#define QI8_LD (QI8_BK + 16)      // padded LDS row (bytes)
+
+__global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
+  int tm, tn;
+  qgemm_tile_id(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const unsigned char* A = (const unsigned char*)p.A;
+  const unsigned char* B = (const unsigned char*)p.B;
+  const int K = p.K;
+  const int nkt = (K + QI8_BK - 1) / QI8_BK;
+
+  // staging: 128 rows x 64 B per operand = 512 x 16 B -> 2 chunks per thread per operand
+  int64_t offA[2], offB[2];
+  bool okA[2], okB[2];
+  int kq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    const int row = f >> 2;
+    kq[i] = (f & 3) * 16;
+    okA[i] = (m0 + row) < p.M;
+    okB[i] = (n0 + row) < p.N;
+    offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + kq[i];
+    offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + kq[i];
+  }
+  i32x4 ra[2], rb[2];
+  auto gload = [&](int kt) {
+    const int k0 = kt * QI8_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool kin = (k0 + kq[i]) < K;                 // K % 16 == 0 (host check): a chunk is all in or all out
+      const i32x4 va = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq[i]));
+      const i32x4 vb = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq[i]));
+      const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
+      ra[i] = va & ma;
+      rb[i] = vb & mb;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 2;
+      *reinterpret_cast<i32x4*>(&smem[buf][row * QI8_LD + kq[i]]) = ra[i];
+      *reinterpret_cast<i32x4*>(&smem[buf][(BM + row) * QI8_LD + kq[i]]) = rb[i];
+    }
+  };
+
+  i32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1) < nkt;
+    if (more) gload(kt + 1);
+    const unsigned char* a = &smem[buf][(wm * 64 + l31) * QI8_LD + lh * 16];
+    const unsigned char* b = &smem[buf][(BM + wn * 64 + l31) * QI8_LD + lh * 16];
+#pragma unroll
+    for (int ks = 0; ks < QI8_BK / 32; ++ks) {
+      i32x4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const i32x4*>(a + i * 32 * QI8_LD + ks * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const i32x4*>(b + j * 32 * QI8_LD + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
+  float csn[2], rn[2], bz[2];
+  int ncol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ncol[j] = n0 + wn * 64 + j * 32 + l31;
+    const int nc = min(ncol[j], p.N - 1);
+    csn[j] = p.cs[nc] * p.alpha;
+    rn[j] = p.r ? p.r[nc] : 0.f;
+    bz[j] = p.bias ? p.bias[nc] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      const float ae = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (ncol[j] < p.N)
+          p.C[(int64_t)m * p.ldc + ncol[j]] =
+              __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bf16-split backward
+#define QBS_BK 32                      // k per stage
+#define QBS_LD (QBS_BK * 2 + 16)       // padded LDS row in bytes (bf16)
+
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
+  // two fp32 whose low 16 bits are zero -> one dword of two bf16 (element order: lo_elem first)
+  return (__float_as_uint(lo_elem) >> 16) | (__float_as_uint(hi_elem) & 0xffff0000u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSPLIT * PLANE + BN * QBS_LD];
+  int tm, tn;
+  qgemm_tile_id(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* A = (const float*)p.A;
+  const unsigned short* B = (const unsigned short*)p.B;
+  const int K = p.K;
+  const int nkt = (K + QBS_BK - 1) / QBS_BK;
+
+  // A: 128 rows x 32 fp32 = 1024 float4 -> 4 per thread (row = f >> 3, kq = f & 7)
+  // B: 128 rows x 32 bf16 = 512 x 16 B  -> 2 per thread (row = f >> 2, kq = f & 3)
+  int64_t offA[4], offB[2];
+  bool okA[4], okB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + 256 * i;
+    const int row = f >> 3;
+    okA[i] = (m0 + row) < p.M;
+    offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + (f & 7) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    const int row = f >> 2;
+    okB[i] = (n0 + row) < p.N;
+    offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + (f & 3) * 8;
+  }
+  const int kqa = (tid & 7) * 4;       // same for all 4 chunks (256 % 8 == 0)
+  const int kqb = (tid & 3) * 8;
+  float4 ra[4], rks;
+  i32x4 rb[2];
+  auto gload = [&](int kt) {
+    const int k0 = kt * QBS_BK;
+    const bool kina = (k0 + kqa) < K, kinb = (k0 + kqb) < K;       // K % 8 == 0 (host check)
+    rks = p.s ? *reinterpret_cast<const float4*>(p.s + (kina ? k0 + kqa : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = *reinterpret_cast<const float4*>(A + offA[i] + (kina ? k0 : -kqa));
+      if (!(okA[i] && kina)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const i32x4 v = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
+      rb[i] = v & ((okB[i] && kinb) ? -1 : 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 3;
+      float x[4] = {ra[i].x * rks.x, ra[i].y * rks.y, ra[i].z * rks.z, ra[i].w * rks.w};
+      float pc[NSPLIT][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rem = x[e];
+#pragma unroll
+        for (int sidx = 0; sidx < NSPLIT; ++sidx) {
+          const float h = trunc_bf16(rem);
+          pc[sidx][e] = h;
+          rem = __fsub_rn(rem, h);          // exact: h holds the leading 8 significand bits of rem
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < NSPLIT; ++sidx) {
+        uint2 w;
+        w.x = pack_hi16(pc[sidx][0], pc[sidx][1]);
+        w.y = pack_hi16(pc[sidx][2], pc[sidx][3]);
+        *reinterpret_cast<uint2*>(&smem[sidx * PLANE + row * QBS_LD + kqa * 2]) = w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 2;
+      *reinterpret_cast<i32x4*>(&smem[NSPLIT * PLANE + row * QBS_LD + kqb * 2]) = rb[i];
+    }
+  };
+
+  f32x16q acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+    const unsigned char* a = &smem[(wm * 64 + l31) * QBS_LD + lh * 16];
+    const unsigned char* b = &smem[NSPLIT * PLANE + (wn * 64 + l31) * QBS_LD + lh * 16];
+#pragma unroll
+    for (int ks = 0; ks < QBS_BK / 16; ++ks) {
+      bf16x8 bv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD + ks * 32);
+#pragma unroll
+      for (int sidx = 0; sidx < NSPLIT; ++sidx) {
+        bf16x8 av[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          av[i] = *reinterpret_cast<const bf16x8*>(a + sidx * PLANE + i * 32 * QBS_LD + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.M) {
+          float* dst = p.C + (int64_t)m * p.ldc + n;
+          float v = acc[i][j][e] * p.alpha;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+// codes^T as bf16: in int8 [R][Cc] -> out bf16 [Cc][R]   (weights only: a few MB per step)
+__global__ __launch_bounds__(256) void codes_transpose_bf16_kernel(const int8_t* __restrict__ in, unsigned short* __restrict__ out,
+                                                                   int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? (float)in[(int64_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) out[(int64_t)c * R + r] = (unsigned short)(__float_as_uint(tile[tx][i]) >> 16);
+  }
+}
+
+// r[n] = sum_k vec[k] * codes[n][k]   (the post-quantiser offset's contribution to every output column)
+__global__ __launch_bounds__(256) void rowdot_i8_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vec,
+                                                        float* __restrict__ out, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += vec[k] * (float)codes[(int64_t)n * K + k];
+  acc = ofq_wave_sum(acc);
+  if (lane == 0) out[n] = acc;
+}
+
+extern "C" int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream) {
+  if (!codes || !out_bf16 || rows <= 0 || cols <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(codes_transpose_bf16_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
+                     0, (hipStream_t)stream, codes, (unsigned short*)out_bf16, (int)rows, (int)cols);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols,
+                             ofq_stream_t stream) {
+  if (!codes || !vec || !out || rows <= 0 || cols <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(rowdot_i8_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vec, out,
+                     (int)rows, (int)cols);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
+                               float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,
+                               int64_t N, int64_t K,
+                               int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream) {
+  if (!A || !B || !C || !col_scale || !lsq_s || M <= 0 || N <= 0 || K <= 0 || S <= 0) return OFQ_EINVAL;
+  if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30)) return OFQ_EINVAL;
+  QGemmArgs a = {};
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult;
+  hipLaunchKernelGGL(qgemm_i8_nt_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha,
+                                  int accumulate, int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                  int64_t ldc, ofq_stream_t stream) {
+  if (!A || !B_bf16 || !C || M <= 0 || N <= 0 || K <= 0) return OFQ_EINVAL;
+  if ((K & 7) || (lda & 3) || (ldb & 7) || !al16(A) || !al16(B_bf16) || (k_scale && !al16(k_scale)) || M >= (1ll << 30) ||
+      N >= (1ll << 30) || (nsplit != 2 && nsplit != 3))
+    return OFQ_EINVAL;
+  QGemmArgs a = {};
+  a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate;
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -8,7 +8,7 @@
 __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict__ W, int64_t rows, int64_t cols,
                                                          float n, float* __restrict__ out,
                                                          float* __restrict__ scale, int8_t* __restrict__ levels,
-                                                         int scale_given) {
+                                                         int scale_given, int odd_codes) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
       r.x = q1(t.x, L0); r.y = q1(t.y, L1); r.z = q1(t.z, L2); r.w = q1(t.w, L3);
       o4[i] = r;
       if (lv) {
+        if (odd_codes) { L0 = 2.f * L0 + 1.f; L1 = 2.f * L1 + 1.f; L2 = 2.f * L2 + 1.f; L3 = 2.f * L3 + 1.f; }
         char4 c4 = make_char4((signed char)L0, (signed char)L1, (signed char)L2, (signed char)L3);
         reinterpret_cast<char4*>(lv)[i] = c4;
       }
@@ -61,18 +62,19 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
     for (int64_t i = lane; i < cols; i += 64) {
       float L;
       o[i] = q1(w[i], L);
-      if (lv) lv[i] = (int8_t)L;
+      if (lv) lv[i] = (int8_t)(odd_codes ? 2.f * L + 1.f : L);
     }
   }
 }
 
 extern "C" int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
-                              int8_t* levels, int scale_given, ofq_stream_t stream) {
+                              int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream) {
   if (!W || !out || !scale || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
+  if (odd_codes && bits > 7) return OFQ_EINVAL;       // 2L+1 must fit int8
   float n = (float)(1 << (bits - 1));
   dim3 grid((unsigned)((rows + 3) / 4));
   hipLaunchKernelGGL(statsq_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, rows, cols, n, out, scale,
-                     levels, scale_given);
+                     levels, scale_given, odd_codes);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -39,6 +39,57 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(ctx.in_shape) if dx is not None else None), dW, db
 
 
+class CodesLinearFn(torch.autograd.Function):
+    """Same function as LinearFn, computed on the integer codes: forward is one exact int8-MFMA GEMM with the
+    scales applied in the epilogue (ofq_qgemm_i8_nt), dX is the 3-way bf16-split GEMM against the transposed
+    weight codes (ofq_qgemm_bf16s_nt, fp32-exact), dW stays a split-K fp32-MFMA GEMM on the fake-quant input.
+    `xq` / `Wq` are the fp32 fake-quant tensors (they carry the autograd edges to the quantisers); `aux` holds
+    the non-differentiable codes and scales."""
+
+    @staticmethod
+    def forward(ctx, xq, Wq, bias, aux):
+        shp = xq.shape
+        K = shp[-1]
+        x2d = xq.reshape(-1, K)
+        r = ops.rowdot_i8(aux["wcodes"], aux["baft"]) if aux["baft"] is not None else None
+        y = ops.qgemm_i8_nt(aux["xcodes"].view(-1, K), aux["wcodes"], bias, aux["w_scale"], aux["w_mult"], r,
+                            aux["act_s"], aux["act_S"], aux["act_gscale"])
+        ctx.save_for_backward(x2d)
+        ctx.aux = aux
+        ctx.has_bias = bias is not None
+        ctx.in_shape = shp
+        return y.view(*shp[:-1], Wq.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2d,) = ctx.saved_tensors
+        aux = ctx.aux
+        dy2d = dy.reshape(-1, dy.shape[-1])
+        if not dy2d.is_contiguous():
+            dy2d = dy2d.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"]).view(ctx.in_shape)
+        dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy2d) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dW, db, None
+
+
+def codes_linear_ok(in_features, wquant, act_quant):
+    """The code GEMMs need K % 16 == 0, StatsQ weights of <= 7 bits (2L+1 in int8) and activation codes in int8."""
+    return (in_features % 16 == 0 and wquant.num_bits <= 7 and act_quant.thd_neg >= -128 and act_quant.thd_pos <= 127)
+
+
+def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias):
+    """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True)."""
+    Wq = wquant(weight, want_codes=True)
+    aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev,
+           "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
+           "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
+           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale}
+    return CodesLinearFn.apply(xq, Wq, bias, aux)
+
+
 class WqkFn(torch.autograd.Function):
     """W_qk[h] = W_q[h]^T @ W_k[h]  ->  (H*C, C)   (attention.py:190-194)."""
 

@@ -78,7 +78,7 @@ def workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ StatsQ
-def statsq_fwd(W, bits, want_levels=False, scale=None):
+def statsq_fwd(W, bits, want_levels=False, scale=None, odd_codes=False):
     _dev(W, "weight")
     W = W.contiguous()
     rows, cols = W.shape
@@ -87,7 +87,7 @@ def statsq_fwd(W, bits, want_levels=False, scale=None):
     s = scale.contiguous() if given else torch.empty(rows, dtype=torch.float32, device=W.device)
     lv = torch.empty((rows, cols), dtype=torch.int8, device=W.device) if want_levels else None
     _chk(lib().ofq_statsq_fwd(W.data_ptr(), rows, cols, bits, out.data_ptr(), s.data_ptr(), _p(lv), int(given),
-                              _stream()), "ofq_statsq_fwd")
+                              int(odd_codes), _stream()), "ofq_statsq_fwd")
     return out, s, lv
 
 
@@ -216,6 +216,44 @@ def linear_bwd_weight(dy, x2d):
     K = x2d.shape[1]
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     return gemm(dy, x2d, dW, N, K, M, dy.stride(0), x2d.stride(0), K, transA=True, split_k=_pick_split(N, K, M))
+
+
+# ------------------------------------------------------------------------------------------------ code GEMMs
+def codes_transpose_bf16(codes):
+    rows, cols = codes.shape
+    out = torch.empty((cols, rows), dtype=torch.bfloat16, device=codes.device)
+    _chk(lib().ofq_codes_transpose_bf16(codes.data_ptr(), out.data_ptr(), rows, cols, _stream()), "ofq_codes_transpose_bf16")
+    return out
+
+
+def rowdot_i8(codes, vec):
+    rows, cols = codes.shape
+    out = torch.empty(rows, dtype=torch.float32, device=codes.device)
+    _chk(lib().ofq_rowdot_i8(codes.data_ptr(), vec.data_ptr(), out.data_ptr(), rows, cols, _stream()), "ofq_rowdot_i8")
+    return out
+
+
+def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale):
+    """y = col_mult*col_scale[n]*(a_eff[m % S]*(xcodes @ wcodes^T) + r[n]) + bias[n]"""
+    M, K = xcodes.shape
+    N = wcodes.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=xcodes.device)
+    _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
+                               col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
+                               wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
+    return y
+
+
+def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3):
+    """out[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k],  A fp32, B bf16 integer codes"""
+    M, K = A.shape
+    N = B_bf16.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
+                                  nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),
+         "ofq_qgemm_bf16s_nt")
+    return out
 
 
 def colsum(x2d):

@@ -14,7 +14,9 @@ from ..quantizer.lsq import LsqQuantizer, LsqQuantizer4v
 from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkreparam_cga
 from ...deit_vision_transformer import Attention as deit_attention
 from ... import ops
-from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn)
+from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn, codes_linear,
+                           codes_linear_ok)
+from . import qlinear as _ql
 
 
 def _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise, weight_quant_method,
@@ -134,14 +136,22 @@ class QAttention_qkreparam(deit_attention):
     def forward(self, x):
         B, N, C = x.shape
         H = self.num_heads
-        xq = self.quant_x_4_qkv(x)                                               # attention.py:177
-        # ---- V branch (:179-187)
-        Wv = self.v_quant(self.v.weight)
-        v = LinearFn.apply(xq, Wv, self.v.bias)
+        xin = self.quant_x_4_qkv
+        use_codes = _ql.USE_CODE_GEMM and codes_linear_ok(C, self.v_quant, xin.input_quant_fn)
+        if use_codes:
+            xq, xcodes, xgeom = xin(x, want_codes=True)                          # attention.py:177
+            v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
+                             self.v.bias)                                        # :179-181
+        else:
+            xq = xin(x)
+            v = LinearFn.apply(xq, self.v_quant(self.v.weight), self.v.bias)
         v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
-        Wqk = self.qk_quant(WqkFn.apply(self.q.weight, self.k.weight, H))
-        qkx = LinearFn.apply(xq, Wqk, None)                                      # (B, N, H*C)   einsum :200
+        Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
+        if use_codes:
+            qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None)
+        else:
+            qkx = LinearFn.apply(xq, self.qk_quant(Wqk_fp), None)                # (B, N, H*C)   einsum :200
         qkx = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
                                        shape=(B, N * H, C), out_shape=(B, N, H, C))   # :201-206, s per (token, head)
         S = QKRScoresFn.apply(xq, qkx, H)                                        # :210

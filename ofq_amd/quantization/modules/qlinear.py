@@ -10,7 +10,12 @@ from ..quantizer.statsq import StatsQuantizer
 from ..quantizer.lsq import (LsqQuantizer, LsqQuantizerWeight, LsqQuantizer4img, LsqQuantizer4Conv2d,
                              LsqQuantizer4head_input)
 from ...deit_vision_transformer import Mlp, to_2tuple
-from ...functional import LinearFn
+from ...functional import LinearFn, codes_linear, codes_linear_ok
+
+
+# Exact integer-code GEMMs (int8 forward, bf16-split dX) instead of the fp32-MFMA GEMM on fake-quant values.
+# Same mathematical function; toggled off by the parity tests that compare the two paths.
+USE_CODE_GEMM = True
 
 
 class LSQ_input(nn.Module):
@@ -25,8 +30,8 @@ class LSQ_input(nn.Module):
         self.move_b4 = LearnableBias(learanbaleBiasdim)
         self.move_aft = LearnableBias(learanbaleBiasdim)
 
-    def forward(self, input):
-        return self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias)
+    def forward(self, input, want_codes=False):
+        return self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=want_codes)
 
 
 class QLinear(nn.Linear):
@@ -58,10 +63,14 @@ class QLinear(nn.Linear):
         self._prologue = 0          # 1: exact GELU fused in front of the input quantiser (set by QMLP for fc2)
 
     def forward(self, input):
-        if self.weight_quant_method == "statsq":
-            weight = self.statsq_fn(self.weight)                                 # qlinear.py:62
-        else:
+        if self.weight_quant_method != "statsq":
             raise ValueError("Unknown quant_method")
+        if USE_CODE_GEMM and codes_linear_ok(self.in_features, self.statsq_fn, self.input_quant_fn):
+            xq, xcodes, geom = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias,
+                                                         prologue=self._prologue, want_codes=True)
+            return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
+                                self.statsq_fn, self.bias)
+        weight = self.statsq_fn(self.weight)                                     # qlinear.py:62
         xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, prologue=self._prologue)
         return LinearFn.apply(xq, weight, self.bias)                             # qlinear.py:69-71
 

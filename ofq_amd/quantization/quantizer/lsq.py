@@ -26,20 +26,23 @@ class _LsqFn(torch.autograd.Function):
     """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
 
     @staticmethod
-    def forward(ctx, x, s, b4, baft, geom):
-        y, _ = ops.lsq_fwd(x, s, b4, baft, geom)
+    def forward(ctx, x, s, b4, baft, geom, want_codes):
+        y, codes = ops.lsq_fwd(x, s, b4, baft, geom, want_codes=want_codes)
         ctx.save_for_backward(x, s, b4)
         ctx.geom = geom
         ctx.has_bias = b4 is not None
-        return y
+        if codes is None:
+            codes = torch.empty(0, dtype=torch.int8, device=x.device)
+        ctx.mark_non_differentiable(codes)
+        return y, codes
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gcodes):
         x, s, b4 = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx.view(x.shape), ds, db4, dbaft, None
+        return dx.view(x.shape), ds, db4, dbaft, None, None
 
 
 class _LsqBase(nn.Module):
@@ -67,7 +70,8 @@ class _LsqBase(nn.Module):
         self.s = nn.Parameter(init_val.to(xin.device).float().contiguous().clone(), requires_grad=bool(self.learnable))
         self.initialized_alpha = True
 
-    def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None):
+    def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
+              want_codes=False):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
         is a strided column slice)."""
         if not x.is_cuda:
@@ -83,8 +87,11 @@ class _LsqBase(nn.Module):
                 xin = self._add_bias_for_init(xin, b4.detach())
             self.init_from(xin)
         geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
-        y = _LsqFn.apply(x, self.s, b4, baft, geom)
-        return y.view(out_shape if out_shape is not None else shp)
+        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes)
+        y = y.view(out_shape if out_shape is not None else shp)
+        if want_codes:
+            return y, codes, geom
+        return y
 
     def _add_bias_for_init(self, xin, b4):
         return xin + b4

@@ -9,14 +9,16 @@ from ... import ops
 
 class _StatsQFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, bits, holder):
-        out, s, _ = ops.statsq_fwd(weight, bits)
+    def forward(ctx, weight, bits, holder, want_codes):
+        out, s, codes = ops.statsq_fwd(weight, bits, want_levels=want_codes, odd_codes=want_codes)
         holder._s_dev = s
+        holder._codes = codes                      # int8 (2L+1), [out][in]: operand of the exact i8 forward GEMM
+        holder._codesT = None                      # bf16 [in][out], built on demand for the backward GEMM
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, None, None          # statsq.py:148: Wq.detach() - W.detach() + W  => dW = g
+        return g, None, None, None    # statsq.py:148: Wq.detach() - W.detach() + W  => dW = g
 
 
 class StatsQuantizer(nn.Module):
@@ -25,6 +27,14 @@ class StatsQuantizer(nn.Module):
         self.num_bits = num_bits
         self.clip_val = nn.Parameter(torch.Tensor([2.0]), requires_grad=False)     # statsq.py:126-128
         self._s_dev = None
+        self._codes = None
+        self._codesT = None
+
+    def codes_T(self):
+        """Weight codes transposed to [in][out] as bf16 (exact small integers) for dX = dY @ W_hat."""
+        if self._codesT is None:
+            self._codesT = ops.codes_transpose_bf16(self._codes)
+        return self._codesT
 
     @property
     def s(self):
@@ -32,10 +42,10 @@ class StatsQuantizer(nn.Module):
         call, statsq.py:143; here the copy happens only when somebody reads it)."""
         return None if self._s_dev is None else self._s_dev.detach().cpu()
 
-    def forward(self, weight):
+    def forward(self, weight, want_codes=False):
         if weight.dim() != 2:
             raise ValueError("StatsQuantizer: only 2-D weights are on the hot path (statsq.py:137-138)")
-        return _StatsQFn.apply(weight, self.num_bits, self)
+        return _StatsQFn.apply(weight, self.num_bits, self, bool(want_codes) and self.num_bits <= 7)
 
     def extra_repr(self):
         return "num_bits=%d" % self.num_bits

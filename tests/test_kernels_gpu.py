@@ -329,3 +329,48 @@ def test_cga_golden_bit_exact(ops):
 def test_cpu_tensors_are_rejected_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.statsq_fwd(torch.zeros(4, 8), 2)
+
+
+# ------------------------------------------------------------------------------------------------ exact code GEMMs
+@pytest.mark.parametrize("mnk", [(396, 384, 384), (792, 1536, 384), (200, 384, 1536), (130, 70, 48), (64, 2304, 384)])
+def test_qgemm_i8_forward_is_exact(ops, mnk):
+    M, N, K = mnk
+    rs = np.random.RandomState(3)
+    qa = torch.from_numpy(rs.randint(-8, 8, (M, K)).astype(np.int8))
+    qw = torch.from_numpy((2 * rs.randint(-4, 4, (N, K)) + 1).astype(np.int8))
+    S = 198 if M % 198 == 0 else M
+    s = T(det_uniform((S,), 71, 0.1, 1.0))
+    s[1] = 3e-6                                                    # below the 1e-5 floor
+    cs = T(det_uniform((N,), 72, 0.01, 0.1))
+    baft = T(det_uniform((K,), 73, -0.05, 0.05))
+    bias = T(det_uniform((N,), 74, -0.1, 0.1))
+    gscale = 1.0 / math.sqrt(7 * 4 * K)
+    r = ops.rowdot_i8(qw.cuda(), baft.cuda())
+    assert rel_err(r.cpu(), (qw.double() @ baft.double()).float()) < 1e-6
+    y = ops.qgemm_i8_nt(qa.cuda(), qw.cuda(), bias.cuda(), cs.cuda(), 0.125, r, s.cuda(), S, gscale)
+    ae = O.lsq_effective_scale(s, gscale)[torch.arange(M) % S].double()
+    ref = (0.125 * cs.double()) * (ae[:, None] * (qa.double() @ qw.double().t()) + (qw.double() @ baft.double())) + bias.double()
+    assert rel_err(y.cpu(), ref.float()) < 1e-6
+    # same numbers as the fp32 path on the fake-quant values: x_hat = ae*qa + baft, W_hat = cs/8 * qw
+    xh = (ae[:, None] * qa.double() + baft.double()).float()
+    wh = ((0.125 * cs.double())[:, None] * qw.double()).float()
+    y2 = ops.linear_fwd(xh.cuda(), wh.cuda(), bias.cuda())
+    assert rel_err(y.cpu(), y2.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("mnk", [(396, 384, 384), (792, 384, 1536), (200, 1536, 384), (130, 72, 40), (256, 384, 2304)])
+@pytest.mark.parametrize("nsplit", [3, 2])
+def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
+    M, N, K = mnk
+    rs = np.random.RandomState(4)
+    dy = T(det_normalish((M, K), 81, 1.0)) * T(det_uniform((M, 1), 82, 1e-4, 10.0))     # wide dynamic range
+    ks = T(det_uniform((K,), 83, 0.01, 0.1))
+    wcodes = torch.from_numpy((2 * rs.randint(-8, 8, (K, N)) + 1).astype(np.int8))       # [o][c] layout, o = k here
+    wT = ops.codes_transpose_bf16(wcodes.cuda())                                        # [c][o] bf16
+    assert torch.equal(wT.float().cpu(), wcodes.float().t())
+    out = ops.qgemm_bf16s_nt(dy.cuda(), wT, ks.cuda(), 0.25, nsplit=nsplit)
+    ref = 0.25 * ((dy.double() * ks.double()) @ wcodes.double())
+    err = float(((out.cpu().double() - ref).abs() / (((dy.double() * ks.double()).abs() @ wcodes.double().abs()) * 0.25 + 1e-30)).max())
+    assert err < (2e-7 if nsplit == 3 else 2e-5), err
+    out2 = ops.qgemm_bf16s_nt(dy.cuda(), wT, ks.cuda(), 0.25, out=out.clone(), accumulate=True, nsplit=nsplit)
+    assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)

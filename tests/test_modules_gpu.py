@@ -196,3 +196,43 @@ def test_modules_reject_cpu_tensors(env):
     q = QLinear(m=_linear(16, 8), weight_bits=2, input_bits=2, pretrained_initialized=True)
     with pytest.raises(RuntimeError):
         q(torch.zeros(2, 3, 16))
+
+
+def test_code_gemm_path_equals_fp32_gemm_path(env):
+    """The integer-code GEMMs (int8 forward, bf16-split dX) and the fp32-MFMA GEMM on fake-quant values are the same
+    function: identical module, identical inputs, both paths."""
+    from ofq_amd.quantization.modules import qlinear as ql
+    from ofq_amd.quantization.modules.attention import QAttention_qkreparam
+    from ofq_amd.quantization.modules.qlinear import QMLP
+    from ofq_amd.deit_vision_transformer import Attention, Mlp
+    torch.manual_seed(3)
+    B, N, C, H = 4, 198, 192, 3
+    for make in (lambda: QAttention_qkreparam(m=Attention(dim=C, num_heads=H, qkv_bias=True), weight_bits=2, input_bits=2,
+                                              pretrained_initialized=True),
+                 lambda: QMLP(m=Mlp(in_features=C, hidden_features=4 * C, act_layer=nn.GELU), weight_bits=4, input_bits=4,
+                              act_layer=nn.GELU, pretrained_initialized=True)):
+        torch.manual_seed(5)
+        mod = make().cuda().train()
+        with torch.no_grad():
+            for n_, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(B, N, C, device="cuda")
+        gy = torch.randn(B, N, C, device="cuda")
+        with torch.no_grad():
+            mod(x)
+        res = {}
+        for flag in (False, True):
+            ql.USE_CODE_GEMM = flag
+            mod.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            y = mod(xg)
+            y = y[0] if isinstance(y, tuple) else y
+            (y * gy).sum().backward()
+            res[flag] = (y.detach().clone(), xg.grad.clone(), {n_: p.grad.clone() for n_, p in mod.named_parameters()
+                                                                if p.grad is not None})
+        ql.USE_CODE_GEMM = True
+        assert rel_err(res[True][0], res[False][0]) < 1e-5
+        assert _rel_l2(res[True][1], res[False][1]) < 1e-4
+        for n_ in res[False][2]:
+            assert _rel_l2(res[True][2][n_], res[False][2][n_]) < 1e-3 or "move_" in n_, n_
