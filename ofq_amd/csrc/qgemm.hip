@@ -20,6 +20,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x16q __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 struct QGemmArgs {
   const void* A; const void* B; float* C;
   const float* bias;     // [N] optional
@@ -310,6 +312,209 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16-split dW (TN)
+// dW[o,c] = sum_m (dY[m,o] * a_eff[m % S]) * qx[m,c]  +  db[o] * baft[c]          (autograd of F.linear wrt the weight:
+// dY^T @ X_hat with X_hat = a_eff*qx + baft).  Both operands are contiguous along the NON-contracted dimension, so
+// they are staged in their natural [k][t] layout (dY split into three bf16 planes, the int8 codes widened to bf16)
+// and the MFMA fragments are fetched with the gfx950 LDS transpose read ds_read_b64_tr_b16: within a 16-lane group
+// lane p supplies the 8-byte chunk (row k0 + p/4, cols t0 + 4*(p%4) .. +3) and receives column t0 + p, rows k0..k0+3.
+// LDS rows are padded to 320 B so the two 16-lane groups of a half-wave (4 rows x 32 B each) hit disjoint banks.
+// Split-K over the token dimension; partials are reduced in a fixed order together with the rank-1 offset term.
+#define QTN_BK 32
+#define QTN_LD 320                      // bytes per LDS row: 128 bf16 + 64 B pad
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct QTnArgs {
+  const float* A;        // dY   [Ktok][M]  (M = out features)
+  const int8_t* B;       // codes [Ktok][N] (N = in features)
+  float* ws;             // [split][M][N]
+  const float* s;        // LSQ step vector [S]
+  int64_t lda, ldb;
+  int M, N, Ktok, S, split, tiles_m, tiles_n;
+  float gscale;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
+  // two transpose reads: k rows 0..3 and 4..7 of this lane's k-group
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * QTN_LD));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
+  // two small signed integers -> packed bf16 pair (exact for |v| <= 256)
+  return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
+  constexpr int BM = 128, BN = 128, NS = 3;
+  constexpr int PLANE = QTN_BK * QTN_LD;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(NS + 1) * PLANE];
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = blockIdx.x % ntiles, sidx = blockIdx.x / ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
+  const int tps = (nkt + p.split - 1) / p.split;
+  const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
+
+  // staging maps
+  const int a_k = tid >> 5, a_t = (tid & 31) * 4;          // + 8*i rows
+  const int b_k = tid >> 3, b_c = (tid & 7) * 16;
+  const bool a_ok = (m0 + a_t) < p.M;                      // M % 4 == 0 (host check)
+  const bool b_ok = (n0 + b_c) < p.N;                      // N % 16 == 0
+  const float* Ap = p.A + (a_ok ? m0 + a_t : 0);
+  const int8_t* Bp = p.B + (b_ok ? n0 + b_c : 0);
+  float4 ra[4];
+  float rs[4];
+  i32x4 rb;
+  auto gload = [&](int kt) {
+    const int k0 = kt * QTN_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + a_k + 8 * i;
+      const int kc = min(k, p.Ktok - 1);
+      float4 v = *reinterpret_cast<const float4*>(Ap + (int64_t)kc * p.lda);
+      if (!(a_ok && k < p.Ktok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = v;
+      rs[i] = ofq_lsq_eff_scale(p.s[kc % p.S], p.gscale);
+    }
+    const int k = k0 + b_k;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb);
+    rb = v & ((b_ok && k < p.Ktok) ? -1 : 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x[4] = {ra[i].x * rs[i], ra[i].y * rs[i], ra[i].z * rs[i], ra[i].w * rs[i]};
+      float pc[NS][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rem = x[e];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float h = trunc_bf16(rem);
+          pc[q][e] = h;
+          rem = __fsub_rn(rem, h);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 w;
+        w.x = pack_hi16(pc[q][0], pc[q][1]);
+        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        *reinterpret_cast<uint2*>(&smem[q * PLANE + (a_k + 8 * i) * QTN_LD + a_t * 2]) = w;
+      }
+    }
+    // 16 int8 codes -> 16 bf16
+    unsigned w[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int word = rb[d];
+      w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
+      w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
+    }
+    unsigned char* dst = &smem[NS * PLANE + b_k * QTN_LD + b_c * 2];
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+  };
+
+  f32x16q acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // per-lane transpose-read address inside a [k][t] plane (k-step 0, fragment column block 0)
+  const int p16 = lane & 15;
+  const int fr_off = (8 * lh + (p16 >> 2)) * QTN_LD + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+
+  if (t_begin < t_end) {
+    gload(t_begin);
+    for (int kt = t_begin; kt < t_end; ++kt) {
+      lstore();
+      __syncthreads();
+      if (kt + 1 < t_end) gload(kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < QTN_BK / 16; ++ks) {
+        bf16x8 bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bv[j] = tr_frag(&smem[NS * PLANE + ks * 16 * QTN_LD + fr_off + (wn * 64 + j * 32) * 2]);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          bf16x8 av[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) av[i] = tr_frag(&smem[q * PLANE + ks * 16 * QTN_LD + fr_off + (wm * 64 + i * 32) * 2]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* W = p.ws + (int64_t)sidx * p.M * p.N;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
+      }
+  }
+}
+
+// dW[o][c] = sum_s ws[s][o][c] + db[o] * baft[c]
+__global__ __launch_bounds__(256) void qgemm_tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                              const float* __restrict__ db, const float* __restrict__ baft,
+                                                              int M, int N, int split) {
+  const int64_t MN = (int64_t)M * N;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MN) return;
+  float acc = 0.f;
+  for (int s = 0; s < split; ++s) acc += ws[(int64_t)s * MN + i];
+  if (db && baft) acc += db[i / N] * baft[i % N];
+  C[i] = acc;
+}
+
+extern "C" size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split) {
+  return (size_t)split * M * N * sizeof(float);
+}
+
+extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S,
+                                  float gscale, const float* db, const float* baft, int64_t Ktok, int64_t M, int64_t N,
+                                  int64_t lda, int64_t ldb, int split, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!dY || !codes || !dW || !lsq_s || !ws || Ktok <= 0 || M <= 0 || N <= 0 || S <= 0 || split < 1) return OFQ_EINVAL;
+  if ((M & 3) || (N & 15) || (lda & 3) || (ldb & 15) || !al16(dY) || !al16(codes) || Ktok >= (1ll << 30)) return OFQ_EINVAL;
+  if (ws_bytes < ofq_qgemm_bf16s_tn_ws_bytes(M, N, split)) return OFQ_ENOWS;
+  QTnArgs a = {};
+  a.A = dY; a.B = codes; a.ws = (float*)ws; a.s = lsq_s; a.lda = lda; a.ldb = ldb;
+  a.M = (int)M; a.N = (int)N; a.Ktok = (int)Ktok; a.S = (int)S; a.split = split;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
+  OFQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, (const float*)ws, dW, db,
+                     baft, (int)M, (int)N, split);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ helpers
 // codes^T as bf16: in int8 [R][Cc] -> out bf16 [Cc][R]   (weights only: a few MB per step)
 __global__ __launch_bounds__(256) void codes_transpose_bf16_kernel(const int8_t* __restrict__ in, unsigned short* __restrict__ out,
@@ -356,8 +561,6 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
   OFQ_LAUNCH_CHECK();
   return 0;
 }
-
-static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
                                float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,

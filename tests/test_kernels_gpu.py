@@ -374,3 +374,27 @@ def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     assert err < (2e-7 if nsplit == 3 else 2e-5), err
     out2 = ops.qgemm_bf16s_nt(dy.cuda(), wT, ks.cuda(), 0.25, out=out.clone(), accumulate=True, nsplit=nsplit)
     assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(792, 384, 384), (1188, 1536, 384), (396, 384, 1536), (500, 72, 48), (2000, 2304, 384)])
+def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
+    Ktok, Mo, Nc = shape
+    rs = np.random.RandomState(5)
+    dy = T(det_normalish((Ktok, Mo), 91, 1.0)) * T(det_uniform((Ktok, 1), 92, 1e-3, 10.0))
+    codes = torch.from_numpy(rs.randint(-8, 8, (Ktok, Nc)).astype(np.int8))
+    S = 198 if Ktok % 198 == 0 else Ktok
+    s = T(det_uniform((S,), 93, 0.1, 1.0))
+    gscale = 0.01
+    baft = T(det_uniform((Nc,), 94, -0.05, 0.05))
+    db = dy.double().sum(0).float()
+    ae = O.lsq_effective_scale(s, gscale)[torch.arange(Ktok) % S].double()
+    ref = (dy.double() * ae[:, None]).t() @ codes.double() + db.double()[:, None] * baft.double()[None, :]
+    den = ((dy.double() * ae[:, None]).abs().t() @ codes.double().abs()) + 1e-30
+    for split in (None, 1, 5):
+        dW = ops.qgemm_bf16s_tn(dy.cuda(), codes.cuda(), s.cuda(), S, gscale, db.cuda(), baft.cuda(), split=split)
+        err = float(((dW.cpu().double() - ref).abs() / den).max())
+        assert err < 1e-6, (split, err)
+    # identical to the fp32-MFMA GEMM on the fake-quant values
+    xh = (ae[:, None] * codes.double() + baft.double()).float()
+    dW2 = ops.linear_bwd_weight(dy.cuda(), xh.cuda())
+    assert rel_err(dW.cpu(), dW2.cpu()) < 1e-5
