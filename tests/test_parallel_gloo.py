@@ -1,0 +1,116 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel layer: rank-0 broadcast of parameters and
+lazily-created LSQ steps, flat-bucket gradient all-reduce launched from autograd hooks, equality with the
+single-process gradient on the concatenated batch, and the StatsQ replica-consistency check."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 32)
+        self.c = nn.Linear(32, 4)
+        self.register_buffer("signed", torch.zeros(1))
+        self.frozen = nn.Parameter(torch.tensor([2.0]), requires_grad=False)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofq_amd.parallel import DataParallel, check_statsq_consistency
+    torch.manual_seed(100 + rank)                       # different init on every rank ...
+    net = Net()
+    if rank == 0:
+        net.signed.fill_(1.0)
+        net.extra = nn.Parameter(torch.full((3,), 7.0))  # ... and a late-created parameter (like an LSQ `s`)
+    else:
+        net.extra = nn.Parameter(torch.zeros(3))
+    dp = DataParallel(net, bucket_mb=0.002)             # tiny buckets -> several collectives in flight
+    # rank 0 wins
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [net.signed])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref)
+    assert float(net.signed) == 1.0 and float(net.extra[0]) == 7.0
+    assert len(dp.buckets) >= 3
+    # one step on a rank-specific shard
+    torch.manual_seed(7)
+    X = torch.randn(8, 16)
+    Y = torch.randn(8, 4)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    dp.zero_grad()
+    loss = ((dp(xs) - ys) ** 2).mean() + 0.0 * net.extra.sum()
+    loss.backward()
+    dp.finish_gradient_sync()
+    g_dp = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
+    # single-process reference on the full batch
+    import copy
+    net2 = copy.deepcopy(net)
+    for p in net2.parameters():
+        p.grad = None
+    (((net2(X) - Y) ** 2).mean() + 0.0 * net2.extra.sum()).backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in net2.parameters() if p.requires_grad])
+    assert torch.allclose(g_dp, g_ref, rtol=1e-5, atol=1e-7), float((g_dp - g_ref).abs().max())
+    # gradients are views into the flat buckets (no pack/unpack copies)
+    for b in dp.buckets:
+        for p in b.params:
+            assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
+    # second step works after the reset, and optimizer steps keep replicas identical
+    opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=1e-2)
+    for _ in range(2):
+        dp.zero_grad()
+        ((dp(xs) - ys) ** 2).mean().backward()
+        dp.finish_gradient_sync()
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo, hi)
+    # StatsQ statistic is a pure function of the (identical) weights: max - min over ranks must be exactly 0
+    class Holder(nn.Module):
+        pass
+    h = Holder()
+    h._s_dev = 2 * net.a.weight.detach().abs().mean(1)
+    net.holder = h
+    assert check_statsq_consistency(net) == 0.0
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
