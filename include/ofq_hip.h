@@ -120,11 +120,13 @@ int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float
                        ofq_stream_t stream);
 /*  weight gradient: dW[o,c] = sum_m (dY[m,o] * a_eff[m % S]) * codes[m,c] + db[o]*baft[c]  (= dY^T @ X_hat with
  *            X_hat = a_eff*codes + baft).  dY fp32 [Ktok][M], codes int8 [Ktok][N]; three bf16 pieces of dY*a_eff,
- *            LDS transpose reads, split-K over tokens with a deterministic reduction.  M % 4 == 0, N % 16 == 0. */
+ *            LDS transpose reads, split-K over tokens with a deterministic reduction.  M % 4 == 0, N % 16 == 0.
+ *            compute_db != 0: db[o] = sum_m dY[m,o] (the bias gradient) is produced by the same pass over dY and
+ *            written to `db`; otherwise `db` (may be NULL) is an input. */
 size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split);
 int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S, float gscale,
-                       const float* db, const float* baft, int64_t Ktok, int64_t M, int64_t N, int64_t lda, int64_t ldb,
-                       int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                       float* db, int compute_db, const float* baft, int64_t Ktok, int64_t M, int64_t N, int64_t lda,
+                       int64_t ldb, int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
 /*  int8 codes [rows][cols] -> bf16 [cols][rows];   out[r] = sum_k vec[k]*codes[r][k] */
 int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
 int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);

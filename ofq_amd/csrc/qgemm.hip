@@ -328,6 +328,7 @@ struct QTnArgs {
   const float* A;        // dY   [Ktok][M]  (M = out features)
   const int8_t* B;       // codes [Ktok][N] (N = in features)
   float* ws;             // [split][M][N]
+  float* csum;           // [split][M] column sums of dY over this split's tokens (optional)
   const float* s;        // LSQ step vector [S]
   int64_t lda, ldb;
   int M, N, Ktok, S, split, tiles_m, tiles_n;
@@ -374,6 +375,8 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   float4 ra[4];
   float rs[4];
   i32x4 rb;
+  float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of the raw dY (bias gradient), tn == 0 tiles only
+  const bool do_csum = p.csum != nullptr && tn == 0;
   auto gload = [&](int kt) {
     const int k0 = kt * QTN_BK;
 #pragma unroll
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
       float4 v = *reinterpret_cast<const float4*>(Ap + (int64_t)kc * p.lda);
       if (!(a_ok && k < p.Ktok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
       ra[i] = v;
+      csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
       rs[i] = ofq_lsq_eff_scale(p.s[kc % p.S], p.gscale);
     }
     const int k = k0 + b_k;
@@ -477,6 +481,29 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
         if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
       }
   }
+  if (do_csum) {     // reduce the 8 row-groups that share a column quad, one writer per quad
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[a_k * 32 + (tid & 31)] = csacc;
+    __syncthreads();
+    if (a_k == 0) {
+      float4 t = red[tid & 31];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) {
+        const float4 u = red[g * 32 + (tid & 31)];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+    }
+  }
+}
+
+// db[o] = sum_s csum[s][o]
+__global__ __launch_bounds__(256) void qgemm_tn_db_kernel(const float* __restrict__ csum, float* __restrict__ db, int M, int split) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= M) return;
+  float acc = 0.f;
+  for (int s = 0; s < split; ++s) acc += csum[(int64_t)s * M + o];
+  db[o] = acc;
 }
 
 // dW[o][c] = sum_s ws[s][o][c] + db[o] * baft[c]
@@ -493,12 +520,13 @@ __global__ __launch_bounds__(256) void qgemm_tn_reduce_kernel(const float* __res
 }
 
 extern "C" size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split) {
-  return (size_t)split * M * N * sizeof(float);
+  return (size_t)split * M * (N + 1) * sizeof(float);       // partial products + partial column sums
 }
 
 extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S,
-                                  float gscale, const float* db, const float* baft, int64_t Ktok, int64_t M, int64_t N,
-                                  int64_t lda, int64_t ldb, int split, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                  float gscale, float* db, int compute_db, const float* baft, int64_t Ktok, int64_t M,
+                                  int64_t N, int64_t lda, int64_t ldb, int split, void* ws, size_t ws_bytes,
+                                  ofq_stream_t stream) {
   if (!dY || !codes || !dW || !lsq_s || !ws || Ktok <= 0 || M <= 0 || N <= 0 || S <= 0 || split < 1) return OFQ_EINVAL;
   if ((M & 3) || (N & 15) || (lda & 3) || (ldb & 15) || !al16(dY) || !al16(codes) || Ktok >= (1ll << 30)) return OFQ_EINVAL;
   if (ws_bytes < ofq_qgemm_bf16s_tn_ws_bytes(M, N, split)) return OFQ_ENOWS;
@@ -506,9 +534,16 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   a.A = dY; a.B = codes; a.ws = (float*)ws; a.s = lsq_s; a.lda = lda; a.ldb = ldb;
   a.M = (int)M; a.N = (int)N; a.Ktok = (int)Ktok; a.S = (int)S; a.split = split;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale;
+  if (compute_db && !db) return OFQ_EINVAL;
+  a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   OFQ_LAUNCH_CHECK();
+  if (compute_db) {
+    hipLaunchKernelGGL(qgemm_tn_db_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, st, (const float*)a.csum, db, (int)M,
+                       split);
+    OFQ_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, (const float*)ws, dW, db,
                      baft, (int)M, (int)N, split);
   OFQ_LAUNCH_CHECK();

@@ -70,16 +70,17 @@ class CodesLinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"]).view(ctx.in_shape)
-        db = ops.colsum(dy2d) if (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None else None
-        dW = None
-        if ctx.needs_input_grad[1]:
-            N_out, K_in = dy2d.shape[1], x2d.shape[1]
-            if N_out % 4 == 0 and K_in % 16 == 0:
-                # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term
-                dW = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"], aux["act_gscale"],
-                                        db if aux["baft"] is not None else None, aux["baft"])
-            else:
-                dW = ops.linear_bwd_weight(dy2d, x2d)
+        need_db = (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None
+        dW = db = None
+        N_out, K_in = dy2d.shape[1], x2d.shape[1]
+        if ctx.needs_input_grad[1] and N_out % 4 == 0 and K_in % 16 == 0:
+            # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
+            # dY also yields the bias gradient (column sums)
+            dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
+                                        aux["act_gscale"], None, aux["baft"], compute_db=True)
+        else:
+            db = ops.colsum(dy2d) if need_db else None
+            dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         return dx, dW, (db if ctx.has_bias else None), None
 
 

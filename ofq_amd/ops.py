@@ -256,19 +256,21 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     return out
 
 
-def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None):
-    """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c]"""
+def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False):
+    """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c];  compute_db: also returns db = colsum(dy)"""
     Ktok, M = dy2d.shape
     N = xcodes2d.shape[1]
     if split is None:
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         split = max(1, min(512 // tiles, (Ktok + 31) // 32 // 4))
     dW = torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
+    if compute_db:
+        db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
     _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
-                                  _p(db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0), split,
-                                  ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
-    return dW
+                                  _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
+                                  split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
+    return (dW, db) if compute_db else dW
 
 
 def colsum(x2d):

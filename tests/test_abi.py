@@ -46,7 +46,7 @@ def test_workspace_size_queries_are_pure_host_arithmetic():
     assert lib.ofq_lsq_bwd_ws_bytes(128, 198, 384, 384, 0) > 0
     assert lib.ofq_softmax_lsq_bwd_ws_bytes(1000) >= 4000
     assert lib.ofq_colsum_ws_bytes(25344, 384) == 64 * 384 * 4
-    assert lib.ofq_qgemm_bf16s_tn_ws_bytes(384, 384, 8) == 8 * 384 * 384 * 4
+    assert lib.ofq_qgemm_bf16s_tn_ws_bytes(384, 384, 8) == 8 * 384 * 385 * 4
     d = _lib.GemmDesc()
     d.M, d.N, d.K, d.nb0, d.nb1, d.split_k = 384, 384, 25344, 1, 1, 16
     assert lib.ofq_gemm_ws_bytes(ctypes.byref(d)) == 16 * 384 * 384 * 4

@@ -394,6 +394,10 @@ def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
         dW = ops.qgemm_bf16s_tn(dy.cuda(), codes.cuda(), s.cuda(), S, gscale, db.cuda(), baft.cuda(), split=split)
         err = float(((dW.cpu().double() - ref).abs() / den).max())
         assert err < 1e-6, (split, err)
+        dWb, dbg = ops.qgemm_bf16s_tn(dy.cuda(), codes.cuda(), s.cuda(), S, gscale, None, baft.cuda(), split=split,
+                                      compute_db=True)
+        assert rel_err(dbg.cpu(), db) < 1e-5
+        assert float(((dWb.cpu().double() - ref).abs() / den).max()) < 1e-5
     # identical to the fp32-MFMA GEMM on the fake-quant values
     xh = (ae[:, None] * codes.double() + baft.double()).float()
     dW2 = ops.linear_bwd_weight(dy.cuda(), xh.cuda())
