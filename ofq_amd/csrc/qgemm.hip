@@ -25,13 +25,21 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 struct QGemmArgs {
   const void* A; const void* B; float* C;
   const float* bias;     // [N] optional
-  const float* cs;       // i8: column scale [N]
-  const float* r;        // i8: offset term [N] (optional)
-  const float* s;        // i8: LSQ step vector [S];  bf16s: k-scale ks[K] (optional)
+  const float* cs;       // i8 linear: column scale [N]
+  const float* r;        // i8 linear: offset term [N] (optional)
+  const float* s;        // i8: LSQ step vector of the rows [S];  bf16s: k-scale ks (optional)
+  // attention epilogues (i8) / extras (bf16s)
+  const float* s2;       // second LSQ step vector (columns: qkx steps [N*nb1] / v steps [C])
+  const float* u;        // scores: [nb0][M][nb1]      bf16s-nt: per-row addend [nb0][M][nb1]
+  const float* tq;       // scores: [nb0][N][nb1]
+  const float* z;        // scores: [nb1]              pv: column offset vector bav [C]
+  const float* rp;       // pv: row sums of the P codes [nb0][nb1][M]
   int64_t lda, ldb, ldc;
-  int M, N, K, S;
-  int tiles_m, tiles_n, accumulate;
-  float gscale, alpha;
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;   // batch strides (elements)
+  int64_t sK1;           // bf16s: offset of the k-scale vector per inner batch index b1
+  int M, N, K, S, nb1;
+  int tiles_m, tiles_n, accumulate, b_is_i8;
+  float gscale, gscale2, alpha;
 };
 
 __device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& tn) {
@@ -48,6 +56,8 @@ __device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& 
 #define QI8_BK 64                 // bytes of k per LDS stage (two 32x32x32 MFMA steps)
 #define QI8_LD (QI8_BK + 16)      // padded LDS row (bytes)
 
+// EPI 0: linear layer   1: QKR attention scores   2: P*V
+template <int EPI>
 __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
@@ -57,8 +67,9 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const unsigned char* A = (const unsigned char*)p.A;
-  const unsigned char* B = (const unsigned char*)p.B;
+  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
+  const unsigned char* B = (const unsigned char*)p.B + b0 * p.sB0 + b1 * p.sB1;
   const int K = p.K;
   const int nkt = (K + QI8_BK - 1) / QI8_BK;
 
@@ -134,30 +145,81 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
     buf ^= 1;
   }
 
-  // epilogue: y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
-  float csn[2], rn[2], bz[2];
+  float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
   int ncol[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    ncol[j] = n0 + wn * 64 + j * 32 + l31;
-    const int nc = min(ncol[j], p.N - 1);
-    csn[j] = p.cs[nc] * p.alpha;
-    rn[j] = p.r ? p.r[nc] : 0.f;
-    bz[j] = p.bias ? p.bias[nc] : 0.f;
-  }
+  for (int j = 0; j < 2; ++j) ncol[j] = n0 + wn * 64 + j * 32 + l31;
+  if (EPI == 0) {
+    // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
+    float csn[2], rn[2], bz[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (m >= p.M) continue;
-      const float ae = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (ncol[j] < p.N)
-          p.C[(int64_t)m * p.ldc + ncol[j]] =
-              __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+    for (int j = 0; j < 2; ++j) {
+      const int nc = min(ncol[j], p.N - 1);
+      csn[j] = p.cs[nc] * p.alpha;
+      rn[j] = p.r ? p.r[nc] : 0.f;
+      bz[j] = p.bias ? p.bias[nc] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const float ae = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (ncol[j] < p.N)
+            Cb[(int64_t)m * p.ldc + ncol[j]] =
+                __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+      }
+  } else if (EPI == 1) {
+    // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
+    float aq[2], tqa[2];
+    const float zz = p.z[b1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nc = min(ncol[j], p.N - 1);
+      aq[j] = ofq_lsq_eff_scale(p.s2[nc * p.nb1 + b1], p.gscale2);
+      tqa[j] = __fadd_rn(__fmul_rn(aq[j], p.tq[((int64_t)b0 * p.N + nc) * p.nb1 + b1]), zz);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const float ax = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+        const float uu = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (ncol[j] < p.N)
+            Cb[(int64_t)m * p.ldc + ncol[j]] =
+                __fadd_rn(__fmul_rn(ax, __fadd_rn(__fmul_rn(aq[j], (float)acc[i][j][e]), uu)), tqa[j]);
+      }
+  } else {
+    // O[n,c] = ap[n] * (av[c] * I + bav[c] * rp[n])                                 (P_hat . V_hat, attention.py:219)
+    float av[2], bv2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nc = min(ncol[j], p.N - 1) + b1 * p.N;
+      av[j] = ofq_lsq_eff_scale(p.s2[nc], p.gscale2);
+      bv2[j] = p.z ? p.z[nc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const float ap = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+        const float rpm = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (ncol[j] < p.N)
+            Cb[(int64_t)m * p.ldc + ncol[j]] =
+                __fmul_rn(ap, __fadd_rn(__fmul_rn(av[j], (float)acc[i][j][e]), __fmul_rn(bv2[j], rpm)));
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ bf16-split backward
@@ -170,6 +232,11 @@ __device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
+__device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
+  // two small signed integers -> packed bf16 pair (exact for |v| <= 256)
+  return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
+}
+
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
@@ -181,8 +248,11 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const float* A = (const float*)p.A;
-  const unsigned short* B = (const unsigned short*)p.B;
+  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const float* A = (const float*)p.A + b0 * p.sA0 + b1 * p.sA1;
+  const unsigned short* B = (const unsigned short*)p.B + (p.b_is_i8 ? 0 : b0 * p.sB0 + b1 * p.sB1);
+  const signed char* B8 = (const signed char*)p.B + b0 * p.sB0 + b1 * p.sB1;
+  const float* ksp = p.s ? p.s + b1 * p.sK1 : nullptr;
   const int K = p.K;
   const int nkt = (K + QBS_BK - 1) / QBS_BK;
 
@@ -211,7 +281,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   auto gload = [&](int kt) {
     const int k0 = kt * QBS_BK;
     const bool kina = (k0 + kqa) < K, kinb = (k0 + kqb) < K;       // K % 8 == 0 (host check)
-    rks = p.s ? *reinterpret_cast<const float4*>(p.s + (kina ? k0 + kqa : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
+    rks = ksp ? *reinterpret_cast<const float4*>(ksp + (kina ? k0 + kqa : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = *reinterpret_cast<const float4*>(A + offA[i] + (kina ? k0 : -kqa));
@@ -220,8 +290,18 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const i32x4 v = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
-      rb[i] = v & ((okB[i] && kinb) ? -1 : 0);
+      if (!p.b_is_i8) {
+        const i32x4 v = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
+        rb[i] = v & ((okB[i] && kinb) ? -1 : 0);
+      } else {   // 8 int8 codes -> 8 bf16
+        const uint2 v = *reinterpret_cast<const uint2*>(B8 + offB[i] + (kinb ? k0 : -kqb));
+        const int m = (okB[i] && kinb) ? -1 : 0;
+        const int w0 = (int)v.x & m, w1 = (int)v.y & m;
+        rb[i].x = (int)i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
+        rb[i].y = (int)i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
+        rb[i].z = (int)i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
+        rb[i].w = (int)i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
+      }
     }
   };
   auto lstore = [&]() {
@@ -303,8 +383,9 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m < p.M) {
-          float* dst = p.C + (int64_t)m * p.ldc + n;
+          float* dst = p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m * p.ldc + n;
           float v = acc[i][j][e] * p.alpha;
+          if (p.u) v += p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
           if (p.accumulate) v += *dst;
           *dst = v;
         }
@@ -330,8 +411,12 @@ struct QTnArgs {
   float* ws;             // [split][M][N]
   float* csum;           // [split][M] column sums of dY over this split's tokens (optional)
   const float* s;        // LSQ step vector [S]
-  int64_t lda, ldb;
-  int M, N, Ktok, S, split, tiles_m, tiles_n;
+  // direct (batched, un-split) mode: C written by the GEMM kernel itself
+  float* C;              // NULL = split-K mode
+  const float* baft;     // direct mode: + colsum_k(A)[m] * baft[n]
+  int64_t lda, ldb, ldc;
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  int M, N, Ktok, S, split, tiles_m, tiles_n, nb1, Mstore, Nstore, trans_out;
   float gscale;
 };
 
@@ -342,11 +427,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
-}
-
-__device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
-  // two small signed integers -> packed bf16 pair (exact for |v| <= 256)
-  return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
 }
 
 __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
@@ -360,6 +440,8 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const bool direct = p.C != nullptr;
 
   const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
   const int tps = (nkt + p.split - 1) / p.split;
@@ -370,13 +452,13 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   const int b_k = tid >> 3, b_c = (tid & 7) * 16;
   const bool a_ok = (m0 + a_t) < p.M;                      // M % 4 == 0 (host check)
   const bool b_ok = (n0 + b_c) < p.N;                      // N % 16 == 0
-  const float* Ap = p.A + (a_ok ? m0 + a_t : 0);
-  const int8_t* Bp = p.B + (b_ok ? n0 + b_c : 0);
+  const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1 + (a_ok ? m0 + a_t : 0);
+  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1 + (b_ok ? n0 + b_c : 0);
   float4 ra[4];
   float rs[4];
   i32x4 rb;
   float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of the raw dY (bias gradient), tn == 0 tiles only
-  const bool do_csum = p.csum != nullptr && tn == 0;
+  const bool do_csum = direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0);
   auto gload = [&](int kt) {
     const int k0 = kt * QTN_BK;
 #pragma unroll
@@ -468,19 +550,22 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
       __syncthreads();
     }
   }
-  float* W = p.ws + (int64_t)sidx * p.M * p.N;
+  if (!direct) {
+    float* W = p.ws + (int64_t)sidx * p.M * p.N;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= p.N) continue;
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= p.N) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
+        }
+    }
   }
+  float* red1 = reinterpret_cast<float*>(smem) + 8 * 32 * 4;      // 128 finished column sums live behind the partials
   if (do_csum) {     // reduce the 8 row-groups that share a column quad, one writer per quad
     float4* red = reinterpret_cast<float4*>(smem);
     red[a_k * 32 + (tid & 31)] = csacc;
@@ -492,7 +577,34 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
         const float4 u = red[g * 32 + (tid & 31)];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+      if (!direct) {
+        if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+      } else {
+        *reinterpret_cast<float4*>(red1 + a_t) = t;
+      }
+    }
+    __syncthreads();
+  }
+  if (direct) {
+    float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= p.Nstore) continue;
+      const float bf = p.baft ? p.baft[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int m = m0 + ml;
+          if (m < p.Mstore) {
+            float v = acc[i][j][e];
+            if (p.baft) v += red1[ml] * bf;
+            if (p.trans_out) Cb[(int64_t)n * p.ldc + m] = v;
+            else Cb[(int64_t)m * p.ldc + n] = v;
+          }
+        }
     }
   }
 }
@@ -533,7 +645,7 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   QTnArgs a = {};
   a.A = dY; a.B = codes; a.ws = (float*)ws; a.s = lsq_s; a.lda = lda; a.ldb = ldb;
   a.M = (int)M; a.N = (int)N; a.Ktok = (int)Ktok; a.S = (int)S; a.split = split;
-  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.nb1 = 1;
   if (compute_db && !db) return OFQ_EINVAL;
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -548,6 +660,165 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
                      baft, (int)M, (int)N, split);
   OFQ_LAUNCH_CHECK();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ bf16-split NN (attention dxq)
+// dxq[b,n,c] = sum_h sum_m (dS[b,h,n,m] * aq[m,h]) * qq[b,m,h,c]      (autograd of attention.py:210 wrt x_hat)
+// A = dS is K-contiguous (m), scaled along k by the (token, head) LSQ step gathered with stride H and split into three
+// bf16 planes [row][k]; B = the qkx codes, contiguous along c, staged as a [k][c] bf16 plane and read with the
+// LDS transpose read.  The head sum is a k-batch loop inside the kernel, so dxq is written once.
+struct QNnArgs {
+  const float* A; const int8_t* B; float* C;
+  const float* s;        // LSQ steps of qkx: index k*ks_stride + kb
+  int64_t lda, ldb, ldc, sA0, sB0, sC0, sAk, sBk;
+  int M, N, K, nkb, ks_stride, tiles_m, tiles_n, accumulate;
+  float gscale;
+};
+
+__global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
+  constexpr int BM = 128, NS = 3;
+  constexpr int PLANE_A = BM * QBS_LD;              // [row][k] bf16, 80 B rows
+  constexpr int PLANE_B = QTN_BK * QTN_LD;          // [k][c]  bf16, 320 B rows
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + PLANE_B];
+  const int tile = blockIdx.x;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * 128;
+  const int b0 = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* Ab = p.A + b0 * p.sA0;
+  const int8_t* Bb = p.B + b0 * p.sB0;
+  const int K = p.K;
+  const int nkt = (K + QBS_BK - 1) / QBS_BK;
+  const int T = nkt * p.nkb;
+
+  int64_t offA[4];
+  bool okA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + 256 * i;
+    const int row = f >> 3;
+    okA[i] = (m0 + row) < p.M;
+    offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + (f & 7) * 4;
+  }
+  const int kqa = (tid & 7) * 4;
+  const int b_k = tid >> 3, b_c = (tid & 7) * 16;
+  const bool b_ok = (n0 + b_c) < p.N;
+  float4 ra[4], rks;
+  i32x4 rb;
+  auto gload = [&](int t) {
+    const int kb = t / nkt, kt = t - kb * nkt;
+    const int k0 = kt * QBS_BK;
+    const bool kina = (k0 + kqa) < K;
+    const int kbase = kina ? k0 + kqa : 0;
+    const float* sp = p.s + kb;
+    rks.x = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 0, K - 1) * p.ks_stride], p.gscale);
+    rks.y = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 1, K - 1) * p.ks_stride], p.gscale);
+    rks.z = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 2, K - 1) * p.ks_stride], p.gscale);
+    rks.w = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 3, K - 1) * p.ks_stride], p.gscale);
+    const float* At = Ab + kb * p.sAk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = *reinterpret_cast<const float4*>(At + offA[i] + (kina ? k0 : -kqa));
+      if (!(okA[i] && kina)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = v;
+    }
+    const int k = k0 + b_k;
+    const i32x4 v = *reinterpret_cast<const i32x4*>(Bb + kb * p.sBk + (int64_t)min(k, K - 1) * p.ldb + (b_ok ? n0 + b_c : 0));
+    rb = v & ((b_ok && k < K) ? -1 : 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 3;
+      float x[4] = {ra[i].x * rks.x, ra[i].y * rks.y, ra[i].z * rks.z, ra[i].w * rks.w};
+      float pc[NS][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rem = x[e];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float h = trunc_bf16(rem);
+          pc[q][e] = h;
+          rem = __fsub_rn(rem, h);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 w;
+        w.x = pack_hi16(pc[q][0], pc[q][1]);
+        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        *reinterpret_cast<uint2*>(&smem[q * PLANE_A + row * QBS_LD + kqa * 2]) = w;
+      }
+    }
+    unsigned w[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int word = rb[d];
+      w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
+      w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
+    }
+    unsigned char* dst = &smem[NS * PLANE_A + b_k * QTN_LD + b_c * 2];
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+  };
+
+  f32x16q acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int p16 = lane & 15;
+  const int fr_off = (8 * lh + (p16 >> 2)) * QTN_LD + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  gload(0);
+  for (int t = 0; t < T; ++t) {
+    lstore();
+    __syncthreads();
+    if (t + 1 < T) gload(t + 1);
+    const unsigned char* a = &smem[(wm * 64 + l31) * QBS_LD + lh * 16];
+#pragma unroll
+    for (int ks = 0; ks < QBS_BK / 16; ++ks) {
+      bf16x8 bv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bv[j] = tr_frag(&smem[NS * PLANE_A + ks * 16 * QTN_LD + fr_off + (wn * 64 + j * 32) * 2]);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        bf16x8 av[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE_A + i * 32 * QBS_LD + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* Cb = p.C + b0 * p.sC0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.M) {
+          float* dst = Cb + (int64_t)m * p.ldc + n;
+          float v = acc[i][j][e];
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -606,8 +877,8 @@ extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
-  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult;
-  hipLaunchKernelGGL(qgemm_i8_nt_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -622,10 +893,179 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   QGemmArgs a = {};
   a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
-  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r][v] = sum_k vecs[v][k] * codes[r][k]          (several offset vectors at once; V <= 32)
+__global__ __launch_bounds__(256) void rowdot_i8_multi_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vecs,
+                                                              float* __restrict__ out, int R, int K, int V) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  for (int v = 0; v < V; ++v) {
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += vecs[(int64_t)v * K + k] * (float)codes[(int64_t)r * K + k];
+    acc = ofq_wave_sum(acc);
+    if (lane == 0) out[(int64_t)r * V + v] = acc;
+  }
+}
+
+// out[r][h] = sum_{c<d} x[r][h*d + c] * vec[h*d + c]      (per-head dot of an fp32 row with an offset vector)
+__global__ __launch_bounds__(256) void rowdot_f32_seg_kernel(const float* __restrict__ x, const float* __restrict__ vec,
+                                                             float* __restrict__ out, int R, int H, int d, int64_t ld) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  for (int h = 0; h < H; ++h) {
+    float acc = 0.f;
+    for (int c = lane; c < d; c += 64) acc += x[(int64_t)r * ld + h * d + c] * vec[h * d + c];
+    acc = ofq_wave_sum(acc);
+    if (lane == 0) out[(int64_t)r * H + h] = acc;
+  }
+}
+
+// batched int8 transpose with zero padding: in [B][R][Cc] -> out [B][Cc][Rp]  (V codes for the P*V product)
+__global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out, int R,
+                                                                 int Cc, int Rp) {
+  __shared__ int8_t tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int8_t* ib = in + (int64_t)blockIdx.z * R * Cc;
+  int8_t* ob = out + (int64_t)blockIdx.z * Cc * Rp;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? ib[(int64_t)r * Cc + c] : (int8_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < Rp) ob[(int64_t)c * Rp + r] = tile[tx][i];
+  }
+}
+
+extern "C" int ofq_rowdot_i8_multi(const int8_t* codes, const float* vecs, float* out, int64_t rows, int64_t cols, int nvec,
+                                   ofq_stream_t stream) {
+  if (!codes || !vecs || !out || rows <= 0 || cols <= 0 || nvec <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(rowdot_i8_multi_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vecs,
+                     out, (int)rows, (int)cols, nvec);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int ofq_rowdot_f32_seg(const float* x, const float* vec, float* out, int64_t rows, int heads, int head_dim, int64_t ld,
+                                  ofq_stream_t stream) {
+  if (!x || !vec || !out || rows <= 0 || heads <= 0 || head_dim <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(rowdot_f32_seg_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, vec, out,
+                     (int)rows, heads, head_dim, ld);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t batches, int64_t rows, int64_t cols, int64_t rows_padded,
+                                      ofq_stream_t stream) {
+  if (!in || !out || batches <= 0 || rows <= 0 || cols <= 0 || rows_padded < rows) return OFQ_EINVAL;
+  hipLaunchKernelGGL(codes_transpose_i8_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows_padded, 32), (unsigned)batches),
+                     dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols, (int)rows_padded);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- attention products on the codes -------------------------------------------------------------------------
+// scores: S[b,h,n,m] = ax[n]*(aq[m,h]*(qx[b,n,:].qq[b,m,h,:]) + u[b,n,h]) + aq[m,h]*tq[b,m,h] + z[h]
+extern "C" int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, const float* sx, float gscale_x,
+                                   const float* sq, float gscale_q, const float* u, const float* tq, const float* z, int64_t B,
+                                   int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
+  if (!xcodes || !qcodes || !S || !sx || !sq || !u || !tq || !z || B <= 0 || H <= 0 || N <= 0 || (C & 15) || ldS < N)
+    return OFQ_EINVAL;
+  QGemmArgs a = {};
+  a.A = xcodes; a.B = qcodes; a.C = S; a.s = sx; a.s2 = sq; a.u = u; a.tq = tq; a.z = z;
+  a.lda = C; a.ldb = H * C; a.ldc = ldS;
+  a.sA0 = N * C; a.sA1 = 0; a.sB0 = N * H * C; a.sB1 = C; a.sC0 = H * N * ldS; a.sC1 = N * ldS;
+  a.M = (int)N; a.N = (int)N; a.K = (int)C; a.S = (int)N; a.nb1 = (int)H;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale_x; a.gscale2 = gscale_q;
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// P*V: O[b,n,h*d+c] = ap[n]*(av[h*d+c]*(qp[b,h,n,:].qvT[b,h*d+c,:]) + bav[h*d+c]*rp[b,h,n])
+extern "C" int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, float* O, const float* sp, float gscale_p,
+                               const float* sv, float gscale_v, const float* bav, const float* rp, int64_t B, int64_t H,
+                               int64_t N, int64_t d, int64_t Np, ofq_stream_t stream) {
+  if (!pcodes || !vcodesT || !O || !sp || !sv || !rp || B <= 0 || H <= 0 || N <= 0 || d <= 0 || (Np & 15) || Np < N) return OFQ_EINVAL;
+  QGemmArgs a = {};
+  const int64_t C = H * d;
+  a.A = pcodes; a.B = vcodesT; a.C = O; a.s = sp; a.s2 = sv; a.z = bav; a.rp = rp;
+  a.lda = Np; a.ldb = Np; a.ldc = C;
+  a.sA0 = H * N * Np; a.sA1 = N * Np; a.sB0 = C * Np; a.sB1 = d * Np; a.sC0 = N * C; a.sC1 = d;
+  a.M = (int)N; a.N = (int)d; a.K = (int)Np; a.S = (int)N; a.nb1 = (int)H;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(d, 128); a.gscale = gscale_p; a.gscale2 = gscale_v;
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// dP[b,h,n,m] = sum_c (dO[b,n,h*d+c]*av[h*d+c]) * qv[b,m,h*d+c] + w[b,n,h]
+extern "C" int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* av_eff, const float* w, int64_t B,
+                                  int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream) {
+  if (!dO || !vcodes || !dP || !av_eff || B <= 0 || H <= 0 || N <= 0 || (d & 7) || ldP < N) return OFQ_EINVAL;
+  QGemmArgs a = {};
+  const int64_t C = H * d;
+  a.A = dO; a.B = vcodes; a.C = dP; a.s = av_eff; a.u = w; a.b_is_i8 = 1;
+  a.lda = C; a.ldb = C; a.ldc = ldP;
+  a.sA0 = N * C; a.sA1 = d; a.sB0 = N * C; a.sB1 = d; a.sC0 = H * N * ldP; a.sC1 = N * ldP; a.sK1 = d;
+  a.M = (int)N; a.N = (int)N; a.K = (int)d; a.nb1 = (int)H; a.alpha = 1.f;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128);
+  hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// dV[b,m,h*d+c] = sum_n qp[b,h,n,m] * (ap[n] * dO[b,n,h*d+c])
+extern "C" int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
+                                  int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream) {
+  if (!dO || !pcodes || !dV || !sp || B <= 0 || H <= 0 || N <= 0 || (d & 3) || (Np & 15) || Np < N) return OFQ_EINVAL;
+  QTnArgs a = {};
+  const int64_t C = H * d;
+  a.A = dO; a.B = pcodes; a.C = dV; a.s = sp; a.lda = C; a.ldb = Np; a.ldc = C;
+  a.sA0 = N * C; a.sA1 = d; a.sB0 = H * N * Np; a.sB1 = N * Np; a.sC0 = N * C; a.sC1 = d;
+  a.M = (int)d; a.N = (int)Np; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
+  a.Mstore = (int)d; a.Nstore = (int)N; a.trans_out = 1; a.gscale = gscale_p;
+  a.tiles_m = (int)ceil_div(d, 128); a.tiles_n = (int)ceil_div(Np, 128);
+  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// dqkx[b,m,h,c] = sum_n dS[b,h,n,m] * (ax[n]*qx[b,n,c] + bax[c])
+extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,
+                                    const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
+  if (!dS || !xcodes || !dqkx || !sx || B <= 0 || H <= 0 || N <= 0 || (C & 15) || (ldS & 3) || ldS < N) return OFQ_EINVAL;
+  QTnArgs a = {};
+  a.A = dS; a.B = xcodes; a.C = dqkx; a.s = sx; a.baft = bax; a.lda = ldS; a.ldb = C; a.ldc = H * C;
+  a.sA0 = H * N * ldS; a.sA1 = N * ldS; a.sB0 = N * C; a.sB1 = 0; a.sC0 = N * H * C; a.sC1 = C;
+  a.M = (int)ldS; a.N = (int)C; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
+  a.Mstore = (int)N; a.Nstore = (int)C; a.trans_out = 0; a.gscale = gscale_x;
+  a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(C, 128);
+  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// dxq[b,n,c] (+)= sum_h sum_m (dS[b,h,n,m]*aq[m,h]) * qq[b,m,h,c]
+extern "C" int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float* dxq, const float* sq, float gscale_q,
+                                   int accumulate, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
+  if (!dS || !qcodes || !dxq || !sq || B <= 0 || H <= 0 || N <= 0 || (C & 15) || (ldS & 7) || ldS < N) return OFQ_EINVAL;
+  QNnArgs a = {};
+  a.A = dS; a.B = qcodes; a.C = dxq; a.s = sq; a.lda = ldS; a.ldb = H * C; a.ldc = C;
+  a.sA0 = H * N * ldS; a.sB0 = N * H * C; a.sC0 = N * C; a.sAk = N * ldS; a.sBk = C;
+  a.M = (int)N; a.N = (int)C; a.K = (int)N; a.nkb = (int)H; a.ks_stride = (int)H; a.accumulate = accumulate; a.gscale = gscale_q;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(C, 128);
+  hipLaunchKernelGGL(qgemm_bf16s_nn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
