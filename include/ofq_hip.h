@@ -72,12 +72,14 @@ int ofq_lsq_bwd(const float* g, const float* x, const float* s, const float* b4,
  *  query token r % S); prob (saved for backward) and y are written with the same ld, pad columns = 0.
  *  y = LSQ_unsigned(softmax(scores * alpha)); s has S entries. */
 int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
-                        int64_t ld, int64_t S, float alpha, int hi, float gscale, ofq_stream_t stream);
+                        int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes, float* code_rowsum,
+                        ofq_stream_t stream);   /* codes (optional, [rows][ld] uint8) and their row sums feed ofq_qattn_pv_i8 */
 size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows);
 /*  backward: g = dL/dy -> dscores (may alias g), ds[S] overwritten. */
 int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
                         int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
-                        void* ws, size_t ws_bytes, ofq_stream_t stream);
+                        float* ds_rowsum, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                        /* ds_rowsum (optional, [rows]): sum_m dscores[r][m], used by ofq_qattn_dxq's offset term */
 
 /* ---- K6-K9, K11  fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chain):
  *  F.linear qlinear.py:69, torch.einsum attention.py:200/:210, `@` attention.py:96/:102/:193/:219 and
@@ -130,6 +132,33 @@ int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const fl
 /*  int8 codes [rows][cols] -> bf16 [cols][rows];   out[r] = sum_k vec[k]*codes[r][k] */
 int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
 int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);
+
+/* ---- attention products on the integer codes (QAttention_qkreparam.forward attention.py:200-219 and autograd).
+ *  Layouts: xcodes [B][N][C], qcodes (qkx) [B][N][H][C], vcodes [B][N][C], vcodesT [B][C][Np] (zero padded),
+ *  pcodes [B][H][N][Np] (uint8 softmax codes, zero padded), S/dS/dP fp32 [B][H][N][ldS];  C = H*d, Np % 16 == 0.
+ *  sx/sq/sv/sp are the LSQ step vectors of x (N), qkx (N*H), v (C), softmax (N) with their gradient scales. */
+int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, const float* sx, float gscale_x,
+                        const float* sq, float gscale_q, const float* u, const float* tq, const float* z, int64_t B,
+                        int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, float* O, const float* sp, float gscale_p,
+                    const float* sv, float gscale_v, const float* bav, const float* rp, int64_t B, int64_t H, int64_t N,
+                    int64_t d, int64_t Np, ofq_stream_t stream);
+int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* av_eff, const float* w, int64_t B,
+                       int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream);
+int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
+                       int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream);
+int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,
+                         const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float* dxq, const float* sq, float gscale_q, int accumulate,
+                        int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+/*  helpers: out[r][v] = sum_k vecs[v][k]*codes[r][k];  out[r][h] = sum_{c<d} x[r][h*d+c]*vec[h*d+c];
+ *  batched int8 transpose with zero padding in [B][R][C] -> out [B][C][Rp] */
+int ofq_rowdot_i8_multi(const int8_t* codes, const float* vecs, float* out, int64_t rows, int64_t cols, int nvec,
+                        ofq_stream_t stream);
+int ofq_rowdot_f32_seg(const float* x, const float* vec, float* out, int64_t rows, int heads, int head_dim, int64_t ld,
+                       ofq_stream_t stream);
+int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t batches, int64_t rows, int64_t cols, int64_t rows_padded,
+                           ofq_stream_t stream);
 
 /* ---- column sum (bias gradients of F.linear: autograd of qlinear.py:71):  out[c] = sum_r x[r][c] */
 size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols);

@@ -30,9 +30,9 @@ SIGNATURES = {
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
                           vp, sz, vp]),
-    "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp]),
+    "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, vp]),
     "ofq_softmax_lsq_bwd_ws_bytes": (sz, [i64]),
-    "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, sz, vp]),
+    "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, sz, vp]),
     "ofq_gemm_ws_bytes": (sz, [C.POINTER(GemmDesc)]),
     "ofq_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
     "ofq_qgemm_i8_nt": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64, vp]),
@@ -41,6 +41,15 @@ SIGNATURES = {
     "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
+    "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_pv_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp]),
+    "ofq_rowdot_i8_multi": (i32, [vp, vp, vp, i64, i64, i32, vp]),
+    "ofq_rowdot_f32_seg": (i32, [vp, vp, vp, i64, i32, i32, i64, vp]),
+    "ofq_codes_transpose_i8": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "ofq_colsum_ws_bytes": (sz, [i64, i64]),
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),

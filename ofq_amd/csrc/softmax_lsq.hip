@@ -10,7 +10,8 @@
 __global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ s,
                                                               float* __restrict__ prob, float* __restrict__ y,
                                                               int64_t rows, int n, int64_t ld, int64_t S, float alpha,
-                                                              float hi, float gscale) {
+                                                              float hi, float gscale, unsigned char* __restrict__ codes,
+                                                              float* __restrict__ code_rowsum) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -33,20 +34,27 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __res
   }
   sum = ofq_wave_sum(sum);
   const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+  float qsum = 0.f;
 #pragma unroll
   for (int e = 0; e < SM_MAXE; ++e) {
     int c = lane + 64 * e;
     if (c < ld) {
-      float p = 0.f, out = 0.f;
+      float p = 0.f, out = 0.f, q = 0.f;
       if (c < n) {
         p = ofq_div(t[e], sum);
-        float q, v;
+        float v;
         float yi = ofq_lsq_quant(p, a, 0.f, hi, q, v);
         out = __fmul_rn(yi, a);
       }
       prob[r * ld + c] = p;
       y[r * ld + c] = out;
+      if (codes) codes[r * ld + c] = (unsigned char)(int)q;
+      qsum += q;
     }
+  }
+  if (code_rowsum) {
+    qsum = ofq_wave_sum(qsum);
+    if (lane == 0) code_rowsum[r] = qsum;
   }
 }
 
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
                                                               const float* __restrict__ s, float* __restrict__ dsc,
                                                               float* __restrict__ rowpart, int64_t rows, int n,
                                                               int64_t ld, int64_t S, float alpha, float hi,
-                                                              float gscale) {
+                                                              float gscale, float* __restrict__ ds_rowsum) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -79,19 +87,27 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
   rowds = ofq_wave_sum(rowds);
   dot = ofq_wave_sum(dot);
   if (lane == 0) rowpart[r] = rowds;
+  float rsum = 0.f;
 #pragma unroll
   for (int e = 0; e < SM_MAXE; ++e) {
     int c = lane + 64 * e;
-    if (c < ld) dsc[r * ld + c] = (c < n) ? (dq[e] - dot) * p[e] * alpha : 0.f;
+    const float o = (c < n) ? (dq[e] - dot) * p[e] * alpha : 0.f;
+    if (c < ld) dsc[r * ld + c] = o;
+    rsum += o;
+  }
+  if (ds_rowsum) {       // ~0 in exact arithmetic; kept so that the offset term of dx_hat matches the reference's fp32 value
+    rsum = ofq_wave_sum(rsum);
+    if (lane == 0) ds_rowsum[r] = rsum;
   }
 }
 
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
-                                   int64_t ld, int64_t S, float alpha, int hi, float gscale, ofq_stream_t stream) {
+                                   int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes,
+                                   float* code_rowsum, ofq_stream_t stream) {
   if (!scores || !s || !prob || !y || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
     return OFQ_EINVAL;
   hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale);
+                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -100,14 +116,14 @@ extern "C" size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows) { return (size_t)ro
 
 extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
                                    int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
-                                   void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                   float* ds_rowsum, void* ws, size_t ws_bytes, ofq_stream_t stream) {
   if (!g || !prob || !s || !dscores || !ws || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE ||
       S <= 0 || rows % S)
     return OFQ_EINVAL;
   if (ws_bytes < (size_t)rows * sizeof(float)) return OFQ_ENOWS;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
-                     (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale);
+                     (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
   OFQ_LAUNCH_CHECK();
   if (ds) {
     SumJobs jobs = {};

@@ -278,3 +278,95 @@ class QKVSplitLsqFn(torch.autograd.Function):
             res.append((ds, dbaft))
         return (dqkv.view(B, N, 3 * C), torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
+
+
+# =====================================================================================================
+# QKR attention core on the integer codes (same functions as QKRScoresFn / SoftmaxLsqFn / PVFn above)
+# =====================================================================================================
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class QKRScoresCodesFn(torch.autograd.Function):
+    """S[b,h,n,m] = x_hat[b,n,:] . qkx_hat[b,m,h,:] with x_hat = ax*qx + bax, qkx_hat = aq*qq + baq: one exact int8
+    GEMM per (b,h) plus three small offset terms applied in its epilogue; backward = two bf16-split GEMMs."""
+
+    @staticmethod
+    def forward(ctx, xq, qkx, aux):
+        B, N, C = xq.shape
+        H = aux["H"]
+        Np = pad16(N)
+        baq2 = aux["baq"].view(H, C)
+        u = ops.rowdot_i8_multi(aux["xcodes"].view(B * N, C), baq2)          # [B*N, H]
+        tq = ops.rowdot_i8(aux["qcodes"].view(B * N * H, C), aux["bax"])      # [B*N*H]
+        z = torch.mv(baq2, aux["bax"])                                        # [H]
+        S = ops.qattn_scores(aux["xcodes"], aux["qcodes"], aux["sx"], aux["gx"], aux["sq"], aux["gq"], u, tq, z, B, H, N, C, Np)
+        ctx.aux = aux
+        ctx.dims = (B, H, N, C, Np)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        aux = ctx.aux
+        B, H, N, C, Np = ctx.dims
+        dS = dS.contiguous()
+        dqkx = ops.qattn_dqkx(dS, aux["xcodes"], aux["sx"], aux["gx"], aux["bax"], B, H, N, C, Np)
+        dxq = ops.qattn_dxq(dS, aux["qcodes"], aux["sq"], aux["gq"], B, H, N, C, Np)
+        rs = aux["link"].pop("ds_rowsum", None)
+        if rs is None:
+            rs = dS[..., :N].sum(-1).reshape(-1)
+        # + sum_h rowsum_m(dS)[b,h,n] * baq[h,c]   (zero in exact arithmetic)
+        dxq.view(B * N, C).addmm_(rs.view(B, H, N).permute(0, 2, 1).reshape(B * N, H), aux["baq"].view(H, C))
+        return dxq, dqkx, None
+
+
+class SoftmaxLsqCodesFn(torch.autograd.Function):
+    """SoftmaxLsqFn that also emits the uint8 codes of P_hat and their row sums (operands of the int8 P.V GEMM)."""
+
+    @staticmethod
+    def forward(ctx, S, s, N, alpha, hi, link):
+        B, H = S.shape[0], S.shape[1]
+        Np = S.shape[3]
+        rows = B * H * N
+        prob, y, codes, rsum = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N, want_codes=True)
+        ctx.save_for_backward(prob, s)
+        ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
+        ctx.link = link
+        ctx.mark_non_differentiable(codes, rsum)
+        return y, codes, rsum
+
+    @staticmethod
+    def backward(ctx, g, _gc, _gr):
+        prob, s = ctx.saved_tensors
+        rows, N, Np, alpha, hi, M = ctx.meta
+        g = g.contiguous()
+        dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True, want_rowsum=True)
+        ctx.link["ds_rowsum"] = rs
+        return dS, ds, None, None, None, None
+
+
+class PVCodesFn(torch.autograd.Function):
+    """O = P_hat @ V_hat per head on the codes: P_hat = ap*qp, V_hat = av*qv + bav."""
+
+    @staticmethod
+    def forward(ctx, P, v, aux):
+        B, H, N, Np = P.shape
+        C = v.shape[2]
+        d = C // H
+        vT = ops.codes_transpose_i8(aux["vcodes"].view(B, N, C), Np)
+        O = ops.qattn_pv(aux["pcodes"], vT, aux["sp"], aux["gp"], aux["sv"], aux["gv"], aux["bav"], aux["rp"], B, H, N, d, Np)
+        ctx.aux = aux
+        ctx.dims = (B, H, N, d, Np)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        aux = ctx.aux
+        B, H, N, d, Np = ctx.dims
+        C = H * d
+        dO = dO.contiguous()
+        w = ops.rowdot_f32_seg(dO.view(B * N, C), aux["bav"], H, d)
+        av_eff = ops.lsq_eff_scale(aux["sv"], aux["gv"])
+        dP = ops.qattn_dp(dO, aux["vcodes"], av_eff, w, B, H, N, d, Np)
+        dV = ops.qattn_dv(dO, aux["pcodes"], aux["sp"], aux["gp"], B, H, N, d, Np)
+        return dP, dV, None

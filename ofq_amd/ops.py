@@ -135,23 +135,30 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
 
 
 # ------------------------------------------------------------------------------------------------ softmax + LSQ
-def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M):
+def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M, want_codes=False):
     prob = torch.empty_like(scores)
     y = torch.empty_like(scores)
     gscale = 1.0 / math.sqrt(hi * M)
+    codes = torch.empty(scores.shape, dtype=torch.uint8, device=scores.device) if want_codes else None
+    rsum = torch.empty(rows, dtype=torch.float32, device=scores.device) if want_codes else None
     _chk(lib().ofq_softmax_lsq_fwd(scores.data_ptr(), s.data_ptr(), prob.data_ptr(), y.data_ptr(), rows, n, ld, S,
-                                   alpha, hi, gscale, _stream()), "ofq_softmax_lsq_fwd")
+                                   alpha, hi, gscale, _p(codes), _p(rsum), _stream()), "ofq_softmax_lsq_fwd")
+    if want_codes:
+        return prob, y, codes, rsum
     return prob, y
 
 
-def softmax_lsq_bwd(g, prob, s, rows, n, ld, S, alpha, hi, M, inplace=True):
+def softmax_lsq_bwd(g, prob, s, rows, n, ld, S, alpha, hi, M, inplace=True, want_rowsum=False):
     dsc = g if inplace else torch.empty_like(g)
     ds = torch.empty_like(s)
     gscale = 1.0 / math.sqrt(hi * M)
+    rs = torch.empty(rows, dtype=torch.float32, device=g.device) if want_rowsum else None
     ws = workspace(lib().ofq_softmax_lsq_bwd_ws_bytes(rows), g.device)
     _chk(lib().ofq_softmax_lsq_bwd(g.data_ptr(), prob.data_ptr(), s.data_ptr(), dsc.data_ptr(), ds.data_ptr(), rows, n,
-                                   ld, S, alpha, hi, gscale, ws.data_ptr(), ws.numel(), _stream()),
+                                   ld, S, alpha, hi, gscale, _p(rs), ws.data_ptr(), ws.numel(), _stream()),
          "ofq_softmax_lsq_bwd")
+    if want_rowsum:
+        return dsc, ds, rs
     return dsc, ds
 
 
@@ -271,6 +278,83 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
                                   _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
                                   split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
     return (dW, db) if compute_db else dW
+
+
+# ------------------------------------------------------------------------------------------------ attention on codes
+def lsq_eff_scale(s, gscale):
+    """(a - a*g) + a*g with a = max(s, 1e-5): the scale VALUE the LSQ kernels divide by (fp32, lsq.py:6-18)."""
+    a = torch.where(s > 1e-5, s, torch.full_like(s, 1e-5))
+    t = a * gscale
+    return (a - t) + t
+
+
+def rowdot_i8_multi(codes2d, vecs2d):
+    R, K = codes2d.shape
+    V = vecs2d.shape[0]
+    out = torch.empty((R, V), dtype=torch.float32, device=codes2d.device)
+    _chk(lib().ofq_rowdot_i8_multi(codes2d.data_ptr(), vecs2d.data_ptr(), out.data_ptr(), R, K, V, _stream()),
+         "ofq_rowdot_i8_multi")
+    return out
+
+
+def rowdot_f32_seg(x2d, vec, H, d):
+    R = x2d.shape[0]
+    out = torch.empty((R, H), dtype=torch.float32, device=x2d.device)
+    _chk(lib().ofq_rowdot_f32_seg(x2d.data_ptr(), vec.data_ptr(), out.data_ptr(), R, H, d, x2d.stride(0), _stream()),
+         "ofq_rowdot_f32_seg")
+    return out
+
+
+def codes_transpose_i8(codes3d, rows_padded):
+    Bn, R, Cc = codes3d.shape
+    out = torch.empty((Bn, Cc, rows_padded), dtype=torch.int8, device=codes3d.device)
+    _chk(lib().ofq_codes_transpose_i8(codes3d.data_ptr(), out.data_ptr(), Bn, R, Cc, rows_padded, _stream()),
+         "ofq_codes_transpose_i8")
+    return out
+
+
+def qattn_scores(xcodes, qcodes, sx, gx, sq, gq, u, tq, z, B, H, N, C, ldS):
+    S = torch.empty((B, H, N, ldS), dtype=torch.float32, device=xcodes.device)
+    _chk(lib().ofq_qattn_scores_i8(xcodes.data_ptr(), qcodes.data_ptr(), S.data_ptr(), sx.data_ptr(), gx, sq.data_ptr(),
+                                   gq, u.data_ptr(), tq.data_ptr(), z.data_ptr(), B, H, N, C, ldS, _stream()),
+         "ofq_qattn_scores_i8")
+    return S
+
+
+def qattn_pv(pcodes, vcodesT, sp, gp, sv, gv, bav, rp, B, H, N, d, Np):
+    O = torch.empty((B, N, H * d), dtype=torch.float32, device=pcodes.device)
+    _chk(lib().ofq_qattn_pv_i8(pcodes.data_ptr(), vcodesT.data_ptr(), O.data_ptr(), sp.data_ptr(), gp, sv.data_ptr(), gv,
+                               _p(bav), rp.data_ptr(), B, H, N, d, Np, _stream()), "ofq_qattn_pv_i8")
+    return O
+
+
+def qattn_dp(dO, vcodes, av_eff, w, B, H, N, d, ldP):
+    dP = torch.empty((B, H, N, ldP), dtype=torch.float32, device=dO.device)
+    _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), av_eff.data_ptr(), _p(w), B, H, N, d,
+                                  ldP, _stream()), "ofq_qattn_dp_bf16s")
+    return dP
+
+
+def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
+    dV = torch.empty((B, N, H * d), dtype=torch.float32, device=dO.device)
+    _chk(lib().ofq_qattn_dv_bf16s(dO.data_ptr(), pcodes.data_ptr(), dV.data_ptr(), sp.data_ptr(), gp, B, H, N, d, Np,
+                                  _stream()), "ofq_qattn_dv_bf16s")
+    return dV
+
+
+def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS):
+    dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
+    _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
+                                    ldS, _stream()), "ofq_qattn_dqkx_bf16s")
+    return dq
+
+
+def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
+    _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
+                                   H, N, C, ldS, _stream()), "ofq_qattn_dxq_bf16s")
+    return out
 
 
 def colsum(x2d):

@@ -15,7 +15,7 @@ from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkrepar
 from ...deit_vision_transformer import Attention as deit_attention
 from ... import ops
 from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn, codes_linear,
-                           codes_linear_ok)
+                           codes_linear_ok, QKRScoresCodesFn, SoftmaxLsqCodesFn, PVCodesFn)
 from . import qlinear as _ql
 
 
@@ -145,18 +145,42 @@ class QAttention_qkreparam(deit_attention):
         else:
             xq = xin(x)
             v = LinearFn.apply(xq, self.v_quant(self.v.weight), self.v.bias)
-        v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
+        d = C // H
+        attn_codes = (use_codes and C % 16 == 0 and d % 8 == 0 and N <= 256 and self.quan_a_softmax_fn.thd_pos <= 127
+                      and self.quan_a_v_fn.thd_neg >= -128 and self.quan_a_qkx_fn.thd_neg >= -128)
+        if attn_codes:
+            v, vcodes, vgeom = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias, want_codes=True)
+        else:
+            v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
         Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
         if use_codes:
             qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None)
         else:
             qkx = LinearFn.apply(xq, self.qk_quant(Wqk_fp), None)                # (B, N, H*C)   einsum :200
-        qkx = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
-                                       shape=(B, N * H, C), out_shape=(B, N, H, C))   # :201-206, s per (token, head)
-        S = QKRScoresFn.apply(xq, qkx, H)                                        # :210
-        P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)               # :213-216
-        out = PVFn.apply(P, v, N)                                                # :219
+        if not attn_codes:
+            qkx = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
+                                           shape=(B, N * H, C), out_shape=(B, N, H, C))   # :201-206, s per (token, head)
+            S = QKRScoresFn.apply(xq, qkx, H)                                    # :210
+            P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)           # :213-216
+            out = PVFn.apply(P, v, N)                                            # :219
+        else:
+            qkx, qcodes, qgeom = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
+                                                          shape=(B, N * H, C), out_shape=(B, N, H, C), want_codes=True)
+            link = {}
+            S = QKRScoresCodesFn.apply(xq, qkx, {
+                "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,
+                "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
+                "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link})   # :210
+            sm = self.quan_a_softmax_fn
+            if not sm.initialized_alpha or sm.s is None:
+                with torch.no_grad():
+                    sm.init_from(torch.softmax(S[..., :N].detach() * self.scale, dim=-1))
+            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, self.scale, sm.thd_pos, link)   # :213-216
+            gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
+            out = PVCodesFn.apply(P, v, {
+                "pcodes": pcodes, "rp": rp, "vcodes": vcodes, "sp": sm.s.detach(), "gp": gp,
+                "sv": self.quan_a_v_fn.s.detach(), "gv": vgeom.gscale, "bav": self.move_v_aft.bias.detach()})   # :219
         return self.proj_drop(self.proj(out)), None                              # :220-222
 
 

@@ -402,3 +402,83 @@ def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
     xh = (ae[:, None] * codes.double() + baft.double()).float()
     dW2 = ops.linear_bwd_weight(dy.cuda(), xh.cuda())
     assert rel_err(dW.cpu(), dW2.cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention on codes
+def test_qattn_code_kernels_vs_fp64(ops):
+    B, H, N, d = 2, 3, 198, 32
+    C = H * d
+    Np = 208
+    rs = np.random.RandomState(7)
+    gx, gq, gp, gv = 0.011, 0.013, 0.017, 0.019
+    xcodes = torch.from_numpy(rs.randint(-2, 2, (B, N, C)).astype(np.int8))
+    qcodes = torch.from_numpy(rs.randint(-2, 2, (B, N, H, C)).astype(np.int8))
+    vcodes = torch.from_numpy(rs.randint(-8, 8, (B, N, C)).astype(np.int8))
+    pcodes = torch.zeros(B, H, N, Np, dtype=torch.uint8)
+    pcodes[..., :N] = torch.from_numpy(rs.randint(0, 4, (B, H, N, N)).astype(np.uint8))
+    sx, sq = T(det_uniform((N,), 101, 0.2, 1.0)), T(det_uniform((N * H,), 102, 0.2, 1.0))
+    sp, sv = T(det_uniform((N,), 103, 0.05, 0.3)), T(det_uniform((C,), 104, 0.2, 1.0))
+    bax, baq, bav = T(det_uniform((C,), 105, -0.1, 0.1)), T(det_uniform((H * C,), 106, -0.1, 0.1)), T(det_uniform((C,), 107, -0.1, 0.1))
+    ax, aq = O.lsq_effective_scale(sx, gx).double(), O.lsq_effective_scale(sq, gq).double().view(N, H)
+    ap, av = O.lsq_effective_scale(sp, gp).double(), O.lsq_effective_scale(sv, gv).double()
+    xh = ax[None, :, None] * xcodes.double() + bax.double()                                   # (B,N,C)
+    qh = aq[None, :, :, None] * qcodes.double() + baq.double().view(1, 1, H, C)               # (B,N,H,C)
+    vh = av * vcodes.double() + bav.double()                                                  # (B,N,C)
+    ph = ap[None, None, :, None] * pcodes[..., :N].double()                                   # (B,H,N,N)
+    cu = lambda t: t.cuda()
+    # ---- scores
+    u = ops.rowdot_i8_multi(cu(xcodes).view(B * N, C), cu(baq).view(H, C))
+    assert rel_err(u.cpu(), (xcodes.double().view(B * N, C) @ baq.double().view(H, C).t()).float()) < 1e-6
+    tq = ops.rowdot_i8(cu(qcodes).view(B * N * H, C), cu(bax))
+    z = (baq.double().view(H, C) @ bax.double()).float()
+    S = ops.qattn_scores(cu(xcodes), cu(qcodes), cu(sx), gx, cu(sq), gq, u, tq, cu(z), B, H, N, C, Np)
+    S_ref = torch.einsum("bnc,bmhc->bhnm", xh, qh)
+    assert rel_err(S.cpu()[..., :N], S_ref.float()) < 2e-6
+    # ---- P.V
+    vT = ops.codes_transpose_i8(cu(vcodes), Np)
+    assert torch.equal(vT.cpu()[:, :, :N], vcodes.transpose(1, 2)) and int(vT.cpu()[:, :, N:].abs().max()) == 0
+    rp = pcodes.float().sum(-1).reshape(-1)
+    Oo = ops.qattn_pv(cu(pcodes).view(torch.int8), vT, cu(sp), gp, cu(sv), gv, cu(bav), cu(rp), B, H, N, d, Np)
+    O_ref = (ph @ vh.view(B, N, H, d).permute(0, 2, 1, 3)).transpose(1, 2).reshape(B, N, C)
+    assert rel_err(Oo.cpu(), O_ref.float()) < 2e-6
+    # ---- dP, dV
+    dO = T(det_normalish((B, N, C), 108, 1.0))
+    w = ops.rowdot_f32_seg(cu(dO).view(B * N, C), cu(bav), H, d)
+    dP = ops.qattn_dp(cu(dO), cu(vcodes), cu(av.float()), w, B, H, N, d, Np)
+    dP_ref = torch.einsum("bnhj,bmhj->bhnm", dO.double().view(B, N, H, d), vh.view(B, N, H, d))
+    assert rel_err(dP.cpu()[..., :N], dP_ref.float()) < 2e-6
+    dV = ops.qattn_dv(cu(dO), cu(pcodes).view(torch.int8), cu(sp), gp, B, H, N, d, Np)
+    dV_ref = torch.einsum("bhnm,bnhj->bmhj", ph, dO.double().view(B, N, H, d)).reshape(B, N, C)
+    assert rel_err(dV.cpu(), dV_ref.float()) < 2e-6
+    # ---- dqkx, dxq
+    dS = torch.zeros(B, H, N, Np)
+    dS[..., :N] = T(det_normalish((B, H, N, N), 109, 1.0))
+    dq = ops.qattn_dqkx(cu(dS), cu(xcodes), cu(sx), gx, cu(bax), B, H, N, C, Np)
+    dq_ref = torch.einsum("bhnm,bnc->bmhc", dS[..., :N].double(), xh)
+    assert rel_err(dq.cpu(), dq_ref.float()) < 2e-6
+    dxq = ops.qattn_dxq(cu(dS), cu(qcodes), cu(sq), gq, B, H, N, C, Np)
+    dxq_ref = torch.einsum("bhnm,bmhc->bnc", dS[..., :N].double(), aq[None, :, :, None] * qcodes.double())
+    assert rel_err(dxq.cpu(), dxq_ref.float()) < 2e-6
+    dxq2 = ops.qattn_dxq(cu(dS), cu(qcodes), cu(sq), gq, B, H, N, C, Np, out=dxq.clone(), accumulate=True)
+    assert rel_err(dxq2.cpu(), 2 * dxq_ref.float()) < 2e-6
+
+
+def test_softmax_lsq_codes_and_rowsums(ops):
+    B, H, N, bits = 2, 3, 198, 2
+    ld = 208
+    hi = 3
+    sc = torch.zeros(B, H, N, ld)
+    sc[..., :N] = T(det_normalish((B, H, N, N), 111, 3.0))
+    s = T(det_uniform((N,), 112, 0.01, 0.05))
+    M = B * H * N
+    prob, y, codes, rsum = ops.softmax_lsq_fwd(sc.cuda(), s.cuda(), B * H * N, N, ld, N, 0.125, hi, M, want_codes=True)
+    a = O.lsq_effective_scale(s, 1.0 / math.sqrt(hi * M))
+    q_ref = torch.clamp(prob.cpu()[..., :N] / a[:, None], 0, hi).round()
+    assert torch.equal(codes.cpu()[..., :N].float(), q_ref)
+    assert int(codes.cpu()[..., N:].max()) == 0
+    assert torch.equal(rsum.cpu().view(B, H, N), q_ref.sum(-1))
+    g = torch.zeros(B, H, N, ld)
+    g[..., :N] = T(det_uniform((B, H, N, N), 113, -1, 1))
+    dS, ds, rs = ops.softmax_lsq_bwd(g.cuda(), prob, s.cuda(), B * H * N, N, ld, N, 0.125, hi, M, inplace=False, want_rowsum=True)
+    assert torch.allclose(rs.cpu().view(B, H, N), dS.cpu().sum(-1), atol=1e-6)
+    assert float(dS.cpu()[..., N:].abs().max()) == 0.0
