@@ -237,7 +237,7 @@ __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
   return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool B_I8>
 __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
   const float* A = (const float*)p.A + b0 * p.sA0 + b1 * p.sA1;
-  const unsigned short* B = (const unsigned short*)p.B + (p.b_is_i8 ? 0 : b0 * p.sB0 + b1 * p.sB1);
+  const unsigned short* B = (const unsigned short*)p.B + (B_I8 ? 0 : b0 * p.sB0 + b1 * p.sB1);
   const signed char* B8 = (const signed char*)p.B + b0 * p.sB0 + b1 * p.sB1;
   const float* ksp = p.s ? p.s + b1 * p.sK1 : nullptr;
   const int K = p.K;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (!p.b_is_i8) {
+      if (!B_I8) {
         const i32x4 v = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
         rb[i] = v & ((okB[i] && kinb) ? -1 : 0);
       } else {   // 8 int8 codes -> 8 bf16
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
         if (m < p.M) {
           float* dst = p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m * p.ldc + n;
           float v = acc[i][j][e] * p.alpha;
-          if (p.u) v += p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+          if (B_I8 && p.u) v += p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
           if (p.accumulate) v += *dst;
           *dst = v;
         }
@@ -895,8 +895,8 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-  if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -1019,7 +1019,7 @@ extern "C" int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* 
   a.sA0 = N * C; a.sA1 = d; a.sB0 = N * C; a.sB1 = d; a.sC0 = H * N * ldP; a.sC1 = N * ldP; a.sK1 = d;
   a.M = (int)N; a.N = (int)N; a.K = (int)d; a.nb1 = (int)H; a.alpha = 1.f;
   a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128);
-  hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+  hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, true>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
