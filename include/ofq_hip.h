@@ -49,7 +49,7 @@ int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* 
  *  b4 / baft (optional, may be NULL) have bias_len = k*inner entries, bias index = (r % k)*inner + c.
  *  y = ((rne(u) - u) + u) * a_eff + baft,  u = clamp((pre(x) + b4) / a_eff, lo, hi),
  *  a_eff = (a - a*g) + a*g with a = max(s, 1e-5), g = gscale  (fp32, lsq.py:6-18, :593).
- *  prologue: 0 none, 1 exact GELU.   codes (optional, contiguous, 1 byte/elt) receives rne(u): int8 for signed
+ *  prologue: 0 none, 1 exact GELU.   y may be NULL when only the codes are wanted.   codes (optional, contiguous, 1 byte/elt) receives rne(u): int8 for signed
  *  ranges, uint8 for unsigned ones.
  *  ldx / ldy: row strides of x (and dx) / of y (and g), so column slices of a wider matrix (the q,k,v
  *  thirds of the qkv projection, attention.py:72-75) are quantised in place.  inner, ldx, ldy % 4 == 0. */

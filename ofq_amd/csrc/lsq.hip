@@ -94,18 +94,32 @@ __global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
   const int nslot = TX >= 64 ? TX / 64 : 1;
 
   if (active_row_group) {
-    for (int64_t r = (int64_t)blockIdx.x * TY + ty; r < a.R; r += (int64_t)gridDim.x * TY) {
+    // software-pipelined row walk: the next row's loads are issued before the current row is processed, so a wave
+    // always has 2 rows (J float4 per tensor each) in flight and the stores never sit between a load and its use
+    const int64_t rstride = (int64_t)gridDim.x * TY;
+    int64_t r = (int64_t)blockIdx.x * TY + ty;
+    float4 xn[J], gn[J];
+    auto issue = [&](int64_t rr) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (cok[j]) {
+          const int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
+          xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + col);
+          if (BWD) gn[j] = *reinterpret_cast<const float4*>(a.g + rr * a.ldy + col);
+        }
+      }
+    };
+    if (r < a.R) issue(r);
+    for (; r < a.R; r += rstride) {
       float arow = 1.f;
       if (!a.colmode) arow = ofq_lsq_eff_scale(a.s[r % a.S], a.gscale);
       float4 xv[J], gv[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        if (cok[j]) {
-          int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
-          xv[j] = *reinterpret_cast<const float4*>(a.x + r * a.ldx + col);
-          if (BWD) gv[j] = *reinterpret_cast<const float4*>(a.g + r * a.ldy + col);
-        }
+        xv[j] = xn[j];
+        if (BWD) gv[j] = gn[j];
       }
+      if (r + rstride < a.R) issue(r + rstride);
       float rowds = 0.f;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
             out[e] = __fadd_rn(__fmul_rn(yi, al), ba[e]);
             cd[e] = (signed char)(int)q;   // low 8 bits: int8 for signed ranges, uint8 for unsigned
           }
-          *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = make_float4(out[0], out[1], out[2], out[3]);
+          if (a.y) *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = make_float4(out[0], out[1], out[2], out[3]);
           if (a.codes) *reinterpret_cast<char4*>(a.codes + r * a.inner + col) = make_char4(cd[0], cd[1], cd[2], cd[3]);
         } else {
           float ge[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
@@ -211,7 +225,7 @@ extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, cons
                            int8_t* codes, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
                            int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
                            ofq_stream_t stream) {
-  if (!x || !s || !y || outer <= 0 || S <= 0) return OFQ_EINVAL;
+  if (!x || !s || (!y && !codes) || outer <= 0 || S <= 0) return OFQ_EINVAL;
   if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
   if ((b4 || baft) && bias_len <= 0) return OFQ_EINVAL;
   if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;

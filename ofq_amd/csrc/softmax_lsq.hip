@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __res
         out = __fmul_rn(yi, a);
       }
       prob[r * ld + c] = p;
-      y[r * ld + c] = out;
+      if (y) y[r * ld + c] = out;
       if (codes) codes[r * ld + c] = (unsigned char)(int)q;
       qsum += q;
     }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
                                    int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes,
                                    float* code_rowsum, ofq_stream_t stream) {
-  if (!scores || !s || !prob || !y || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
+  if (!scores || !s || !prob || (!y && !codes) || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
     return OFQ_EINVAL;
   hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                      scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum);

@@ -54,7 +54,8 @@ class CodesLinearFn(torch.autograd.Function):
         r = ops.rowdot_i8(aux["wcodes"], aux["baft"]) if aux["baft"] is not None else None
         y = ops.qgemm_i8_nt(aux["xcodes"].view(-1, K), aux["wcodes"], bias, aux["w_scale"], aux["w_mult"], r,
                             aux["act_s"], aux["act_S"], aux["act_gscale"])
-        ctx.save_for_backward(x2d)
+        ctx.codes_only = xq.stride(-1) == 0           # x_hat exists only as codes (placeholder carrier tensor)
+        ctx.save_for_backward(*(() if ctx.codes_only else (x2d,)))
         ctx.aux = aux
         ctx.has_bias = bias is not None
         ctx.in_shape = shp
@@ -62,7 +63,7 @@ class CodesLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        (x2d,) = ctx.saved_tensors
+        x2d = None if ctx.codes_only else ctx.saved_tensors[0]
         aux = ctx.aux
         dy2d = dy.reshape(-1, dy.shape[-1])
         if not dy2d.is_contiguous():
@@ -72,7 +73,7 @@ class CodesLinearFn(torch.autograd.Function):
             dx = ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"]).view(ctx.in_shape)
         need_db = (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None
         dW = db = None
-        N_out, K_in = dy2d.shape[1], x2d.shape[1]
+        N_out, K_in = dy2d.shape[1], ctx.in_shape[-1]
         if ctx.needs_input_grad[1] and N_out % 4 == 0 and K_in % 16 == 0:
             # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
             # dY also yields the bias gradient (column sums)
@@ -82,6 +83,11 @@ class CodesLinearFn(torch.autograd.Function):
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         return dx, dW, (db if ctx.has_bias else None), None
+
+
+def codes_only_ok(in_features, out_features):
+    """x_hat may stay un-materialised (codes only) when the weight-gradient GEMM can run on the codes as well."""
+    return in_features % 16 == 0 and out_features % 4 == 0
 
 
 def codes_linear_ok(in_features, wquant, act_quant):
@@ -328,7 +334,8 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
         B, H = S.shape[0], S.shape[1]
         Np = S.shape[3]
         rows = B * H * N
-        prob, y, codes, rsum = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N, want_codes=True)
+        prob, y, codes, rsum = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N, want_codes=True,
+                                                   need_values=False)
         ctx.save_for_backward(prob, s)
         ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
         ctx.link = link

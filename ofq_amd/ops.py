@@ -106,12 +106,23 @@ class LsqGeom:
         self.prologue = int(prologue)
 
 
-def lsq_fwd(x, s, b4, baft, g, y=None, want_codes=False):
+def placeholder(shape, device):
+    """Zero-stride tensor of the given shape: an autograd edge carrier for values that only exist as integer codes."""
+    return torch.empty(1, dtype=torch.float32, device=device).expand(*shape)
+
+
+def lsq_fwd(x, s, b4, baft, g, y=None, want_codes=False, need_values=True):
     _dev(x, "x")
-    if y is None:
-        y = torch.empty((g.outer * g.S, g.ldy), dtype=torch.float32, device=x.device)
+    yptr = 0
+    if not need_values:
+        assert want_codes
+        y = placeholder((g.outer * g.S, g.ldy), x.device)
+    else:
+        if y is None:
+            y = torch.empty((g.outer * g.S, g.ldy), dtype=torch.float32, device=x.device)
+        yptr = y.data_ptr()
     codes = torch.empty((g.outer * g.S, g.inner), dtype=torch.int8, device=x.device) if want_codes else None
-    _chk(lib().ofq_lsq_fwd(x.data_ptr(), s.data_ptr(), _p(b4), _p(baft), y.data_ptr(), _p(codes), g.outer, g.S,
+    _chk(lib().ofq_lsq_fwd(x.data_ptr(), s.data_ptr(), _p(b4), _p(baft), yptr, _p(codes), g.outer, g.S,
                            g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale, g.prologue, _stream()),
          "ofq_lsq_fwd")
     return y, codes
@@ -135,14 +146,15 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
 
 
 # ------------------------------------------------------------------------------------------------ softmax + LSQ
-def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M, want_codes=False):
+def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M, want_codes=False, need_values=True):
     prob = torch.empty_like(scores)
-    y = torch.empty_like(scores)
+    y = torch.empty_like(scores) if need_values else placeholder(scores.shape, scores.device)
     gscale = 1.0 / math.sqrt(hi * M)
     codes = torch.empty(scores.shape, dtype=torch.uint8, device=scores.device) if want_codes else None
     rsum = torch.empty(rows, dtype=torch.float32, device=scores.device) if want_codes else None
-    _chk(lib().ofq_softmax_lsq_fwd(scores.data_ptr(), s.data_ptr(), prob.data_ptr(), y.data_ptr(), rows, n, ld, S,
-                                   alpha, hi, gscale, _p(codes), _p(rsum), _stream()), "ofq_softmax_lsq_fwd")
+    _chk(lib().ofq_softmax_lsq_fwd(scores.data_ptr(), s.data_ptr(), prob.data_ptr(), y.data_ptr() if need_values else 0,
+                                   rows, n, ld, S, alpha, hi, gscale, _p(codes), _p(rsum), _stream()),
+         "ofq_softmax_lsq_fwd")
     if want_codes:
         return prob, y, codes, rsum
     return prob, y

@@ -138,18 +138,20 @@ class QAttention_qkreparam(deit_attention):
         H = self.num_heads
         xin = self.quant_x_4_qkv
         use_codes = _ql.USE_CODE_GEMM and codes_linear_ok(C, self.v_quant, xin.input_quant_fn)
+        d = C // H
+        attn_codes = (use_codes and C % 16 == 0 and d % 8 == 0 and N <= 256 and self.quan_a_softmax_fn.thd_pos <= 127
+                      and self.quan_a_v_fn.thd_neg >= -128 and self.quan_a_qkx_fn.thd_neg >= -128)
         if use_codes:
-            xq, xcodes, xgeom = xin(x, want_codes=True)                          # attention.py:177
+            # with the attention core on codes too, no consumer reads the fp32 x_hat / v_hat / qkx_hat values
+            xq, xcodes, xgeom = xin(x, want_codes=True, need_values=not attn_codes)   # attention.py:177
             v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
                              self.v.bias)                                        # :179-181
         else:
             xq = xin(x)
             v = LinearFn.apply(xq, self.v_quant(self.v.weight), self.v.bias)
-        d = C // H
-        attn_codes = (use_codes and C % 16 == 0 and d % 8 == 0 and N <= 256 and self.quan_a_softmax_fn.thd_pos <= 127
-                      and self.quan_a_v_fn.thd_neg >= -128 and self.quan_a_qkx_fn.thd_neg >= -128)
         if attn_codes:
-            v, vcodes, vgeom = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias, want_codes=True)
+            v, vcodes, vgeom = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias, want_codes=True,
+                                                      need_values=False)
         else:
             v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
@@ -166,7 +168,8 @@ class QAttention_qkreparam(deit_attention):
             out = PVFn.apply(P, v, N)                                            # :219
         else:
             qkx, qcodes, qgeom = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
-                                                          shape=(B, N * H, C), out_shape=(B, N, H, C), want_codes=True)
+                                                          shape=(B, N * H, C), out_shape=(B, N, H, C), want_codes=True,
+                                                          need_values=False)
             link = {}
             S = QKRScoresCodesFn.apply(xq, qkx, {
                 "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,

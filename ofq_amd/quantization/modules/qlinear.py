@@ -10,7 +10,7 @@ from ..quantizer.statsq import StatsQuantizer
 from ..quantizer.lsq import (LsqQuantizer, LsqQuantizerWeight, LsqQuantizer4img, LsqQuantizer4Conv2d,
                              LsqQuantizer4head_input)
 from ...deit_vision_transformer import Mlp, to_2tuple
-from ...functional import LinearFn, codes_linear, codes_linear_ok
+from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
 
 
 # Exact integer-code GEMMs (int8 forward, bf16-split dX) instead of the fp32-MFMA GEMM on fake-quant values.
@@ -30,8 +30,9 @@ class LSQ_input(nn.Module):
         self.move_b4 = LearnableBias(learanbaleBiasdim)
         self.move_aft = LearnableBias(learanbaleBiasdim)
 
-    def forward(self, input, want_codes=False):
-        return self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=want_codes)
+    def forward(self, input, want_codes=False, need_values=True):
+        return self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=want_codes,
+                                         need_values=need_values)
 
 
 class QLinear(nn.Linear):
@@ -67,7 +68,8 @@ class QLinear(nn.Linear):
             raise ValueError("Unknown quant_method")
         if USE_CODE_GEMM and codes_linear_ok(self.in_features, self.statsq_fn, self.input_quant_fn):
             xq, xcodes, geom = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias,
-                                                         prologue=self._prologue, want_codes=True)
+                                                         prologue=self._prologue, want_codes=True,
+                                                         need_values=not codes_only_ok(self.in_features, self.out_features))
             return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
                                 self.statsq_fn, self.bias)
         weight = self.statsq_fn(self.weight)                                     # qlinear.py:62

@@ -26,8 +26,8 @@ class _LsqFn(torch.autograd.Function):
     """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
 
     @staticmethod
-    def forward(ctx, x, s, b4, baft, geom, want_codes):
-        y, codes = ops.lsq_fwd(x, s, b4, baft, geom, want_codes=want_codes)
+    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True):
+        y, codes = ops.lsq_fwd(x, s, b4, baft, geom, want_codes=want_codes, need_values=need_values)
         ctx.save_for_backward(x, s, b4)
         ctx.geom = geom
         ctx.has_bias = b4 is not None
@@ -42,7 +42,7 @@ class _LsqFn(torch.autograd.Function):
         g = ctx.geom
         gy = gy.contiguous()
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx.view(x.shape), ds, db4, dbaft, None, None
+        return dx.view(x.shape), ds, db4, dbaft, None, None, None
 
 
 class _LsqBase(nn.Module):
@@ -71,7 +71,7 @@ class _LsqBase(nn.Module):
         self.initialized_alpha = True
 
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
-              want_codes=False):
+              want_codes=False, need_values=True):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
         is a strided column slice)."""
         if not x.is_cuda:
@@ -87,7 +87,7 @@ class _LsqBase(nn.Module):
                 xin = self._add_bias_for_init(xin, b4.detach())
             self.init_from(xin)
         geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
-        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes)
+        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values)
         y = y.view(out_shape if out_shape is not None else shp)
         if want_codes:
             return y, codes, geom
