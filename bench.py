@@ -25,7 +25,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# dense matrix-core peaks, /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters" / "Matrix cores (MFMA)")
+PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
+         "qgemm_bf16s": 2500.0,    # Peak BF16 MFMA dense; the fp32-exact product issues 3 bf16 MFMAs per algorithmic FMA
+         "qgemm_i8": 5000.0}       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
 
 
 def parse():
@@ -135,8 +138,8 @@ def main():
         if args.verbose:
             torch.cuda.synchronize()
             say("warmup step %d done" % i)
-    timer = None if args.no_roofline_events else ops.KernelTimer()
-    ops.GEMM_TIMER = timer
+    timer = None if args.no_roofline_events else {}
+    ops.TIMERS = timer
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -147,7 +150,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.GEMM_TIMER = None
+    ops.TIMERS = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,15 +162,22 @@ def main():
     out = None
     if rank == 0:
         roof = None
-        if timer is not None:
-            sm = timer.summary()
+        if timer:
+            sums = {k: v.summary() for k, v in timer.items()}
+            name = max(sums, key=lambda k: sums[k]["total_ms"])          # dominant matrix-core kernel class by time
+            sm = sums[name]
+            peak = [v for k, v in PEAKS.items() if name.startswith(k)][0]
             achieved = sm["total_units"] / (sm["total_ms"] * 1e-3) / 1e12 if sm["total_ms"] > 0 else 0.0
-            roof = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": sm["launches"] / args.steps,
-                    "avg_launch_ms": round(sm["avg_ms"], 4), "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
-                    "gemm_ms_per_step": round(sm["total_ms"] / args.steps, 3)}
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over the "
+                            "timed steps; for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact)",
+                    "launches_per_step": sm["launches"] / args.steps, "avg_launch_ms": round(sm["avg_ms"], 4),
+                    "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
+                    "ms_per_step": round(sm["total_ms"] / args.steps, 3),
+                    "all_classes_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sums.items()},
+                    "all_classes_tflops": {k: round(v["total_units"] / (v["total_ms"] * 1e-3) / 1e12, 1) for k, v in sums.items()
+                                           if v["total_ms"] > 0}}
         out = {"metric": "images/sec QAT (DeiT-S W2A2, 224px synthetic)", "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -434,7 +434,16 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   constexpr int PLANE = QTN_BK * QTN_LD;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(NS + 1) * PLANE];
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int tile = blockIdx.x % ntiles, sidx = blockIdx.x / ntiles;
+  // XCD-aware order: block b runs on XCD b % 8; give each XCD a contiguous run of logical ids so that the tiles which
+  // share one dY panel (same split, same tm, all tn) hit the same L2 instead of re-fetching the panel per XCD
+  int lid = blockIdx.x;
+  {
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = lid & 7, loc = lid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile = lid % ntiles, sidx = lid / ntiles;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

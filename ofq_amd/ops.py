@@ -36,6 +36,31 @@ class KernelTimer:
 
 
 GEMM_TIMER = None   # set to a KernelTimer to time every ofq_gemm_f32 launch
+TIMERS = None       # set to {} to time every matrix-core kernel class separately (bench.py roofline)
+
+
+class _Timed:
+    """with _Timed("class", flops): launch   -> HIP events around the launch when TIMERS is enabled."""
+    __slots__ = ("ev",)
+
+    def __init__(self, name, units):
+        t = TIMERS
+        if t is None:
+            self.ev = None
+        else:
+            kt = t.get(name)
+            if kt is None:
+                kt = t[name] = KernelTimer()
+            self.ev = kt.bracket(units)
+
+    def __enter__(self):
+        if self.ev is not None:
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if self.ev is not None:
+            self.ev[1].record()
+        return False
 
 
 def lib():
@@ -196,13 +221,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     d.tile_hint = tile_hint
     wsb = lib().ofq_gemm_ws_bytes(C.byref(d))
     ws = workspace(wsb, A.device) if wsb else None
-    timer = GEMM_TIMER
-    if timer is not None:
-        ev0, ev1 = timer.bracket(2.0 * M * N * K * nb0 * nb1 * nkb)
-        ev0.record()
-    _chk(lib().ofq_gemm_f32(C.byref(d), _p(ws), ws.numel() if ws is not None else 0, _stream()), "ofq_gemm_f32")
-    if timer is not None:
-        ev1.record()
+    with _Timed("gemm_f32 (v_mfma_f32_32x32x2_f32)", 2.0 * M * N * K * nb0 * nb1 * nkb):
+        _chk(lib().ofq_gemm_f32(C.byref(d), _p(ws), ws.numel() if ws is not None else 0, _stream()), "ofq_gemm_f32")
     return Cout
 
 
@@ -257,9 +277,10 @@ def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale):
     M, K = xcodes.shape
     N = wcodes.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=xcodes.device)
-    _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
-                               col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
-                               wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * M * N * K):
+        _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
+                                   col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
+                                   wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
     return y
 
 
@@ -269,9 +290,10 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     N = B_bf16.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
-                                  nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),
-         "ofq_qgemm_bf16s_nt")
+    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+        _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
+                                      nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),
+             "ofq_qgemm_bf16s_nt")
     return out
 
 
@@ -286,9 +308,10 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     if compute_db:
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
-    _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
-                                  _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
-                                  split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
+    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * Ktok * M * N):
+        _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
+                                      _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
+                                      split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
     return (dW, db) if compute_db else dW
 
 
@@ -327,45 +350,51 @@ def codes_transpose_i8(codes3d, rows_padded):
 
 def qattn_scores(xcodes, qcodes, sx, gx, sq, gq, u, tq, z, B, H, N, C, ldS):
     S = torch.empty((B, H, N, ldS), dtype=torch.float32, device=xcodes.device)
-    _chk(lib().ofq_qattn_scores_i8(xcodes.data_ptr(), qcodes.data_ptr(), S.data_ptr(), sx.data_ptr(), gx, sq.data_ptr(),
-                                   gq, u.data_ptr(), tq.data_ptr(), z.data_ptr(), B, H, N, C, ldS, _stream()),
-         "ofq_qattn_scores_i8")
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * C):
+        _chk(lib().ofq_qattn_scores_i8(xcodes.data_ptr(), qcodes.data_ptr(), S.data_ptr(), sx.data_ptr(), gx, sq.data_ptr(),
+                                       gq, u.data_ptr(), tq.data_ptr(), z.data_ptr(), B, H, N, C, ldS, _stream()),
+             "ofq_qattn_scores_i8")
     return S
 
 
 def qattn_pv(pcodes, vcodesT, sp, gp, sv, gv, bav, rp, B, H, N, d, Np):
     O = torch.empty((B, N, H * d), dtype=torch.float32, device=pcodes.device)
-    _chk(lib().ofq_qattn_pv_i8(pcodes.data_ptr(), vcodesT.data_ptr(), O.data_ptr(), sp.data_ptr(), gp, sv.data_ptr(), gv,
-                               _p(bav), rp.data_ptr(), B, H, N, d, Np, _stream()), "ofq_qattn_pv_i8")
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_pv_i8(pcodes.data_ptr(), vcodesT.data_ptr(), O.data_ptr(), sp.data_ptr(), gp, sv.data_ptr(), gv,
+                                   _p(bav), rp.data_ptr(), B, H, N, d, Np, _stream()), "ofq_qattn_pv_i8")
     return O
 
 
 def qattn_dp(dO, vcodes, av_eff, w, B, H, N, d, ldP):
     dP = torch.empty((B, H, N, ldP), dtype=torch.float32, device=dO.device)
-    _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), av_eff.data_ptr(), _p(w), B, H, N, d,
-                                  ldP, _stream()), "ofq_qattn_dp_bf16s")
+    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), av_eff.data_ptr(), _p(w), B, H, N, d,
+                                      ldP, _stream()), "ofq_qattn_dp_bf16s")
     return dP
 
 
 def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
     dV = torch.empty((B, N, H * d), dtype=torch.float32, device=dO.device)
-    _chk(lib().ofq_qattn_dv_bf16s(dO.data_ptr(), pcodes.data_ptr(), dV.data_ptr(), sp.data_ptr(), gp, B, H, N, d, Np,
-                                  _stream()), "ofq_qattn_dv_bf16s")
+    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_dv_bf16s(dO.data_ptr(), pcodes.data_ptr(), dV.data_ptr(), sp.data_ptr(), gp, B, H, N, d, Np,
+                                      _stream()), "ofq_qattn_dv_bf16s")
     return dV
 
 
 def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS):
     dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
-    _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
-                                    ldS, _stream()), "ofq_qattn_dqkx_bf16s")
+    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+        _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
+                                        ldS, _stream()), "ofq_qattn_dqkx_bf16s")
     return dq
 
 
 def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False):
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
-    _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
-                                   H, N, C, ldS, _stream()), "ofq_qattn_dxq_bf16s")
+    with _Timed('qgemm_bf16s_nn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+        _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
+                                       H, N, C, ldS, _stream()), "ofq_qattn_dxq_bf16s")
     return out
 
 
