@@ -73,7 +73,11 @@ int ofq_lsq_bwd(const float* g, const float* x, const float* s, const float* b4,
  *  y = LSQ_unsigned(softmax(scores * alpha)); s has S entries. */
 int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
                         int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes, float* code_rowsum,
-                        ofq_stream_t stream);   /* codes (optional, [rows][ld] uint8) and their row sums feed ofq_qattn_pv_i8 */
+                        const float* addend, int64_t add_period, ofq_stream_t stream);
+                        /* codes (optional, [rows][ld] uint8) and their row sums feed ofq_qattn_pv_i8.
+                         * addend (optional, [add_period][S][ld]): added to scores*alpha before the softmax, slab index
+                         * (r / S) % add_period — Swin's relative-position bias + shift mask, one slab per (window, head)
+                         * (swin_attention_and_mlp.py:201-221). */
 size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows);
 /*  backward: g = dL/dy -> dscores (may alias g), ds[S] overwritten. */
 int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,

@@ -30,7 +30,7 @@ SIGNATURES = {
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
                           vp, sz, vp]),
-    "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, vp]),
+    "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, vp, i64, vp]),
     "ofq_softmax_lsq_bwd_ws_bytes": (sz, [i64]),
     "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, sz, vp]),
     "ofq_gemm_ws_bytes": (sz, [C.POINTER(GemmDesc)]),

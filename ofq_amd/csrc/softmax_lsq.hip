@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __res
                                                               float* __restrict__ prob, float* __restrict__ y,
                                                               int64_t rows, int n, int64_t ld, int64_t S, float alpha,
                                                               float hi, float gscale, unsigned char* __restrict__ codes,
-                                                              float* __restrict__ code_rowsum) {
+                                                              float* __restrict__ code_rowsum, const float* __restrict__ addend,
+                                                              int64_t add_period) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -22,6 +23,8 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_kernel(const float* __res
   for (int e = 0; e < SM_MAXE; ++e) {
     int c = lane + 64 * e;
     t[e] = (c < n) ? __fmul_rn(src[c], alpha) : -INFINITY;
+    // Swin: + relative-position bias (+ shift mask), one [n][ld] slab per (window, head), period = windows*heads
+    if (addend && c < n) t[e] = __fadd_rn(t[e], addend[(((r / S) % add_period) * S + (r % S)) * ld + c]);
     m = fmaxf(m, t[e]);
   }
   m = ofq_wave_max(m);
@@ -103,11 +106,12 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
 
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
                                    int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes,
-                                   float* code_rowsum, ofq_stream_t stream) {
+                                   float* code_rowsum, const float* addend, int64_t add_period, ofq_stream_t stream) {
   if (!scores || !s || !prob || (!y && !codes) || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
     return OFQ_EINVAL;
   hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum);
+                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
+                     add_period > 0 ? add_period : 1);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

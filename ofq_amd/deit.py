@@ -41,7 +41,13 @@ def deit_small_distilled_patch16_224(pretrained=False, **kwargs):
     return _deit(384, 6, pretrained, **kwargs)
 
 
+def _swin_t(**kw):
+    from .swin import swin_t
+    return swin_t(**kw)
+
+
 _REGISTRY = {f.__name__: f for f in (deit_tiny_distilled_patch16_224, deit_small_distilled_patch16_224)}
+_REGISTRY["swin_t"] = _swin_t
 
 
 def create_model(name, **kwargs):

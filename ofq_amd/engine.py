@@ -7,11 +7,24 @@ import torch
 import torch.nn as nn
 
 from .deit import create_model
-from .quantization.modules.utils import replace_module_by_qmodule_deit
+from .quantization.modules.utils import replace_module_by_qmodule_deit, replace_module_by_qmodule_swin
 from .quantization.utils import KDLossSoftandHard
 from . import ops
 
 ACT_LAYER_MAPPINGS = {'relu': nn.ReLU, 'gelu': nn.GELU, 'prelu': nn.PReLU, 'rprelu': 'rprelu', 'None': 'None'}
+
+
+def default_qmodules_swin(depths):
+    """The name list of configs/swin_t_imagenet.attn_q.yml."""
+    names, fi = ["features.0.0"], 1
+    for si, d in enumerate(depths):
+        for li in range(d):
+            names += ["features.%d.%d.attn" % (fi, li), "features.%d.%d.mlp" % (fi, li)]
+        fi += 1
+        if si < len(depths) - 1:
+            names.append("features.%d.reduction" % fi)
+            fi += 1
+    return names + ["head"]
 
 
 def default_qmodules(depth):
@@ -37,8 +50,12 @@ def get_qat_model(model, args):
                 "learnable": getattr(args, "aq_clip_learnable", True)}
         qconfigs[m] = {"weight": wcfg, "act": acfg, "q_attn_dropout": getattr(args, "apply_q_attn_dropout", False),
                        "act_layer": ACT_LAYER_MAPPINGS[getattr(args, "act_layer", "gelu")]}
+    if args.model_type == 'swin':
+        return replace_module_by_qmodule_swin(model, qconfigs, pretrained_initialized=args.pretrained_initialized,
+                                              qk_reparam=args.qk_reparam, qk_reparam_type=args.qk_reparam_type,
+                                              boundaryRange=getattr(args, "boundaryRange", 0.005))
     if args.model_type != 'deit':
-        raise ValueError("model_type %r: only the DeiT family is built so far (Swin is the next §8 row)" % args.model_type)
+        raise ValueError("unknown model_type %r" % args.model_type)
     return replace_module_by_qmodule_deit(model, qconfigs, pretrained_initialized=args.pretrained_initialized,
                                           qk_reparam=args.qk_reparam, qk_reparam_type=args.qk_reparam_type,
                                           boundaryRange=getattr(args, "boundaryRange", 0.005))
@@ -91,10 +108,15 @@ def make_optimizer(model, lr=5.47e-4, weight_decay=0.05, fused=None):
 
 
 # -------------------------------------------------------------------------------------------- CGA (cga.py)
-def cga_modules(model, qk_reparam=True):
-    """cga.py:966-979: blocks.* modules whose name ends with fc1 | fc2 | .v | proj  (QKR), or qkv (plain)."""
+def cga_modules(model, qk_reparam=True, model_type='deit'):
+    """cga.py:966-979: blocks.* modules whose name ends with fc1 | fc2 | .v | proj  (QKR), or qkv (plain);
+    Swin (cga.py:957-964): no `blocks` filter, plus `reduction`."""
     out = []
     for k, v in model.named_modules():
+        if model_type == 'swin':
+            if qk_reparam and (k[-3:] == 'fc1' or k[-3:] == 'fc2' or k[-2:] == '.v' or k[-4:] == 'proj' or k[-9:] == 'reduction'):
+                out.append((k, v))
+            continue
         if 'blocks' not in k:
             continue
         if k[-3:] == 'fc1' or k[-3:] == 'fc2' or k[-4:] == 'proj' or (k[-2:] == '.v' if qk_reparam else k[-3:] == 'qkv'):
@@ -105,8 +127,8 @@ def cga_modules(model, qk_reparam=True):
 class CGAHooks:
     """freeze-outside-boundary gradient mask + weight restore around optimizer.step() (cga.py:953-1013)."""
 
-    def __init__(self, model, wbits, boundary_range=0.005, qk_reparam=True):
-        self.mods = cga_modules(model, qk_reparam)
+    def __init__(self, model, wbits, boundary_range=0.005, qk_reparam=True, model_type='deit'):
+        self.mods = cga_modules(model, qk_reparam, model_type)
         self.bits, self.br = wbits, boundary_range
         self.state = {}
 

@@ -199,16 +199,25 @@ class QKScoresFn(torch.autograd.Function):
         return dq, dk, None
 
 
+def _addend_grad(dS, addend, alpha):
+    """d(addend)[p] = sum over the batch rows that used slab p of dS / alpha   (S' = alpha*S + addend)."""
+    B, H, N, Np = dS.shape
+    P = addend.shape[0]
+    return dS.reshape(B * H // P, P, N, Np).sum(0) / alpha
+
+
 class SoftmaxLsqFn(torch.autograd.Function):
-    """P_hat = LSQ_unsigned(softmax(S * alpha))   (attention.py:96-99 / :213-216).  s per query token."""
+    """P_hat = LSQ_unsigned(softmax(S * alpha [+ addend]))   (attention.py:96-99 / :213-216; Swin adds the
+    relative-position bias and shift mask, swin_attention_and_mlp.py:201-224).  s per query token."""
 
     @staticmethod
-    def forward(ctx, S, s, N, alpha, hi):
+    def forward(ctx, S, s, N, alpha, hi, addend=None):
         B, H = S.shape[0], S.shape[1]
         Np = S.shape[3]
         rows = B * H * N
-        prob, y = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N)
+        prob, y = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N, addend=addend)
         ctx.save_for_backward(prob, s)
+        ctx.addend = addend
         ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
         return y
 
@@ -218,7 +227,8 @@ class SoftmaxLsqFn(torch.autograd.Function):
         rows, N, Np, alpha, hi, M = ctx.meta
         g = g.contiguous()
         dS, ds = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True)
-        return dS, ds, None, None, None
+        dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[5]) else None
+        return dS, ds, None, None, None, dadd
 
 
 class PVFn(torch.autograd.Function):
@@ -330,13 +340,14 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
     """SoftmaxLsqFn that also emits the uint8 codes of P_hat and their row sums (operands of the int8 P.V GEMM)."""
 
     @staticmethod
-    def forward(ctx, S, s, N, alpha, hi, link):
+    def forward(ctx, S, s, N, alpha, hi, link, addend=None):
         B, H = S.shape[0], S.shape[1]
         Np = S.shape[3]
         rows = B * H * N
         prob, y, codes, rsum = ops.softmax_lsq_fwd(S, s, rows, N, Np, N, alpha, hi, B * H * N, want_codes=True,
-                                                   need_values=False)
+                                                   need_values=False, addend=addend)
         ctx.save_for_backward(prob, s)
+        ctx.addend = addend
         ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
         ctx.link = link
         ctx.mark_non_differentiable(codes, rsum)
@@ -349,7 +360,8 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
         g = g.contiguous()
         dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True, want_rowsum=True)
         ctx.link["ds_rowsum"] = rs
-        return dS, ds, None, None, None, None
+        dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[6]) else None
+        return dS, ds, None, None, None, None, dadd
 
 
 class PVCodesFn(torch.autograd.Function):

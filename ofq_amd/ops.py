@@ -171,14 +171,15 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
 
 
 # ------------------------------------------------------------------------------------------------ softmax + LSQ
-def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M, want_codes=False, need_values=True):
+def softmax_lsq_fwd(scores, s, rows, n, ld, S, alpha, hi, M, want_codes=False, need_values=True, addend=None):
     prob = torch.empty_like(scores)
     y = torch.empty_like(scores) if need_values else placeholder(scores.shape, scores.device)
     gscale = 1.0 / math.sqrt(hi * M)
     codes = torch.empty(scores.shape, dtype=torch.uint8, device=scores.device) if want_codes else None
     rsum = torch.empty(rows, dtype=torch.float32, device=scores.device) if want_codes else None
     _chk(lib().ofq_softmax_lsq_fwd(scores.data_ptr(), s.data_ptr(), prob.data_ptr(), y.data_ptr() if need_values else 0,
-                                   rows, n, ld, S, alpha, hi, gscale, _p(codes), _p(rsum), _stream()),
+                                   rows, n, ld, S, alpha, hi, gscale, _p(codes), _p(rsum), _p(addend),
+                                   addend.shape[0] if addend is not None else 1, _stream()),
          "ofq_softmax_lsq_fwd")
     if want_codes:
         return prob, y, codes, rsum

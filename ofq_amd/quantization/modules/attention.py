@@ -27,13 +27,30 @@ def _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwi
                 symmetric=True, pretrained_initialized=pretrained_initialized)
 
 
-def _softmax_lsq(quant, S, N, alpha):
-    """unsigned per-query-token LSQ on softmax(S*alpha); lazily initialises quant.s like lsq.py:544-569."""
+def _softmax_init(quant, S, N, alpha, addend):
+    """lazily initialise the softmax quantiser's step like lsq.py:544-569 (data-dependent, first batch)."""
     if not quant.initialized_alpha or quant.s is None:
         with torch.no_grad():
-            p = torch.softmax(S[..., :N].detach() * alpha, dim=-1)
-            quant.init_from(p)
-    return SoftmaxLsqFn.apply(S, quant.s, N, alpha, quant.thd_pos)
+            a = S[..., :N].detach() * alpha
+            if addend is not None:
+                B, H = a.shape[0], a.shape[1]
+                P = addend.shape[0]
+                a = (a.reshape(B * H // P, P, N, N) + addend[..., :N].detach()).reshape(B, H, N, N)
+            quant.init_from(torch.softmax(a, dim=-1))
+
+
+def _fit_addend(addend, S):
+    """pad the (P, N, N) additive term to the row stride of the score tensor"""
+    if addend is not None and addend.shape[-1] != S.shape[-1]:
+        addend = torch.nn.functional.pad(addend, (0, S.shape[-1] - addend.shape[-1]))
+    return None if addend is None else addend.contiguous()
+
+
+def _softmax_lsq(quant, S, N, alpha, addend=None):
+    """unsigned per-query-token LSQ on softmax(S*alpha [+ addend])."""
+    addend = _fit_addend(addend, S)
+    _softmax_init(quant, S, N, alpha, addend)
+    return SoftmaxLsqFn.apply(S, quant.s, N, alpha, quant.thd_pos, addend)
 
 
 class QAttention(deit_attention):
@@ -64,20 +81,28 @@ class QAttention(deit_attention):
         self.move_v_aft = LearnableBias(C)
         self.quan_a_softmax_fn = LsqQuantizer(bit=input_bits, all_positive=True, per_channel=True, learnable=aq_learnable)
 
-    def _lazy_init(self, qkv):
-        B, N, C3 = qkv.shape
-        C = C3 // 3
-        with torch.no_grad():
-            t = qkv.detach() + self.move_qkv_b4.bias.detach()
-            for i, qz in enumerate((self.quan_a_q_fn, self.quan_a_k_fn, self.quan_a_v_fn)):
-                if not qz.initialized_alpha or qz.s is None:
-                    qz.init_from(t[..., i * C:(i + 1) * C])
-
     def forward(self, x):
+        return self.proj_drop(self.proj(plain_attention_core(self, x, self.scale))), None   # attention.py:103-105
+
+
+def _plain_lazy_init(self, qkv):
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    with torch.no_grad():
+        t = qkv.detach() + self.move_qkv_b4.bias.detach()
+        for i, qz in enumerate((self.quan_a_q_fn, self.quan_a_k_fn, self.quan_a_v_fn)):
+            if not qz.initialized_alpha or qz.s is None:
+                qz.init_from(t[..., i * C:(i + 1) * C])
+
+
+def plain_attention_core(self, x, scale, addend=None):
+    """qkv projection -> offsets/LSQ on q,k,v -> scores -> softmax+LSQ -> P.V, everything before `proj`
+    (attention.py:69-102; shared with the Swin window attention, swin_attention_and_mlp.py:173-228)."""
+    if True:
         B, N, C = x.shape
         H = self.num_heads
         qkv = self.qkv(x)                                                        # attention.py:69
-        self._lazy_init(qkv)
+        _plain_lazy_init(self, qkv)
         lo, hi = self.quan_a_q_fn.thd_neg, self.quan_a_q_fn.thd_pos
         gq = ops.LsqGeom(B, N, C, C, 0, lo, hi, B * C, ldx=3 * C, ldy=C)         # s per token, M = B*H*d
         gv = ops.LsqGeom(B * N, 1, C, C, 1, lo, hi, B * N, ldx=3 * C, ldy=C)     # s per channel, M = B*N
@@ -85,9 +110,8 @@ class QAttention(deit_attention):
                                       self.quan_a_v_fn.s, self.move_q_aft.bias, self.move_k_aft.bias,
                                       self.move_v_aft.bias, gq, gq, gv)          # :71-90
         S = QKScoresFn.apply(q, k, H)                                            # :96 (scale folded into softmax)
-        P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)               # :97-99
-        out = PVFn.apply(P, v, N)                                                # :102
-        return self.proj_drop(self.proj(out)), None                              # :103-105
+        P = _softmax_lsq(self.quan_a_softmax_fn, S, N, scale, addend)            # :97-99
+        return PVFn.apply(P, v, N)                                               # :102
 
 
 class QAttention_qkreparam(deit_attention):
@@ -134,6 +158,13 @@ class QAttention_qkreparam(deit_attention):
         return StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
 
     def forward(self, x):
+        return self.proj_drop(self.proj(qkr_attention_core(self, x, self.scale))), None     # attention.py:220-222
+
+
+def qkr_attention_core(self, x, scale, addend=None):
+    """Everything of QAttention_qkreparam.forward before `proj` (attention.py:177-219); also the core of the Swin
+    QKR window attention (swin_attention_and_mlp.py:374-423), which adds `addend` before the softmax."""
+    if True:
         B, N, C = x.shape
         H = self.num_heads
         xin = self.quant_x_4_qkv
@@ -164,7 +195,7 @@ class QAttention_qkreparam(deit_attention):
             qkx = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
                                            shape=(B, N * H, C), out_shape=(B, N, H, C))   # :201-206, s per (token, head)
             S = QKRScoresFn.apply(xq, qkx, H)                                    # :210
-            P = _softmax_lsq(self.quan_a_softmax_fn, S, N, self.scale)           # :213-216
+            P = _softmax_lsq(self.quan_a_softmax_fn, S, N, scale, addend)        # :213-216
             out = PVFn.apply(P, v, N)                                            # :219
         else:
             qkx, qcodes, qgeom = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
@@ -176,15 +207,14 @@ class QAttention_qkreparam(deit_attention):
                 "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
                 "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link})   # :210
             sm = self.quan_a_softmax_fn
-            if not sm.initialized_alpha or sm.s is None:
-                with torch.no_grad():
-                    sm.init_from(torch.softmax(S[..., :N].detach() * self.scale, dim=-1))
-            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, self.scale, sm.thd_pos, link)   # :213-216
+            addend = _fit_addend(addend, S)
+            _softmax_init(sm, S, N, scale, addend)
+            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)   # :213-216
             gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
             out = PVCodesFn.apply(P, v, {
                 "pcodes": pcodes, "rp": rp, "vcodes": vcodes, "sp": sm.s.detach(), "gp": gp,
                 "sv": self.quan_a_v_fn.s.detach(), "gv": vgeom.gscale, "bav": self.move_v_aft.bias.detach()})   # :219
-        return self.proj_drop(self.proj(out)), None                              # :220-222
+        return out
 
 
 class QAttention_qkreparam_4_cga(QAttention_qkreparam):

@@ -6,6 +6,8 @@ import torch
 from .qlinear import LSQ_QConv2d, QLinear, QMLP, LSQ_QLinear4head
 from .attention import QAttention, QAttention_qkreparam, QAttention_qkreparam_4_cga
 from ...deit_vision_transformer import Attention as deit_attention, Mlp
+from ...swin import ShiftedWindowAttention, MLP as swin_MLP
+from .swin_attention_and_mlp import QAttention_swin, QMLP_swin, QAttention_swin_qkreparam, QAttention_swin_qkreparam_4_cga
 
 QMODULE_MAPPINGS = {torch.nn.Linear: QLinear, deit_attention: QAttention, Mlp: QMLP}
 # 0: QAttention_qkreparam, 1: QAttention_qkreparam_4_cga                        (modules/utils.py:27-39)
@@ -56,5 +58,39 @@ def replace_module_by_qmodule_deit(model, qconfigs, pretrained_initialized=False
                 weight_quant_method=cfg["weight"]["mode"], input_quant_method=cfg["act"]["mode"],
                 aq_learnable=cfg["act"]["learnable"], wq_learnable=cfg["weight"]["learnable"],
                 act_layer=cfg["act_layer"], pretrained_initialized=pretrained_initialized, **extra)
+        set_module_by_name(model, name, qmodule)
+    return model
+
+
+# ---- Swin (modules/utils.py:286-413) ---------------------------------------------------------------------------
+QMODULE_MAPPINGS_SWIN = {torch.nn.Linear: QLinear, ShiftedWindowAttention: QAttention_swin, swin_MLP: QMLP_swin}
+QMODULE_MAPPINGS_QK_REPARAM_SWIN = [
+    {torch.nn.Linear: QLinear, ShiftedWindowAttention: QAttention_swin_qkreparam, swin_MLP: QMLP_swin},
+    {torch.nn.Linear: QLinear, ShiftedWindowAttention: QAttention_swin_qkreparam_4_cga, swin_MLP: QMLP_swin},
+]
+
+
+def replace_module_by_qmodule_swin(model, qconfigs, pretrained_initialized=False, qk_reparam=False, qk_reparam_type=0,
+                                   boundaryRange=0.005):
+    """Name-list driven surgery for Swin: `features.0.0` (4x4 patch conv) and `head` are forced to W8A8 LSQ, attention /
+    MLP / `reduction` linears follow the per-module config (modules/utils.py:305-413)."""
+    mapping = QMODULE_MAPPINGS_QK_REPARAM_SWIN[qk_reparam_type] if qk_reparam else QMODULE_MAPPINGS_SWIN
+    for name, cfg in qconfigs.items():
+        module = get_module_by_name(model, name)
+        if name == "features.0.0":
+            qmodule = LSQ_QConv2d(m=module, act_layer=cfg["act_layer"], pretrained_initialized=pretrained_initialized,
+                                  **_W8A8)
+        elif name == "head":
+            qmodule = LSQ_QLinear4head(m=module, symmetric=True, act_layer=cfg["act_layer"],
+                                       pretrained_initialized=pretrained_initialized, **_W8A8)
+        else:
+            if type(module) not in mapping:
+                raise KeyError("no quantised counterpart for %s (%s)" % (name, type(module).__name__))
+            qmodule = mapping[type(module)](
+                m=module, weight_bits=cfg["weight"]['bit'], input_bits=cfg["act"]['bit'],
+                weight_channelwise=cfg["weight"]["per_channel"], input_channelwise=cfg["act"]["per_channel"],
+                weight_quant_method=cfg["weight"]["mode"], input_quant_method=cfg["act"]["mode"],
+                aq_learnable=cfg["act"]["learnable"], wq_learnable=cfg["weight"]["learnable"],
+                act_layer=cfg["act_layer"], pretrained_initialized=pretrained_initialized)
         set_module_by_name(model, name, qmodule)
     return model

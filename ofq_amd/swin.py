@@ -1,0 +1,243 @@
+"""fp32 Swin-T skeleton — host-side counterpart of src/swin.py (PatchMerging :26, ShiftedWindowAttention :176,
+SwinTransformerBlock :255, SwinTransformer :330, swin_t :512) with the same module tree / state-dict names
+(`features.0.0` = 4x4 patch conv, `features.{1,3,5,7}.{i}.{norm1,attn,norm2,mlp}`, `features.{2,4,6}.{reduction,norm}`),
+so the reference's `qmodules` name lists and checkpoints carry over.  torchvision is not a dependency: `MLP` and
+`Permute` are the few lines needed from it.  Blocks pass `(features, attn_info)` tuples like the reference."""
+from functools import partial
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MLP(nn.Sequential):
+    """torchvision.ops.misc.MLP layout: Linear, act, Dropout, Linear, Dropout  (indices 0..4)."""
+
+    def __init__(self, in_channels, hidden_channels: List[int], activation_layer=nn.GELU, dropout=0.0):
+        layers, d = [], in_channels
+        for h in hidden_channels[:-1]:
+            layers += [nn.Linear(d, h), activation_layer(), nn.Dropout(dropout)]
+            d = h
+        layers += [nn.Linear(d, hidden_channels[-1]), nn.Dropout(dropout)]
+        super().__init__(*layers)
+
+
+class Permute(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+    def forward(self, x):
+        return torch.permute(x, self.dims)
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        fx, info = x
+        H, W, _ = fx.shape[-3:]
+        fx = F.pad(fx, (0, 0, 0, W % 2, 0, H % 2))
+        fx = torch.cat([fx[..., 0::2, 0::2, :], fx[..., 1::2, 0::2, :], fx[..., 0::2, 1::2, :], fx[..., 1::2, 1::2, :]], -1)
+        return self.reduction(self.norm(fx)), info
+
+
+def relative_position_index(window_size):
+    """pair-wise relative position index inside a window (swin.py:220-231)"""
+    ch, cw = torch.arange(window_size[0]), torch.arange(window_size[1])
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += window_size[0] - 1
+    rel[:, :, 1] += window_size[1] - 1
+    rel[:, :, 0] *= 2 * window_size[1] - 1
+    return rel.sum(-1).view(-1)
+
+
+def shift_attention_mask(pad_H, pad_W, window_size, shift_size, device):
+    """(num_windows, N, N) additive mask of the shifted-window scheme: 0 inside a region, -100 across (swin.py:134-151)"""
+    m = torch.zeros((pad_H, pad_W), device=device)
+    hs = ((0, -window_size[0]), (-window_size[0], -shift_size[0]), (-shift_size[0], None))
+    ws = ((0, -window_size[1]), (-window_size[1], -shift_size[1]), (-shift_size[1], None))
+    count = 0
+    for h in hs:
+        for w in ws:
+            m[h[0]:h[1], w[0]:w[1]] = count
+            count += 1
+    nw = (pad_H // window_size[0]) * (pad_W // window_size[1])
+    m = m.view(pad_H // window_size[0], window_size[0], pad_W // window_size[1], window_size[1])
+    m = m.permute(0, 2, 1, 3).reshape(nw, window_size[0] * window_size[1])
+    m = m.unsqueeze(1) - m.unsqueeze(2)
+    return m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
+
+
+class WindowGeometry:
+    """pad -> cyclic shift -> window partition of a (B, H, W, C) map and the inverse (swin.py:103-131, :160-170)."""
+
+    def __init__(self, x, window_size, shift_size):
+        B, H, W, C = x.shape
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.ws = list(window_size)
+        pad_r = (self.ws[1] - W % self.ws[1]) % self.ws[1]
+        pad_b = (self.ws[0] - H % self.ws[0]) % self.ws[0]
+        self.pad = (pad_r, pad_b)
+        self.pH, self.pW = H + pad_b, W + pad_r
+        ss = list(shift_size)
+        if self.ws[0] >= self.pH:
+            ss[0] = 0
+        if self.ws[1] >= self.pW:
+            ss[1] = 0
+        self.ss = ss
+        self.nW = (self.pH // self.ws[0]) * (self.pW // self.ws[1])
+        self.N = self.ws[0] * self.ws[1]
+
+    def partition(self, x):
+        x = F.pad(x, (0, 0, 0, self.pad[0], 0, self.pad[1]))
+        if sum(self.ss) > 0:
+            x = torch.roll(x, shifts=(-self.ss[0], -self.ss[1]), dims=(1, 2))
+        x = x.view(self.B, self.pH // self.ws[0], self.ws[0], self.pW // self.ws[1], self.ws[1], self.C)
+        return x.permute(0, 1, 3, 2, 4, 5).reshape(self.B * self.nW, self.N, self.C)
+
+    def reverse(self, x):
+        x = x.view(self.B, self.pH // self.ws[0], self.pW // self.ws[1], self.ws[0], self.ws[1], self.C)
+        x = x.permute(0, 1, 3, 2, 4, 5).reshape(self.B, self.pH, self.pW, self.C)
+        if sum(self.ss) > 0:
+            x = torch.roll(x, shifts=(self.ss[0], self.ss[1]), dims=(1, 2))
+        return x[:, :self.H, :self.W, :].contiguous()
+
+    def addend(self, table, index, num_heads):
+        """(P, N, N) additive term of the softmax: relative-position bias per head (+ shift mask per window);
+        slab index = window * heads + head, P = heads (no shift) or windows * heads."""
+        bias = table[index].view(self.N, self.N, -1).permute(2, 0, 1)               # (heads, N, N)
+        if sum(self.ss) == 0:
+            return bias.contiguous()
+        mask = shift_attention_mask(self.pH, self.pW, self.ws, self.ss, table.device)  # (nW, N, N)
+        return (bias.unsqueeze(0) + mask.unsqueeze(1)).reshape(self.nW * num_heads, self.N, self.N)
+
+
+class ShiftedWindowAttention(nn.Module):
+    def __init__(self, dim, window_size, shift_size, num_heads, qkv_bias=True, proj_bias=True, attention_dropout=0.0,
+                 dropout=0.0, qqkkvv=False):
+        super().__init__()
+        if len(window_size) != 2 or len(shift_size) != 2:
+            raise ValueError("window_size and shift_size must be of length 2")
+        if qqkkvv:
+            raise ValueError("qqkkvv score outputs belong to the unused kd_hard_and_soft 2/3 losses (out of scope)")
+        self.dim, self.window_size, self.shift_size, self.num_heads = dim, window_size, shift_size, num_heads
+        self.attention_dropout, self.dropout, self.qqkkvv = attention_dropout, dropout, qqkkvv
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(window_size))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, x):
+        g = WindowGeometry(x, self.window_size, self.shift_size)
+        xw = g.partition(x)
+        Bw, N, C = xw.shape
+        H = self.num_heads
+        qkv = self.qkv(xw).reshape(Bw, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = (q * (C // H) ** -0.5).matmul(k.transpose(-2, -1))
+        add = g.addend(self.relative_position_bias_table, self.relative_position_index, H)
+        P = add.shape[0]
+        attn = (attn.reshape(Bw * H // P, P, N, N) + add).reshape(Bw, H, N, N)
+        attn = F.softmax(attn, dim=-1)
+        out = attn.matmul(v).transpose(1, 2).reshape(Bw, N, C)
+        return g.reverse(self.proj(out)), None
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio=4.0, dropout=0.0, qqkkvv=False,
+                 attention_dropout=0.0, stochastic_depth_prob=0.0, norm_layer=nn.LayerNorm,
+                 attn_layer=ShiftedWindowAttention):
+        super().__init__()
+        if stochastic_depth_prob > 0:
+            raise ValueError("stochastic depth is 0 in every OFQ recipe (drop_path: 0.0)")
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_layer(dim, window_size, shift_size, num_heads, attention_dropout=attention_dropout,
+                               dropout=dropout, qqkkvv=qqkkvv)
+        self.qqkkvv = qqkkvv
+        self.stochastic_depth = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = MLP(dim, [int(dim * mlp_ratio), dim], activation_layer=nn.GELU, dropout=dropout)
+        for m in self.mlp.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.normal_(m.bias, std=1e-6)
+
+    def forward(self, x):
+        x = x[0]
+        y, info = self.attn(self.norm1(x))
+        x = x + y
+        x = x + self.mlp(self.norm2(x))
+        return x, info
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, patch_size, embed_dim, depths, num_heads, window_size, mlp_ratio=4.0, dropout=0.0, qqkkvv=False,
+                 attention_dropout=0.0, stochastic_depth_prob=0.0, num_classes=1000, norm_layer=None, block=None):
+        super().__init__()
+        self.num_classes = num_classes
+        block = block or SwinTransformerBlock
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-5)
+        layers = [nn.Sequential(nn.Conv2d(3, embed_dim, kernel_size=tuple(patch_size), stride=tuple(patch_size)),
+                                Permute([0, 2, 3, 1]), norm_layer(embed_dim))]
+        for i_stage in range(len(depths)):
+            dim = embed_dim * 2 ** i_stage
+            stage = [block(dim, num_heads[i_stage], window_size=window_size,
+                           shift_size=[0 if i_layer % 2 == 0 else w // 2 for w in window_size], mlp_ratio=mlp_ratio,
+                           dropout=dropout, qqkkvv=qqkkvv, attention_dropout=attention_dropout,
+                           stochastic_depth_prob=0.0, norm_layer=norm_layer) for i_layer in range(depths[i_stage])]
+            layers.append(nn.Sequential(*stage))
+            if i_stage < len(depths) - 1:
+                layers.append(PatchMerging(dim, norm_layer))
+        self.features = nn.Sequential(*layers)
+        self.qqkkvv = qqkkvv
+        num_features = embed_dim * 2 ** (len(depths) - 1)
+        self.norm = norm_layer(num_features)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(num_features, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward_features(self, x):
+        x = (self.features[0](x), None)
+        infos = []
+        for blk in self.features[1:]:
+            if isinstance(blk, nn.Sequential):
+                info = None
+                for b in blk:
+                    x = b(x)
+                    info = x[1]
+                    x = (x[0], None)
+            else:
+                x = blk(x)
+                info = x[1]
+                x = (x[0], None)
+            infos.append(info)
+        return x[0], infos
+
+    def forward(self, x):
+        x, infos = self.forward_features(x)
+        x = self.norm(x).permute(0, 3, 1, 2)
+        x = torch.flatten(self.avgpool(x), 1)
+        return self.head(x), infos
+
+
+def swin_t(pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained Swin-T weights need network access; load a checkpoint with load_state_dict")
+    kwargs.pop("drop_path", None)
+    kwargs.pop("weights", None)
+    return SwinTransformer(patch_size=[4, 4], embed_dim=kwargs.pop("embed_dim", 96), depths=kwargs.pop("depths", [2, 2, 6, 2]),
+                           num_heads=kwargs.pop("num_heads", [3, 6, 12, 24]), window_size=[7, 7], **kwargs)

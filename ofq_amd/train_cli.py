@@ -142,7 +142,10 @@ def main_worker(local_rank, args, cga, spawned):
     model = create_model(args.model, num_classes=args.num_classes)
     if args.quantized:
         if args.qmodules is None:
-            args.qmodules = engine.default_qmodules(len(model.blocks))
+            if args.model_type == 'swin':
+                args.qmodules = engine.default_qmodules_swin([len(st) for st in model.features[1::2]])
+            else:
+                args.qmodules = engine.default_qmodules(len(model.blocks))
         model = engine.get_qat_model(model, args)                                           # train.py:523
     model.to(dev)
     teacher = None
@@ -151,8 +154,7 @@ def main_worker(local_rank, args, cga, spawned):
     loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, args.num_classes, dev, args.seed + rank)
     val_loader = SyntheticLoader(args.val_steps, args.batch_size, args.num_classes, dev, args.seed + 1000 + rank)
     engine.setup_alpha(model, loader.pool[0][0])                                            # train.py:656-657
-    log(rank, str(model.blocks[0]) if rank == 0 and args.log_interval <= 1 else "model: %s, %.2f M parameters"
-        % (args.model, sum(p.numel() for p in model.parameters()) / 1e6))
+    log(rank, "model: %s, %.2f M parameters" % (args.model, sum(p.numel() for p in model.parameters()) / 1e6))
     optimizer = engine.make_optimizer(model, lr=args.lr, weight_decay=args.weight_decay)    # train.py:662
     start_epoch = 0
     if args.resume:                                                                         # train.py:691-706
@@ -164,7 +166,7 @@ def main_worker(local_rank, args, cga, spawned):
     dp = parallel.DataParallel(model) if world > 1 else None                                # train.py:727
     loss_fn = KDLossSoftandHard()
     qkr = bool(args.qk_reparam)
-    hooks = engine.CGAHooks(model, args.wq_bitw, args.boundaryRange, qk_reparam=qkr) if cga else None
+    hooks = engine.CGAHooks(model, args.wq_bitw, args.boundaryRange, qk_reparam=qkr, model_type=args.model_type) if cga else None
     first, last = (args.epochs, args.epochs + args.freeze_for_n_epochs) if cga else (start_epoch, args.epochs)
     total_steps = max(1, args.epochs * len(loader))
     for epoch in range(first, last):                                                        # cga.py:760 / train.py:816

@@ -232,8 +232,9 @@ def _sub(p, prefix):
     return {k[n:]: v for k, v in p.items() if k.startswith(prefix)}
 
 
-def qattention(x, p, num_heads, wbits, abits):
-    """QAttention.forward, the plain (non-QKR) path (attention.py:67-105)."""
+def qattention(x, p, num_heads, wbits, abits, pre_softmax=None):
+    """QAttention.forward, the plain (non-QKR) path (attention.py:67-105).  `pre_softmax` (Swin) maps the scaled
+    scores to scores + relative-position bias (+ shift mask), swin_attention_and_mlp.py:201-221."""
     B, N, C = x.shape
     d = C // num_heads
     qkv = qlinear(x, _sub(p, "qkv."), wbits, abits)                      # :69
@@ -253,13 +254,109 @@ def qattention(x, p, num_heads, wbits, abits):
     k = k.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
     v = v.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
     attn = (q @ k.transpose(-2, -1).contiguous()) * (d ** -0.5)          # :96
+    if pre_softmax is not None:
+        attn = pre_softmax(attn)
     prob = F.softmax(attn, dim=-1)                                       # :97
     prob = lsq_token(prob, p["quan_a_softmax_fn.s"], abits, True)        # :99
     out = (prob @ v).transpose(1, 2).reshape(B, N, C)                    # :102
     return qlinear(out, _sub(p, "proj."), wbits, abits)                  # :103
 
 
-def qattention_qkr(x, p, num_heads, wbits, abits):
+def _rel_index(ws):
+    ch, cw = torch.arange(ws[0]), torch.arange(ws[1])
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws[0] - 1
+    rel[:, :, 1] += ws[1] - 1
+    rel[:, :, 0] *= 2 * ws[1] - 1
+    return rel.sum(-1).view(-1)
+
+
+def swin_window_attention(x, p, num_heads, window, shift, wbits, abits, qkr):
+    """QAttention_swin.forward / QAttention_swin_qkreparam.forward (swin_attention_and_mlp.py:143-251, :344-461):
+    pad, cyclic shift, window partition, the DeiT attention on each window with relative-position bias and shift mask
+    added to the scaled scores, reverse."""
+    ws, ss = list(window), list(shift)
+    N = ws[0] * ws[1]
+    bias = p["relative_position_bias_table"][_rel_index(ws)].view(N, N, -1).permute(2, 0, 1).contiguous().unsqueeze(0)
+    B, H, W, C = x.shape
+    pad_r = (ws[1] - W % ws[1]) % ws[1]
+    pad_b = (ws[0] - H % ws[0]) % ws[0]
+    x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))                              # :148-150
+    pH, pW = x.shape[1], x.shape[2]
+    if ws[0] >= pH:
+        ss[0] = 0                                                        # :153-156
+    if ws[1] >= pW:
+        ss[1] = 0
+    if sum(ss) > 0:
+        x = torch.roll(x, shifts=(-ss[0], -ss[1]), dims=(1, 2))          # :159-160
+    nW = (pH // ws[0]) * (pW // ws[1])
+    x = x.view(B, pH // ws[0], ws[0], pW // ws[1], ws[1], C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, N, C)   # :163-165
+
+    def pre_softmax(attn):
+        attn = attn + bias                                               # :203
+        if sum(ss) > 0:                                                  # :205-221
+            m = x.new_zeros((pH, pW))
+            hs = ((0, -ws[0]), (-ws[0], -ss[0]), (-ss[0], None))
+            wsl = ((0, -ws[1]), (-ws[1], -ss[1]), (-ss[1], None))
+            count = 0
+            for h in hs:
+                for w in wsl:
+                    m[h[0]:h[1], w[0]:w[1]] = count
+                    count += 1
+            m = m.view(pH // ws[0], ws[0], pW // ws[1], ws[1]).permute(0, 2, 1, 3).reshape(nW, N)
+            m = m.unsqueeze(1) - m.unsqueeze(2)
+            m = m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
+            attn = attn.view(B, nW, num_heads, N, N) + m.unsqueeze(1).unsqueeze(0)
+            attn = attn.view(-1, num_heads, N, N)
+        return attn
+
+    fn = qattention_qkr if qkr else qattention
+    y = fn(x, {k: v for k, v in p.items() if not k.startswith("relative_position")}, num_heads, wbits, abits, pre_softmax)
+    y = y.view(B, pH // ws[0], pW // ws[1], ws[0], ws[1], C).permute(0, 1, 3, 2, 4, 5).reshape(B, pH, pW, C)   # :231-232
+    if sum(ss) > 0:
+        y = torch.roll(y, shifts=(ss[0], ss[1]), dims=(1, 2))            # :235-236
+    return y[:, :H, :W, :].contiguous()                                  # :239
+
+
+def swin_patch_merging(x, p, wbits, abits, eps=1e-5):
+    """PatchMerging.forward with a quantised `reduction` (swin.py:40-60); QLinear on a 4-D input: the LSQ step is
+    indexed by the feature-map column (x.shape[-2])."""
+    H, W, _ = x.shape[-3:]
+    x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[..., 0::2, 0::2, :], x[..., 1::2, 0::2, :], x[..., 0::2, 1::2, :], x[..., 1::2, 1::2, :]], -1)
+    x = F.layer_norm(x, (x.shape[-1],), p["norm.weight"], p["norm.bias"], eps)
+    return qlinear(x, _sub(p, "reduction."), wbits, abits)
+
+
+def swin_forward(img, sd, cfg):
+    """SwinTransformer.forward (swin.py:441-470) with quantised stem, window attention, MLP, reductions and head.
+    cfg: dict(depths, num_heads, window, patch, wbits, abits, qkr)."""
+    wb, ab = cfg["wbits"], cfg["abits"]
+    eps = 1e-5
+    x = qconv_patch_embed_nhwc(img, _sub(sd, "features.0.0."), cfg["patch"])                  # features.0.0 + Permute
+    x = F.layer_norm(x, (x.shape[-1],), sd["features.0.2.weight"], sd["features.0.2.bias"], eps)
+    fi = 1
+    for si, depth in enumerate(cfg["depths"]):
+        for li in range(depth):
+            pre = "features.%d.%d." % (fi, li)
+            C = x.shape[-1]
+            shift = [0 if li % 2 == 0 else w // 2 for w in cfg["window"]]
+            h = F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps)
+            x = x + swin_window_attention(h, _sub(sd, pre + "attn."), cfg["num_heads"][si], cfg["window"], shift, wb, ab,
+                                          cfg["qkr"])
+            h = F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], eps)
+            x = x + qmlp(h, _sub(sd, pre + "mlp."), wb, ab)
+        fi += 1
+        if si < len(cfg["depths"]) - 1:
+            x = swin_patch_merging(x, _sub(sd, "features.%d." % fi), wb, ab)
+            fi += 1
+    x = F.layer_norm(x, (x.shape[-1],), sd["norm.weight"], sd["norm.bias"], eps)
+    x = x.permute(0, 3, 1, 2).mean(dim=(2, 3))                             # AdaptiveAvgPool2d(1) + flatten
+    return qhead(x, _sub(sd, "head."))
+
+
+def qattention_qkr(x, p, num_heads, wbits, abits, pre_softmax=None):
     """QAttention_qkreparam.forward (attention.py:174-222); the `_4_cga` twin (:291-339) is
     numerically identical in value and gradient (SURVEY.md §7 hard part 9)."""
     B, N, C = x.shape
@@ -291,6 +388,8 @@ def qattention_qkr(x, p, num_heads, wbits, abits):
     qkx = qkx.reshape(B, N, H, -1).permute(0, 2, 3, 1)                   # :207  (B,H,C,N)
     attn = torch.einsum("BNC,BHCD->BHND", xq, qkx)                       # :210
     attn = attn * (d ** -0.5)                                            # :213
+    if pre_softmax is not None:
+        attn = pre_softmax(attn)
     prob = F.softmax(attn, dim=-1)                                       # :214
     prob = lsq_token(prob, p["quan_a_softmax_fn.s"], abits, True)        # :216
     out = (prob @ v).transpose(1, 2).reshape(B, N, C)                    # :219
@@ -307,6 +406,14 @@ def qconv_patch_embed(img, p, patch):
     x = x + p["move_aft.bias"].reshape(ww, hh).expand_as(x)              # :173
     y = F.conv2d(x, W, p["bias"], stride=patch)                          # :174
     return y.flatten(2).transpose(1, 2)
+
+
+def qconv_patch_embed_nhwc(img, p, patch):
+    """Swin stem: LSQ_QConv2d then Permute([0,2,3,1]) (swin.py:385-393)."""
+    B = img.shape[0]
+    y = qconv_patch_embed(img, p, patch)                                 # (B, gh*gw, C), row-major over (gh, gw)
+    g = img.shape[-1] // patch
+    return y.reshape(B, img.shape[-2] // patch, g, -1)
 
 
 def qhead(x, p):

@@ -413,9 +413,122 @@ def g8_cga():
     save("g8_cga", out)
 
 
+# ------------------------------------------------------------------------------------------------
+# G9 Swin: window attention (plain / QKR / QKR-cga, shifted and not), 4-D QLinear (`reduction`), QMLP_swin,
+#          and a tiny full Swin model step
+# ------------------------------------------------------------------------------------------------
+def g9_swin():
+    from src.swin import ShiftedWindowAttention, SwinTransformer
+    from src.quantization.modules.swin_attention_and_mlp import (QAttention_swin, QAttention_swin_qkreparam,
+                                                                 QAttention_swin_qkreparam_4_cga, QMLP_swin)
+    from src.quantization.modules.utils import replace_module_by_qmodule_swin
+    from torchvision.ops.misc import MLP as swin_MLP
+    out = {}
+    k = 0
+    for (kind, cls) in [("plain", QAttention_swin), ("qkr", QAttention_swin_qkreparam), ("qkrcga", QAttention_swin_qkreparam_4_cga)]:
+        for shift in (0, 3):
+            for (wb, ab) in [(2, 2), (4, 4)]:
+                if kind == "qkrcga" and (shift == 0 or wb != 2):
+                    continue
+                B, Hh, Ww, C, H = 2, 14, 13, 24, 3           # W = 13 exercises the right-padding path
+                m = ShiftedWindowAttention(C, [7, 7], [shift, shift], H)
+                with torch.no_grad():
+                    m.qkv.weight.copy_(T(det_normalish((3 * C, C), 900 + 10 * k, 0.2)))
+                    m.qkv.bias.copy_(T(det_uniform((3 * C,), 901 + 10 * k, -0.1, 0.1)))
+                    m.proj.weight.copy_(T(det_normalish((C, C), 902 + 10 * k, 0.15)))
+                    m.proj.bias.copy_(T(det_uniform((C,), 903 + 10 * k, -0.1, 0.1)))
+                q = cls(m=m, weight_bits=wb, input_bits=ab, pretrained_initialized=True)
+                with torch.no_grad():
+                    q.relative_position_bias_table.copy_(T(det_normalish(tuple(q.relative_position_bias_table.shape),
+                                                                         904 + 10 * k, 0.5)))
+                x = T(det_normalish((B, Hh, Ww, C), 905 + 10 * k, 1.0))
+                d = run_module(q, x, 906 + 10 * k, out_index=0)
+                d["meta"] = np.array([B, Hh, Ww, C, H, wb, ab, shift, 905 + 10 * k])
+                name = "attn_%s_s%d_w%da%d" % (kind, shift, wb, ab)
+                for kk, v in d.items():
+                    out[name + ":" + kk] = v
+                k += 1
+    # QLinear on a 4-D input (PatchMerging.reduction: bias-less source -> default-initialised QLinear bias)
+    lin = nn.Linear(48, 24, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(T(det_normalish((24, 48), 990, 0.1)))
+    q = QLinear(m=lin, weight_bits=3, input_bits=3, pretrained_initialized=True)
+    with torch.no_grad():
+        q.bias.copy_(T(det_uniform((24,), 991, -0.1, 0.1)))
+    d = run_module(q, T(det_normalish((2, 5, 6, 48), 992, 1.0)), 993)
+    d["meta"] = np.array([2, 5, 6, 48, 24, 3, 3, 992])
+    for kk, v in d.items():
+        out["reduction4d:" + kk] = v
+    mm = swin_MLP(24, [48, 24], activation_layer=nn.GELU, inplace=None, dropout=0.0)
+    with torch.no_grad():
+        mm[0].weight.copy_(T(det_normalish((48, 24), 994, 0.2)))
+        mm[0].bias.copy_(T(det_uniform((48,), 995, -0.1, 0.1)))
+        mm[3].weight.copy_(T(det_normalish((24, 48), 996, 0.15)))
+        mm[3].bias.copy_(T(det_uniform((24,), 997, -0.1, 0.1)))
+    q = QMLP_swin(m=mm, weight_bits=2, input_bits=2, act_layer=nn.GELU, pretrained_initialized=True)
+    d = run_module(q, T(det_normalish((2, 5, 6, 24), 998, 1.0)), 999)
+    d["meta"] = np.array([2, 5, 6, 24, 48, 2, 2, 998])
+    for kk, v in d.items():
+        out["mlp4d:" + kk] = v
+    save("g9_swin_modules", out)
+
+    # tiny full Swin model
+    out = {}
+    for k, (name, qkr, wb, ab) in enumerate([("plain_w4a4", False, 4, 4), ("qkr_w2a2", True, 2, 2)]):
+        depths, heads, dim, ncls = [2, 2], [2, 4], 16, 10
+        model = SwinTransformer(patch_size=[4, 4], embed_dim=dim, depths=depths, num_heads=heads, window_size=[7, 7],
+                                num_classes=ncls)
+        with torch.no_grad():
+            for i, (n, p) in enumerate(model.named_parameters()):
+                if p.dim() >= 2 and "norm" not in n:
+                    p.copy_(T(det_normalish(tuple(p.shape), 1100 + 80 * k + i, 0.15)))
+                elif "norm" in n and n.endswith("weight"):
+                    p.copy_(T(det_uniform(tuple(p.shape), 1100 + 80 * k + i, 0.8, 1.2)))
+                else:
+                    p.copy_(T(det_uniform(tuple(p.shape), 1100 + 80 * k + i, -0.1, 0.1)))
+        names = ["features.0.0"]
+        fi = 1
+        for si, dd in enumerate(depths):
+            for li in range(dd):
+                names += ["features.%d.%d.attn" % (fi, li), "features.%d.%d.mlp" % (fi, li)]
+            fi += 1
+            if si < len(depths) - 1:
+                names.append("features.%d.reduction" % fi)
+                fi += 1
+        names.append("head")
+        model = replace_module_by_qmodule_swin(model, _qconfigs(names, wb, ab), pretrained_initialized=True,
+                                               qk_reparam=qkr, qk_reparam_type=0)
+        B = 1
+        img = T(det_uniform((B, 3, 224, 224), 1260 + k, -2.0, 2.0))
+        target = T(det_int((B,), 1261 + k, ncls))
+        soft = T(det_normalish((B, ncls), 1262 + k, 2.0))
+        model.eval()
+        with torch.no_grad():
+            model(img)
+        randomize_offsets_and_scales(model, 1270 + k)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith("relative_position_bias_table"):
+                    p.copy_(T(det_normalish(tuple(p.shape), 1280 + k, 0.5)))
+        model.train()
+        logits, _ = model(img)
+        loss = KDLossSoftandHard()(logits, target, soft)
+        loss.backward()
+        d = {"logits": npy(logits), "loss": npy(loss), "target": npy(target), "soft": npy(soft),
+             "meta": np.array([B, dim, wb, ab, int(qkr), 1260 + k, ncls] + depths + heads)}
+        for n, p in model.state_dict().items():
+            d["p:" + n] = npy(p)
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                d["grad:" + n] = npy(p.grad)
+        for kk, v in d.items():
+            out[name + ":" + kk] = v
+    save("g9_swin_tiny", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = {"g1": g1_statsq, "g2": g2_lsq, "g3": g3_qlinear, "g4": g4_attention, "g5": g5_qmlp, "g6": g6_stem_head,
-           "g7": g7_tiny_deit, "g8": g8_cga}
+           "g7": g7_tiny_deit, "g8": g8_cga, "g9": g9_swin}
     for w in which:
         fns[w]()

@@ -236,3 +236,71 @@ def test_code_gemm_path_equals_fp32_gemm_path(env):
         assert _rel_l2(res[True][1], res[False][1]) < 1e-4
         for n_ in res[False][2]:
             assert _rel_l2(res[True][2][n_], res[False][2][n_]) < 1e-3 or "move_" in n_, n_
+
+
+def test_swin_modules_golden(env):
+    """Swin window attention (plain / QKR / cga twin, shifted and not, right-padded map), 4-D QLinear, QMLP_swin."""
+    from ofq_amd.swin import ShiftedWindowAttention, MLP
+    from ofq_amd.quantization.modules.swin_attention_and_mlp import (QAttention_swin, QAttention_swin_qkreparam,
+                                                                     QAttention_swin_qkreparam_4_cga, QMLP_swin)
+    from ofq_amd.quantization.modules.qlinear import QLinear
+    d = load_golden("g9_swin_modules")
+    kinds = {"plain": QAttention_swin, "qkr": QAttention_swin_qkreparam, "qkrcga": QAttention_swin_qkreparam_4_cga}
+    n = 0
+    for nme in case_names(d):
+        g = group(d, nme)
+        if nme.startswith("attn_"):
+            B, Hh, Ww, C, H, wb, ab, shift, seed = [int(v) for v in g["meta"]]
+            q = kinds[nme.split("_")[1]](m=ShiftedWindowAttention(C, [7, 7], [shift, shift], H), weight_bits=wb,
+                                         input_bits=ab, pretrained_initialized=True)
+            _run(q, g, T(det_normalish((B, Hh, Ww, C), seed, 1.0)), out_index=0)
+            n += 1
+        elif nme == "reduction4d":
+            B, Hh, Ww, I, Oo, wb, ab, seed = [int(v) for v in g["meta"]]
+            q = QLinear(m=nn.Linear(I, Oo, bias=False), weight_bits=wb, input_bits=ab, pretrained_initialized=True)
+            _run(q, g, T(det_normalish((B, Hh, Ww, I), seed, 1.0)))
+            assert tuple(q.input_quant_fn.s.shape) == (Ww,)
+        else:
+            B, Hh, Ww, C, Hd, wb, ab, seed = [int(v) for v in g["meta"]]
+            q = QMLP_swin(m=MLP(C, [Hd, C], activation_layer=nn.GELU), weight_bits=wb, input_bits=ab, act_layer=nn.GELU,
+                          pretrained_initialized=True)
+            _run(q, g, T(det_normalish((B, Hh, Ww, C), seed, 1.0)))
+    assert n >= 9
+
+
+def test_swin_tiny_full_step_golden(env):
+    from ofq_amd.swin import SwinTransformer
+    from ofq_amd import engine
+    from ofq_amd.quantization.modules.utils import replace_module_by_qmodule_swin
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    d = load_golden("g9_swin_tiny")
+    for nme in case_names(d):
+        g = group(d, nme)
+        meta = [int(v) for v in g["meta"]]
+        B, dim, wb, ab, qkr, seed, ncls = meta[:7]
+        depths, heads = meta[7:9], meta[9:11]
+        model = SwinTransformer(patch_size=[4, 4], embed_dim=dim, depths=depths, num_heads=heads, window_size=[7, 7],
+                                num_classes=ncls)
+        model = replace_module_by_qmodule_swin(model, _qconfigs(engine.default_qmodules_swin(depths), wb, ab),
+                                               pretrained_initialized=True, qk_reparam=bool(qkr), qk_reparam_type=0)
+        model.cuda()
+        img = T(det_uniform((B, 3, 224, 224), seed, -2.0, 2.0)).cuda()
+        model.eval()
+        with torch.no_grad():
+            model(img)
+        _load(model, g)
+        model.train()
+        logits, _ = model(img)
+        loss = KDLossSoftandHard()(logits, T(g["target"]).cuda(), T(g["soft"]).cuda())
+        loss.backward()
+        assert rel_err(logits.detach(), g["logits"]) < TOL
+        assert abs(float(loss.detach()) - float(g["loss"])) < TOL * abs(float(g["loss"]))
+        n, bad = 0, {}
+        for pn, p in model.named_parameters():
+            if "grad:" + pn in g:
+                assert p.grad is not None, pn
+                e = _offset_grad_err(p.grad, g, pn) if "move_" in pn else _rel_l2(p.grad, g["grad:" + pn])
+                if e > 5e-3 and float(np.abs(g["grad:" + pn]).max()) > 1e-6:
+                    bad[pn] = e
+                n += 1
+        assert n > 80 and not bad, bad

@@ -221,3 +221,53 @@ def test_statsq_scale_invariance_property():
         y2, L2, _ = O.statsq(W * 4.0, bits)
         assert torch.equal(L1, L2)
         assert torch.equal(y1 * 4.0, y2)
+
+
+def test_g9_swin_modules():
+    d = load_golden("g9_swin_modules")
+    names = case_names(d)
+    assert sum(n.startswith("attn_") for n in names) >= 9
+    for nme in names:
+        g = group(d, nme)
+        if nme.startswith("attn_"):
+            B, Hh, Ww, C, H, wb, ab, shift, seed = [int(v) for v in g["meta"]]
+            g["_x"] = T(det_normalish((B, Hh, Ww, C), seed, 1.0))
+            qkr = not nme.startswith("attn_plain")
+            _check_module(g, lambda x, p: O.swin_window_attention(x, p, H, [7, 7], [shift, shift], wb, ab, qkr), tol=5e-6)
+        elif nme == "reduction4d":
+            B, Hh, Ww, I, Oo, wb, ab, seed = [int(v) for v in g["meta"]]
+            g["_x"] = T(det_normalish((B, Hh, Ww, I), seed, 1.0))
+            _check_module(g, lambda x, p: O.qlinear(x, p, wb, ab))
+            assert g["p:input_quant_fn.s"].shape == (Ww,)                 # step indexed by the feature-map column
+        else:
+            B, Hh, Ww, C, Hd, wb, ab, seed = [int(v) for v in g["meta"]]
+            g["_x"] = T(det_normalish((B, Hh, Ww, C), seed, 1.0))
+            _check_module(g, lambda x, p: O.qmlp(x, p, wb, ab))
+
+
+def test_g9_swin_tiny_full_step():
+    d = load_golden("g9_swin_tiny")
+    for nme in case_names(d):
+        g = group(d, nme)
+        meta = [int(v) for v in g["meta"]]
+        B, dim, wb, ab, qkr, seed, ncls = meta[:7]
+        depths, heads = meta[7:9], meta[9:11]
+        cfg = dict(depths=depths, num_heads=heads, window=[7, 7], patch=4, wbits=wb, abits=ab, qkr=bool(qkr))
+        p = params(g)
+        img = T(det_uniform((B, 3, 224, 224), seed, -2.0, 2.0))
+        logits = O.swin_forward(img, p, cfg)
+        loss = O.kd_loss_soft_and_hard(logits, logits, T(g["target"]), T(g["soft"]))
+        loss.backward()
+        assert rel_err(logits.detach(), g["logits"]) < 1e-5
+        assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+        n = 0
+        for k, v in g.items():
+            if k.startswith("grad:"):
+                gp = p[k[5:]].grad
+                assert gp is not None, k
+                den = np.abs(v).max()
+                if den < 1e-6:
+                    continue
+                assert rel_err(gp, v) < 2e-4, k
+                n += 1
+        assert n > 80
