@@ -64,7 +64,8 @@ __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { retur
 
 // second stage: dst[c] = scale * sum_{r<nrows} sum_{t<cnt} src[r*row_stride + c*cnt + t], fixed order.
 // Up to three independent jobs (ds, db4, dbaft) in one launch: blockIdx.y selects the job.
-struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; };
+// source offset of column c: (c / col_div) * col_mul + (c % col_div) * cnt   (col_div = 0: plain c * cnt)
+struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; int64_t col_div, col_mul; };
 struct SumJobs { SumJob j[3]; };
 
 __global__ __launch_bounds__(256) void strided_sum_kernel(SumJobs jobs) {
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void strided_sum_kernel(SumJobs jobs) {
   float acc = 0.f;
   if (jb.dst && c < jb.ncols) {
     for (int64_t r = py; r < jb.nrows; r += 16) {
-      const float* p = jb.src + r * jb.row_stride + c * jb.cnt;
+      const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
+      const float* p = jb.src + r * jb.row_stride + co;
       for (int t = 0; t < jb.cnt; ++t) acc += p[t];
     }
   }

@@ -12,7 +12,7 @@
 #include "common.h"
 
 struct LsqGeom {
-  int TX, TY, J, gx, gy, k, nslot;
+  int TX, TY, J, gx, gy, k, nslot, widek;   // widek: more bias phases than row-groups per workgroup
 };
 
 static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g) {
@@ -29,15 +29,22 @@ static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g) {
     gy = (int)ceil_div(w4, (int64_t)TX * J);
   }
   int TY = 256 / TX;
+  int widek = 0;
   if (k > 1) {
-    if (k > TY) return OFQ_EINVAL;
-    TY = (TY / (int)k) * (int)k;
+    if (k > TY) widek = 1;                       // e.g. Swin stage 3/4: 12 / 24 heads but only 8 / 4 row-groups
+    else TY = (TY / (int)k) * (int)k;
   }
   int64_t gx = ceil_div(R, TY);
-  int64_t cap = 1024 / gy;
+  int64_t cap = (widek ? 1024 / TY : 1024) / gy;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
-  g->TX = TX; g->TY = TY; g->J = J; g->gx = (int)gx; g->gy = gy; g->k = (int)k;
+  if (widek) {                                   // the row stride gx*TY must keep every lane on one bias phase
+    int64_t a = k, b = TY;
+    while (b) { int64_t t = a % b; a = b; b = t; }
+    const int64_t mult = k / a;                  // k / gcd(k, TY)
+    gx = ceil_div(gx, mult) * mult;
+  }
+  g->TX = TX; g->TY = TY; g->J = J; g->gx = (int)gx; g->gy = gy; g->k = (int)k; g->widek = widek;
   g->nslot = TX >= 64 ? TX / 64 : 1;
   return 0;
 }
@@ -48,7 +55,7 @@ struct LsqArgs {
   float* rowpart;   // [R][gy*nslot]
   float* colpart;   // [gx][nacc][k*inner]
   int64_t R, S, inner, ldx, ldy;
-  int k, TX, TY, colmode, prologue, nacc;
+  int k, TX, TY, colmode, prologue, nacc, widek;
   float lo, hi, gscale;
 };
 
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int64_t w4 = a.inner / 4;
   const int64_t c4base = (int64_t)blockIdx.y * TX * J;
-  const int ph = (a.k > 1) ? (ty % a.k) : 0;
+  const int ph = (a.k > 1) ? (int)(((int64_t)blockIdx.x * TY + ty) % a.k) : 0;
   const bool active_row_group = ty < TY;
 
   // per-lane column state
@@ -173,9 +180,26 @@ __global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
   }
   if (!BWD) return;
 
+  const int nacc = a.nacc;
+  if (a.widek) {
+    // more phases than row-groups: every row-group writes its own partial, [gridDim.x*TY][nacc][inner]; the phase of
+    // row-group G is G % k, resolved by the second stage
+    if (active_row_group) {
+      float* dst = a.colpart + ((int64_t)blockIdx.x * TY + ty) * nacc * a.inner;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (!cok[j]) continue;
+        const int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
+        *reinterpret_cast<float4*>(dst + col) = make_float4(acc_b4[j][0], acc_b4[j][1], acc_b4[j][2], acc_b4[j][3]);
+        *reinterpret_cast<float4*>(dst + a.inner + col) = make_float4(acc_ba[j][0], acc_ba[j][1], acc_ba[j][2], acc_ba[j][3]);
+        if (nacc == 3)
+          *reinterpret_cast<float4*>(dst + 2 * a.inner + col) = make_float4(acc_ds[j][0], acc_ds[j][1], acc_ds[j][2], acc_ds[j][3]);
+      }
+    }
+    return;
+  }
   // ---- column partials: one LDS pass per workgroup, reduced over the row-groups of equal phase ----
   const int ncol = TX * J * 4;                 // columns of this column tile (incl. masked ones)
-  const int nacc = a.nacc;
   float* base = red + ((size_t)ty * nacc) * ncol;
   if (active_row_group) {
 #pragma unroll
@@ -243,7 +267,7 @@ extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, cons
 static void lsq_ws_layout(const LsqGeom& g, int64_t R, int64_t inner, int nacc, size_t* row_floats,
                           size_t* col_floats) {
   *row_floats = (size_t)R * g.gy * g.nslot;
-  *col_floats = (size_t)g.gx * nacc * g.k * inner;
+  *col_floats = g.widek ? (size_t)g.gx * g.TY * nacc * inner : (size_t)g.gx * nacc * g.k * inner;
 }
 
 extern "C" size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, int64_t bias_len, int scale_mode) {
@@ -272,7 +296,7 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
   a.x = x; a.g = gy; a.s = s; a.b4 = b4; a.dx = dx;
   a.rowpart = (float*)ws; a.colpart = (float*)ws + rf;
   a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
-  a.colmode = scale_mode; a.prologue = prologue; a.nacc = nacc;
+  a.colmode = scale_mode; a.prologue = prologue; a.nacc = nacc; a.widek = g.widek;
   a.lo = (float)lo; a.hi = (float)hi; a.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;
   rc = lsq_launch<true>(g, a, st);
@@ -280,13 +304,25 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
   const int64_t blen = (int64_t)g.k * inner;
   SumJobs jobs = {};
   int64_t maxc = 0;
-  if (ds) {
-    if (scale_mode) jobs.j[0] = {a.colpart + 2 * blen, ds, inner, g.gx, (int64_t)nacc * blen, 1, gscale};
-    else jobs.j[0] = {a.rowpart, ds, S, outer, S * (int64_t)g.gy * g.nslot, g.gy * g.nslot, gscale};
-    maxc = jobs.j[0].ncols;
+  if (g.widek) {
+    // partial row-groups [G][nacc][inner], G = gx*TY, phase(G) = G % k: view as [G/k][k][nacc][inner]
+    const int64_t G = (int64_t)g.gx * g.TY, rs = (int64_t)g.k * nacc * inner, cm = (int64_t)nacc * inner;
+    if (ds) {
+      if (scale_mode) return OFQ_EINVAL;
+      jobs.j[0] = {a.rowpart, ds, S, outer, S * (int64_t)g.gy * g.nslot, g.gy * g.nslot, gscale, 0, 0};
+      maxc = S;
+    }
+    if (db4) { jobs.j[1] = {a.colpart, db4, blen, G / g.k, rs, 1, 1.0f, inner, cm}; if (blen > maxc) maxc = blen; }
+    if (dbaft) { jobs.j[2] = {a.colpart + inner, dbaft, blen, G / g.k, rs, 1, 1.0f, inner, cm}; if (blen > maxc) maxc = blen; }
+  } else {
+    if (ds) {
+      if (scale_mode) jobs.j[0] = {a.colpart + 2 * blen, ds, inner, g.gx, (int64_t)nacc * blen, 1, gscale, 0, 0};
+      else jobs.j[0] = {a.rowpart, ds, S, outer, S * (int64_t)g.gy * g.nslot, g.gy * g.nslot, gscale, 0, 0};
+      maxc = jobs.j[0].ncols;
+    }
+    if (db4) { jobs.j[1] = {a.colpart, db4, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f, 0, 0}; if (blen > maxc) maxc = blen; }
+    if (dbaft) { jobs.j[2] = {a.colpart + blen, dbaft, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f, 0, 0}; if (blen > maxc) maxc = blen; }
   }
-  if (db4) { jobs.j[1] = {a.colpart, db4, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f}; if (blen > maxc) maxc = blen; }
-  if (dbaft) { jobs.j[2] = {a.colpart + blen, dbaft, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f}; if (blen > maxc) maxc = blen; }
   if (maxc > 0) {
     hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(maxc, 16), 3), dim3(256), 0, st, jobs);
     OFQ_LAUNCH_CHECK();

@@ -125,6 +125,8 @@ def _oracle_lsq_sandwich(x, s, b4, baft, mode, bits, unsigned, gelu, H=1):
     dict(B=2, N=198, C=576, H=3, mode="token", bits=4, unsigned=False, gelu=False),
     dict(B=2, N=198, C=768, H=1, mode="token", bits=3, unsigned=True, gelu=True),
     dict(B=3, N=50, C=24, H=1, mode="channel", bits=3, unsigned=False, gelu=False),
+    dict(B=3, N=49, C=4608, H=12, mode="token", bits=3, unsigned=False, gelu=False),     # Swin stage 3 qkx: 12 phases > 8 row-groups
+    dict(B=2, N=49, C=18432, H=24, mode="token", bits=3, unsigned=False, gelu=False),    # Swin stage 4 qkx
 ])
 def test_lsq_sandwich_vs_oracle(ops, case):
     B, N, C, H = case["B"], case["N"], case["C"], case["H"]
