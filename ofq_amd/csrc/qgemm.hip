@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
 // lane p supplies the 8-byte chunk (row k0 + p/4, cols t0 + 4*(p%4) .. +3) and receives column t0 + p, rows k0..k0+3.
 // LDS rows are padded to 320 B so the two 16-lane groups of a half-wave (4 rows x 32 B each) hit disjoint banks.
 // Split-K over the token dimension; partials are reduced in a fixed order together with the rank-1 offset term.
+#include <type_traits>
 #define QTN_BK 32
 #define QTN_LD 320                      // bytes per LDS row: 128 bf16 + 64 B pad
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -618,6 +619,272 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   }
 }
 
+// Wide variant for the linear layers (split-K mode only): 8 waves own a 128 x (128*NJ) tile, so one split of a dY
+// panel feeds NJ times more MFMA work.  tools/probe/overlap_probe.hip shows that on gfx950 the VALU stream of one wave
+// does NOT overlap the MFMA stream of its SIMD partner (233 us together vs 103 + 135 us alone), so every split/convert
+// instruction is paid in full: the lever is fewer VALU instructions per MFMA, which the wide tile gives.  LDS is
+// double buffered with ONE barrier per k-step (LDS-only barrier: global prefetches stay in flight across it).
+// workgroup barrier that orders LDS traffic only: global prefetch loads stay in flight across it (__syncthreads would
+// drain vmcnt and expose the HBM latency once per k-step)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag_ld(const unsigned char* base) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * LD));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+#ifdef TNW_TIMING
+__device__ unsigned long long g_tnw_dbg[8][8];     // [wave][phase] cycles of block 0 (tools/probe/tn_probe.hip)
+#define TNW_T(slot) do { const unsigned long long t_ = clock64(); tacc[slot] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TNW_T(slot) do {} while (0)
+#endif
+
+template <int NJ>
+__global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
+  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int LDA = QTN_LD;                 // 320 B: 4 consecutive k rows land on disjoint 64-B bank slots
+  constexpr int LDB = BN * 2 + 64;            // same residue (64) modulo the 256-B bank line
+  constexpr int PLANE = QTN_BK * LDA;
+  constexpr int STAGE = NS * PLANE + QTN_BK * LDB;
+  constexpr int CPR = BN / 8;                 // 8-byte code chunks per k row
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int lid = blockIdx.x;
+  {
+    const int total = gridDim.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = lid & 7, loc = lid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile = lid % ntiles, sidx = lid / ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
+  const int tps = (nkt + p.split - 1) / p.split;
+  const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
+
+  const int a_k = tid >> 5, a_t = (tid & 31) * 4;          // rows a_k, a_k + 16
+  const bool a_ok = (m0 + a_t) < p.M;
+  const float* Ap = p.A + (a_ok ? m0 + a_t : 0);
+  int b_row[NJ], b_col[NJ];
+  bool b_ok[NJ];
+  const int8_t* Bp[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int f = tid + 512 * i;
+    b_row[i] = f / CPR;
+    b_col[i] = (f % CPR) * 8;
+    b_ok[i] = (n0 + b_col[i]) < p.N;                       // N % 8 == 0 (host check)
+    Bp[i] = p.B + (b_ok[i] ? n0 + b_col[i] : 0);
+  }
+  // two register prefetch slots: the loads of k-step t are issued two steps before their LDS store (the ~2 us HBM
+  // latency is longer than one k-step)
+  float4 ra[2][2];
+  float rs[2][2];
+  bool rok[2][2], rbok[2][NJ];
+  uint2 rb[2][NJ];
+  float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_csum = p.csum != nullptr && tn == 0;
+  // all element offsets fit 32 bits (host check); loads are unconditional on clamped rows, masking happens at the
+  // LDS store so nothing waits on a load inside gload
+  const int ldA = (int)p.lda, ldB = (int)p.ldb;
+  int kmod[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) kmod[i] = (t_begin * QTN_BK + a_k + 16 * i) % p.S;
+#ifdef TNW_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = clock64();
+  const unsigned long long tstart = tlast;
+#endif
+  auto gload = [&](int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const int k0 = kt * QTN_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + a_k + 16 * i;
+      const int kc = min(k, p.Ktok - 1);
+      rok[sl][i] = a_ok && k < p.Ktok;
+      ra[sl][i] = *reinterpret_cast<const float4*>(Ap + (unsigned)(kc * ldA));
+      rs[sl][i] = p.s[kmod[i]];
+      kmod[i] += QTN_BK;                                   // gload runs on consecutive k-steps: k mod S incrementally
+      kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;               // S >= QTN_BK (host check)
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int k = k0 + b_row[i];
+      rbok[sl][i] = b_ok[i] && k < p.Ktok;
+      rb[sl][i] = *reinterpret_cast<const uint2*>(Bp[i] + (unsigned)(min(k, p.Ktok - 1) * ldB));
+    }
+  };
+  auto lstore = [&](unsigned char* sb, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+#ifdef TNW_TIMING
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    TNW_T(4);
+#endif
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float sc = ofq_lsq_eff_scale(rs[sl][i], p.gscale);
+      const unsigned msk = rok[sl][i] ? 0xffffffffu : 0u;
+      float4 v;
+      v.x = __uint_as_float(__float_as_uint(ra[sl][i].x) & msk);
+      v.y = __uint_as_float(__float_as_uint(ra[sl][i].y) & msk);
+      v.z = __uint_as_float(__float_as_uint(ra[sl][i].z) & msk);
+      v.w = __uint_as_float(__float_as_uint(ra[sl][i].w) & msk);
+      csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
+      float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+      float pc[NS][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rem = x[e];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float h = trunc_bf16(rem);
+          pc[q][e] = h;
+          rem = __fsub_rn(rem, h);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 w;
+        w.x = pack_hi16(pc[q][0], pc[q][1]);
+        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        *reinterpret_cast<uint2*>(&sb[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+      }
+    }
+#ifdef TNW_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TNW_T(5);
+#endif
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const unsigned bm = rbok[sl][i] ? 0xffffffffu : 0u;
+      const int w0 = (int)(rb[sl][i].x & bm), w1 = (int)(rb[sl][i].y & bm);
+      uint4 w;
+      w.x = i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
+      w.y = i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
+      w.z = i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
+      w.w = i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
+      *reinterpret_cast<uint4*>(&sb[NS * PLANE + b_row[i] * LDB + b_col[i] * 2]) = w;
+    }
+  };
+
+  f32x16q acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int p16 = lane & 15;
+  const int fr_a = (8 * lh + (p16 >> 2)) * LDA + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  const int fr_b = (8 * lh + (p16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  // all fragments of a k-step (both 16-deep MFMA steps) are requested before the first MFMA, so the LDS latency is paid
+  // once per k-step instead of once per plane; the scheduling barrier keeps the compiler from sinking the reads back
+  auto compute = [&](const unsigned char* sb) {
+    bf16x8 av[QTN_BK / 16][NS][2], bv[QTN_BK / 16][NJ];
+#pragma unroll
+    for (int ks = 0; ks < QTN_BK / 16; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bv[ks][j] = tr_frag_ld<LDB>(&sb[NS * PLANE + ks * 16 * LDB + fr_b + (wn * 32 * NJ + j * 32) * 2]);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          av[ks][q][i] = tr_frag_ld<LDA>(&sb[q * PLANE + ks * 16 * LDA + fr_a + (wm * 64 + i * 32) * 2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < QTN_BK / 16; ++ks)
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  // one k-step: MFMA on `cur` (tile kt) and staging of tile kt+1 (register slot (kt+1)&1 -> `nxt`), then the loads of
+  // tile kt+3 into the freed slot
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    compute(cur);
+    TNW_T(0);
+    if (kt + 1 < t_end) {
+      lstore(nxt, SLOT);
+      TNW_T(1);
+      if (kt + 3 < t_end) gload(kt + 3, SLOT);
+      TNW_T(2);
+    }
+    lds_barrier();
+    TNW_T(3);
+  };
+
+  if (t_begin < t_end) {
+    gload(t_begin, Slot0());
+    if (t_begin + 1 < t_end) gload(t_begin + 1, Slot1());
+    lstore(smem, Slot0());
+    if (t_begin + 2 < t_end) gload(t_begin + 2, Slot0());
+    lds_barrier();
+    for (int kt = t_begin; kt < t_end; kt += 2) {
+      step(kt, smem, smem + STAGE, Slot1());                               // tile kt+1 lives in slot 1
+      if (kt + 1 < t_end) step(kt + 1, smem + STAGE, smem, Slot0());       // tile kt+2 in slot 0
+    }
+  }
+#ifdef TNW_TIMING
+  if (blockIdx.x == 0 && lane == 0) {
+    for (int q = 0; q < 6; ++q) g_tnw_dbg[wid][q] = tacc[q];
+    g_tnw_dbg[wid][6] = clock64() - tstart;
+    g_tnw_dbg[wid][7] = t_end - t_begin;
+  }
+#endif
+  float* W = p.ws + (int64_t)sidx * p.M * p.N;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
+      }
+  }
+  if (do_csum) {     // reduce the 16 row-groups that share a column quad, one writer per quad
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[a_k * 32 + (tid & 31)] = csacc;
+    __syncthreads();
+    if (a_k == 0) {
+      float4 t = red[tid & 31];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) {
+        const float4 u = red[g * 32 + (tid & 31)];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+    }
+  }
+}
+
 // db[o] = sum_s csum[s][o]
 __global__ __launch_bounds__(256) void qgemm_tn_db_kernel(const float* __restrict__ csum, float* __restrict__ db, int M, int split) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,7 +925,13 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   if (compute_db && !db) return OFQ_EINVAL;
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
+  static const bool narrow_only = getenv("OFQ_TN_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
+  if (N % 384 == 0 && !narrow_only && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {          // wide tile: one dY split feeds three 128-column blocks
+    a.tiles_n = (int)(N / 384);
+    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
+  }
   OFQ_LAUNCH_CHECK();
   if (compute_db) {
     hipLaunchKernelGGL(qgemm_tn_db_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, st, (const float*)a.csum, db, (int)M,
@@ -892,6 +1165,180 @@ extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const
   return 0;
 }
 
+// Wide input-gradient kernel for the linear layers: 8 waves own a 128 x (128*NJ) tile of dX, so a row panel of dY is
+// scaled and split into its three bf16 planes once per NJ column blocks (once in total when N <= 384, the qkv / fc1 /
+// proj case) instead of once per 128 columns.  Same pipeline as the wide dW kernel: double-buffered LDS, one LDS-only
+// barrier per k-step, two register prefetch slots.
+template <int NJ>
+__global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int PLANE = BM * QBS_LD;
+  constexpr int STAGE = NS * PLANE + BN * QBS_LD;
+  constexpr int NB = NJ;                               // 16-byte chunks of the weight tile per thread (BN*4/512)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  int tm, tn;
+  qgemm_tile_id(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* A = (const float*)p.A;
+  const unsigned short* B = (const unsigned short*)p.B;
+  const int K = p.K;
+  const int nkt = (K + QBS_BK - 1) / QBS_BK;
+
+  // A: 128 rows x 32 fp32 = 1024 float4 -> 2 per thread (row = f >> 3);  B: BN rows x 32 bf16 -> NJ x 16 B per thread
+  const float* pa[2];
+  bool okA[2];
+  const unsigned short* pb[NB];
+  bool okB[NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid + 512 * i) >> 3;
+    okA[i] = (m0 + row) < p.M;
+#ifdef NTW_SAME_ROWS
+    pa[i] = A + (int64_t)row * p.lda + (tid & 7) * 4;         // experiment: every workgroup reads rows 0..127 (L2 hits)
+#else
+    pa[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + (tid & 7) * 4;
+#endif
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (tid + 512 * i) >> 2;
+    okB[i] = (n0 + row) < p.N;
+    pb[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + (tid & 3) * 8;
+  }
+  const int kqa = (tid & 7) * 4, kqb = (tid & 3) * 8;
+  float4 ra[2][2], rks[2];
+  i32x4 rb[NB];                                         // weights are L2-resident: one step of prefetch is enough
+  bool rka[2], rkb;
+  auto gload = [&](int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const int k0 = kt * QBS_BK;
+    rka[sl] = (k0 + kqa) < K;                           // K % 8 == 0 (host check): chunks are all-in or all-out
+    const int ka = rka[sl] ? k0 : 0;
+    rks[sl] = p.s ? *reinterpret_cast<const float4*>(p.s + ka + kqa) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[sl][i] = *reinterpret_cast<const float4*>(pa[i] + ka);
+  };
+  auto gload_b = [&](int kt) {
+    const int k0 = kt * QBS_BK;
+    rkb = (k0 + kqb) < K;
+    const int kb = rkb ? k0 : 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const i32x4*>(pb[i] + kb);
+  };
+  auto lstore = [&](unsigned char* sb, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    float4 ks = rks[sl];
+    if (!rka[sl]) ks = make_float4(0.f, 0.f, 0.f, 0.f);      // beyond K: zero pieces (register select, the loads are done)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid + 512 * i) >> 3;
+      const float z = okA[i] ? 1.f : 0.f;
+      float x[4] = {ra[sl][i].x * (ks.x * z), ra[sl][i].y * (ks.y * z), ra[sl][i].z * (ks.z * z), ra[sl][i].w * (ks.w * z)};
+      float pc[NS][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rem = x[e];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float h = trunc_bf16(rem);
+          pc[q][e] = h;
+          rem = __fsub_rn(rem, h);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 w;
+        w.x = pack_hi16(pc[q][0], pc[q][1]);
+        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        *reinterpret_cast<uint2*>(&sb[q * PLANE + row * QBS_LD + kqa * 2]) = w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = (tid + 512 * i) >> 2;
+      const int m = (okB[i] && rkb) ? -1 : 0;
+      *reinterpret_cast<i32x4*>(&sb[NS * PLANE + row * QBS_LD + kqb * 2]) = rb[i] & m;
+    }
+  };
+
+  f32x16q acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](const unsigned char* sb) {
+    const unsigned char* a = &sb[(wm * 64 + l31) * QBS_LD + lh * 16];
+    const unsigned char* b = &sb[NS * PLANE + (wn * 32 * NJ + l31) * QBS_LD + lh * 16];
+    bf16x8 av[QBS_BK / 16][NS][2], bv[QBS_BK / 16][NJ];
+#pragma unroll
+    for (int ks = 0; ks < QBS_BK / 16; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[ks][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD + ks * 32);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          av[ks][q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + ks * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < QBS_BK / 16; ++ks)
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    if (kt + 1 < nkt) gload_b(kt + 1);
+    compute(cur);
+    if (kt + 1 < nkt) {
+      lstore(nxt, SLOT);
+      if (kt + 3 < nkt) gload(kt + 3, SLOT);
+    }
+    lds_barrier();
+  };
+  gload(0, Slot0());
+  gload_b(0);
+  if (1 < nkt) gload(1, Slot1());
+  lstore(smem, Slot0());
+  if (2 < nkt) gload(2, Slot0());
+  lds_barrier();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, smem, smem + STAGE, Slot1());
+    if (kt + 1 < nkt) step(kt + 1, smem + STAGE, smem, Slot0());
+  }
+
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.M) {
+          float* dst = p.C + (int64_t)m * p.ldc + n;
+          float v = acc[i][j][e] * p.alpha;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+  }
+}
+
 extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha,
                                   int accumulate, int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                   int64_t ldc, ofq_stream_t stream) {
@@ -903,6 +1350,16 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
+  static const bool narrow_only = getenv("OFQ_NT_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
+  if (nsplit == 3 && N > 128 && !narrow_only) {      // wide tiles: the dY panel is split once per 384 (256) columns
+    const int nj = N > 256 ? 3 : 2;
+    a.tiles_n = (int)ceil_div(N, 128 * nj);
+    dim3 gridw((unsigned)(a.tiles_m * a.tiles_n));
+    if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    OFQ_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);

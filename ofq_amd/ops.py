@@ -303,8 +303,12 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     Ktok, M = dy2d.shape
     N = xcodes2d.shape[1]
     if split is None:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        split = max(1, min(512 // tiles, (Ktok + 31) // 32 // 4))
+        if N % 384 == 0:       # wide 128x384 tiles, one 512-thread workgroup per CU
+            tiles = ((M + 127) // 128) * (N // 384)
+            split = max(1, min(256 // tiles, (Ktok + 31) // 32 // 4))
+        else:
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            split = max(1, min(512 // tiles, (Ktok + 31) // 32 // 4))
     dW = torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
     if compute_db:
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)

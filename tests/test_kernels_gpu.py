@@ -360,7 +360,8 @@ def test_qgemm_i8_forward_is_exact(ops, mnk):
     assert rel_err(y.cpu(), y2.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("mnk", [(396, 384, 384), (792, 384, 1536), (200, 1536, 384), (130, 72, 40), (256, 384, 2304)])
+@pytest.mark.parametrize("mnk", [(396, 384, 384), (792, 384, 1536), (200, 1536, 384), (130, 72, 40), (256, 384, 2304),
+                                 (333, 192, 776), (150, 768, 96), (129, 200, 24)])
 @pytest.mark.parametrize("nsplit", [3, 2])
 def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     M, N, K = mnk
