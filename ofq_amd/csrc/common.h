@@ -68,20 +68,32 @@ __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { retur
 struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; int64_t col_div, col_mul; };
 struct SumJobs { SumJob j[3]; };
 
-__global__ __launch_bounds__(256) void strided_sum_kernel(SumJobs jobs) {
+// 1024 threads = 64 columns (one 256-B line per row) x 16 row lanes, four independent accumulators per lane: the
+// partials are few hundred rows deep, so the kernel is a chain of dependent L2 round trips unless many are in flight.
+#define OFQ_SUM_COLS 64
+__global__ __launch_bounds__(1024) void strided_sum_kernel(SumJobs jobs) {
   const SumJob jb = jobs.j[blockIdx.y];
-  __shared__ float part[16][17];
-  const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
-  const int64_t c = (int64_t)blockIdx.x * 16 + cx;
-  float acc = 0.f;
+  __shared__ float part[16][OFQ_SUM_COLS + 1];
+  const int cx = threadIdx.x & (OFQ_SUM_COLS - 1), py = threadIdx.x / OFQ_SUM_COLS;
+  const int64_t c = (int64_t)blockIdx.x * OFQ_SUM_COLS + cx;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (jb.dst && c < jb.ncols) {
-    for (int64_t r = py; r < jb.nrows; r += 16) {
-      const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
-      const float* p = jb.src + r * jb.row_stride + co;
-      for (int t = 0; t < jb.cnt; ++t) acc += p[t];
+    const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
+    const float* base = jb.src + co;
+    int64_t r = py;
+    for (; r + 48 < jb.nrows; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = base + (r + 16 * u) * jb.row_stride;
+        for (int t = 0; t < jb.cnt; ++t) acc[u] += p[t];
+      }
+    }
+    for (; r < jb.nrows; r += 16) {
+      const float* p = base + r * jb.row_stride;
+      for (int t = 0; t < jb.cnt; ++t) acc[0] += p[t];
     }
   }
-  part[py][cx] = acc;
+  part[py][cx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
   if (py == 0 && jb.dst && c < jb.ncols) {
     float s = 0.f;

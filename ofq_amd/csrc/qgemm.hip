@@ -885,26 +885,42 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   }
 }
 
-// db[o] = sum_s csum[s][o]
-__global__ __launch_bounds__(256) void qgemm_tn_db_kernel(const float* __restrict__ csum, float* __restrict__ db, int M, int split) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= M) return;
-  float acc = 0.f;
-  for (int s = 0; s < split; ++s) acc += csum[(int64_t)s * M + o];
-  db[o] = acc;
-}
-
-// dW[o][c] = sum_s ws[s][o][c] + db[o] * baft[c]
+// one block per output row o:  db[o] = sum_s csum[s][o] (when the GEMM produced column sums), then
+// dW[o][c] = sum_s ws[s][o][c] + db[o] * baft[c]  -- fixed order, four partial sums in flight per thread
 __global__ __launch_bounds__(256) void qgemm_tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
-                                                              const float* __restrict__ db, const float* __restrict__ baft,
-                                                              int M, int N, int split) {
+                                                              const float* __restrict__ csum, float* __restrict__ db,
+                                                              const float* __restrict__ baft, int M, int N, int split) {
+  __shared__ float dbs;
+  const int o = blockIdx.x;
   const int64_t MN = (int64_t)M * N;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= MN) return;
-  float acc = 0.f;
-  for (int s = 0; s < split; ++s) acc += ws[(int64_t)s * MN + i];
-  if (db && baft) acc += db[i / N] * baft[i % N];
-  C[i] = acc;
+  if (threadIdx.x < 64) {
+    float v = 0.f;
+    if (csum) {
+      for (int s = threadIdx.x; s < split; s += 64) v += csum[(int64_t)s * M + o];
+      v = ofq_wave_sum(v);
+      if (threadIdx.x == 0) db[o] = v;
+    } else if (db) {
+      v = db[o];
+    }
+    if (threadIdx.x == 0) dbs = v;
+  }
+  __syncthreads();
+  const float dbo = dbs;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float* p = ws + (int64_t)o * N + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < split; s += 4) {
+      a0 += p[(int64_t)s * MN];
+      a1 += p[(int64_t)(s + 1) * MN];
+      a2 += p[(int64_t)(s + 2) * MN];
+      a3 += p[(int64_t)(s + 3) * MN];
+    }
+    for (; s < split; ++s) a0 += p[(int64_t)s * MN];
+    float acc = (a0 + a1) + (a2 + a3);
+    if (baft && (db || csum)) acc += dbo * baft[c];
+    C[(int64_t)o * N + c] = acc;
+  }
 }
 
 extern "C" size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split) {
@@ -933,13 +949,8 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
     hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   }
   OFQ_LAUNCH_CHECK();
-  if (compute_db) {
-    hipLaunchKernelGGL(qgemm_tn_db_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, st, (const float*)a.csum, db, (int)M,
-                       split);
-    OFQ_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, (const float*)ws, dW, db,
-                     baft, (int)M, (int)N, split);
+  hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, (const float*)ws, dW,
+                     compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -351,10 +351,13 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
         ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
         ctx.link = link
         ctx.mark_non_differentiable(codes, rsum)
+        ctx.set_materialize_grads(False)          # no zero-filled "gradients" for the code outputs
         return y, codes, rsum
 
     @staticmethod
     def backward(ctx, g, _gc, _gr):
+        if g is None:
+            return None, None, None, None, None, None, None
         prob, s = ctx.saved_tensors
         rows, N, Np, alpha, hi, M = ctx.meta
         g = g.contiguous()

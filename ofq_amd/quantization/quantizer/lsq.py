@@ -34,10 +34,13 @@ class _LsqFn(torch.autograd.Function):
         if codes is None:
             codes = torch.empty(0, dtype=torch.int8, device=x.device)
         ctx.mark_non_differentiable(codes)
+        ctx.set_materialize_grads(False)          # no zero-filled int8 "gradient" for the codes output
         return y, codes
 
     @staticmethod
     def backward(ctx, gy, _gcodes):
+        if gy is None:
+            return None, None, None, None, None, None, None
         x, s, b4 = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
