@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libofq_hip.so")
+LIB_PATH = os.environ.get("OFQ_HIP_LIB") or os.path.join(_HERE, "lib", "libofq_hip.so")   # override: kernel experiments only
 
 i64, i32, f32, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
 

@@ -14,7 +14,11 @@
 
 // fp32 ops that must keep the reference's rounding sequence are written with the _rn intrinsics so
 // that no fma contraction can merge them (the library is also built with -ffp-contract=off).
+#ifdef OFQ_EXPERIMENT_APPROX_DIV      // tools/probe only: is the kernel bound by the IEEE division sequence?
+__device__ __forceinline__ float ofq_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 __device__ __forceinline__ float ofq_div(float a, float b) { return __fdiv_rn(a, b); }
+#endif
 
 // Effective LSQ scale value: clip(s,1e-5) then grad_scale():  (a - a*g) + a*g   (lsq.py:6-18, :593)
 __device__ __forceinline__ float ofq_lsq_eff_scale(float s, float g) {

@@ -15,11 +15,15 @@ struct LsqGeom {
   int TX, TY, J, gx, gy, k, nslot, widek;   // widek: more bias phases than row-groups per workgroup
 };
 
-static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g) {
+static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g, bool bwd = false) {
   if (inner <= 0 || (inner & 3) || R <= 0) return OFQ_EINVAL;
   int64_t k = (bias_len > 0) ? bias_len / inner : 1;
   if (bias_len > 0 && k * inner != bias_len) return OFQ_EINVAL;
   int64_t w4 = inner / 4;
+  // backward keeps three accumulator sets per float4 column: at more than two float4 per lane the kernel drops to two
+  // waves per SIMD and loses the loads in flight it needs (tools/lsq_bench.py: 58 -> 38 us on 25216 x 384)
+  static const int maxj_env = getenv("OFQ_LSQ_MAXJ") ? atoi(getenv("OFQ_LSQ_MAXJ")) : 0;      // experiment knob
+  const int maxj = maxj_env ? maxj_env : (bwd ? 2 : 4);
   int TX = 16;
   while (TX < 256 && ceil_div(w4, TX) > 4) TX <<= 1;
   int J = (int)ceil_div(w4, TX);
@@ -27,6 +31,16 @@ static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g) {
   if (J > 4) {  // very wide rows (the 224x224 image planes): tile the columns
     J = 4;
     gy = (int)ceil_div(w4, (int64_t)TX * J);
+  }
+  if (J > maxj) {
+    // fewer float4 per lane: the largest power-of-two lane count (<= 128) that tiles the row exactly, columns tiled by gy
+    int tx = 128;
+    while (tx > 16 && (w4 % tx)) tx >>= 1;
+    if (w4 % tx == 0) {
+      TX = tx;
+      J = maxj;
+      gy = (int)ceil_div(w4, (int64_t)TX * J);
+    }
   }
   int TY = 256 / TX;
   int widek = 0;
@@ -59,8 +73,11 @@ struct LsqArgs {
   float lo, hi, gscale;
 };
 
+#ifndef LSQ_WAVES_PER_EU
+#define LSQ_WAVES_PER_EU
+#endif
 template <int J, bool BWD>
-__global__ __launch_bounds__(256) void lsq_kernel(LsqArgs a) {
+__global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int TX = a.TX, TY = a.TY;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -272,7 +289,7 @@ static void lsq_ws_layout(const LsqGeom& g, int64_t R, int64_t inner, int nacc, 
 
 extern "C" size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, int64_t bias_len, int scale_mode) {
   LsqGeom g;
-  if (lsq_geom(outer * S, inner, bias_len, &g)) return 0;
+  if (lsq_geom(outer * S, inner, bias_len, &g, true)) return 0;
   size_t rf, cf;
   lsq_ws_layout(g, outer * S, inner, scale_mode ? 3 : 2, &rf, &cf);
   return (rf + cf) * sizeof(float) + 256;
@@ -286,7 +303,7 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
   if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
   if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
   LsqGeom g;
-  int rc = lsq_geom(outer * S, inner, bias_len, &g);
+  int rc = lsq_geom(outer * S, inner, bias_len, &g, true);
   if (rc) return rc;
   const int nacc = scale_mode ? 3 : 2;
   size_t rf, cf;

@@ -676,9 +676,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   const int tps = (nkt + p.split - 1) / p.split;
   const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
 
+  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const bool direct = p.C != nullptr;                       // batched, un-split: C written here (attention dqkx)
   const int a_k = tid >> 5, a_t = (tid & 31) * 4;          // rows a_k, a_k + 16
   const bool a_ok = (m0 + a_t) < p.M;
-  const float* Ap = p.A + (a_ok ? m0 + a_t : 0);
+  const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1 + (a_ok ? m0 + a_t : 0);
   int b_row[NJ], b_col[NJ];
   bool b_ok[NJ];
   const int8_t* Bp[NJ];
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     b_row[i] = f / CPR;
     b_col[i] = (f % CPR) * 8;
     b_ok[i] = (n0 + b_col[i]) < p.N;                       // N % 8 == 0 (host check)
-    Bp[i] = p.B + (b_ok[i] ? n0 + b_col[i] : 0);
+    Bp[i] = p.B + b0 * p.sB0 + b1 * p.sB1 + (b_ok[i] ? n0 + b_col[i] : 0);
   }
   // two register prefetch slots: the loads of k-step t are issued two steps before their LDS store (the ~2 us HBM
   // latency is longer than one k-step)
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   bool rok[2][2], rbok[2][NJ];
   uint2 rb[2][NJ];
   float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool do_csum = p.csum != nullptr && tn == 0;
+  const bool do_csum = direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0);
   // all element offsets fit 32 bits (host check); loads are unconditional on clamped rows, masking happens at the
   // LDS store so nothing waits on a load inside gload
   const int ldA = (int)p.lda, ldB = (int)p.ldb;
@@ -856,19 +858,22 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     g_tnw_dbg[wid][7] = t_end - t_begin;
   }
 #endif
-  float* W = p.ws + (int64_t)sidx * p.M * p.N;
+  if (!direct) {
+    float* W = p.ws + (int64_t)sidx * p.M * p.N;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n0 + wn * 32 * NJ + j * 32 + l31;
-    if (n >= p.N) continue;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+      if (n >= p.N) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
+        }
+    }
   }
+  float* red1 = reinterpret_cast<float*>(smem) + 16 * 32 * 4;     // 128 finished column sums behind the partials
   if (do_csum) {     // reduce the 16 row-groups that share a column quad, one writer per quad
     float4* red = reinterpret_cast<float4*>(smem);
     red[a_k * 32 + (tid & 31)] = csacc;
@@ -880,7 +885,33 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
         const float4 u = red[g * 32 + (tid & 31)];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+      if (!direct) {
+        if (a_ok) *reinterpret_cast<float4*>(p.csum + (int64_t)sidx * p.M + m0 + a_t) = t;
+      } else {
+        *reinterpret_cast<float4*>(red1 + a_t) = t;
+      }
+    }
+    __syncthreads();
+  }
+  if (direct) {
+    float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+      if (n >= p.Nstore) continue;
+      const float bf = p.baft ? p.baft[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int m = m0 + ml;
+          if (m < p.Mstore) {
+            float v = acc[i][j][e];
+            if (p.baft) v += red1[ml] * bf;
+            Cb[(int64_t)m * p.ldc + n] = v;
+          }
+        }
     }
   }
 }
@@ -1527,6 +1558,14 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
   a.M = (int)ldS; a.N = (int)C; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
   a.Mstore = (int)N; a.Nstore = (int)C; a.trans_out = 0; a.gscale = gscale_x;
   a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(C, 128);
+  static const bool narrow_only = getenv("OFQ_TN_NARROW") != nullptr;
+  if (C % 384 == 0 && N >= QTN_BK && !narrow_only && N * ldS < (1ll << 31) && N * C < (1ll << 31)) {
+    a.tiles_n = (int)(C / 384);       // one split of a dS panel feeds all 384 columns
+    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(512), 0,
+                       (hipStream_t)stream, a);
+    OFQ_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
