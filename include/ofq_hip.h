@@ -169,6 +169,19 @@ size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols);
 int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* ws, size_t ws_bytes,
                ofq_stream_t stream);
 
+/* ---- LayerNorm over the channel dimension (deit_vision_transformer.py:91-102 Block.norm1/norm2 = nn.LayerNorm(dim,
+ *  eps 1e-6), :138 the final norm; swin: torchvision LayerNorm eps 1e-5), optionally fused with the residual add that
+ *  feeds it:  xsum = x + res (written when res != NULL),  y = (xsum - mean) * rstd * gamma + beta.  mean / rstd [rows]
+ *  are kept for the backward.  Backward: dx = rstd*(g - mean(g) - xh*mean(g*xh)) [+ dres], g = dy*gamma,
+ *  dgamma = sum_r dy*xh, dbeta = sum_r dy (fixed-order two-stage sums).  cols % 4 == 0, cols <= 2048. */
+int ofq_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xsum,
+                      float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps,
+                      ofq_stream_t stream);
+size_t ofq_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols);
+int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, int64_t ldx,
+                      int64_t ldy, void* ws, size_t ws_bytes, ofq_stream_t stream);
+
 /* ---- K16  CGA: freeze_outside_boundary_weight_idx cga.py:450-469 and the step hooks cga.py:962-964,
  *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */
 int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, int bits, float boundary_range,

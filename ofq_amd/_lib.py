@@ -52,6 +52,9 @@ SIGNATURES = {
     "ofq_codes_transpose_i8": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "ofq_colsum_ws_bytes": (sz, [i64, i64]),
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
+    "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp]),
+    "ofq_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
+    "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
     "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
     "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),

@@ -1,0 +1,257 @@
+// LayerNorm over the channel dimension of the token matrix (deit_vision_transformer.py: Block.norm1 / norm2, the final
+// norm; timm Block = x + attn(norm1(x)), x + mlp(norm2(x))), forward and backward, optionally fused with the residual
+// add that precedes it.  HBM-bound: forward 8 B/elt (12 with the add), backward 12 B/elt (16 with the residual
+// gradient) -- the stock three-kernel backward moves 32 B/elt.
+//
+//   fwd :  [xs = x + res]   mu = mean(xs), rstd = 1/sqrt(var(xs) + eps),   y = (xs - mu) * rstd * gamma + beta
+//   bwd :  xh = (xs - mu) * rstd, g = dy * gamma,
+//          dx = rstd * (g - mean(g) - xh * mean(g * xh))  [+ dres],   dgamma = sum_rows dy * xh,   dbeta = sum_rows dy
+//
+// One row is owned by TX lanes (32 or 64) holding J float4 each, so the two row reductions are DPP/shuffle only; a
+// workgroup walks rows with a one-row software prefetch; the column sums for dgamma/dbeta go through LDS once per
+// workgroup and a fixed-order second stage (strided_sum_kernel), like the LSQ offsets.
+#include "common.h"
+
+struct LnArgs {
+  const float* x; const float* res; const float* gamma; const float* beta;
+  float* y; float* xs; float* mean; float* rstd;
+  const float* dy; const float* dres; float* dx; float* colpart;      // colpart [gx][2][C]
+  int64_t R, C, ldx, ldy;
+  int TX, TY;
+  float eps;
+};
+
+template <int TXW>
+__device__ __forceinline__ float ln_row_sum(float v) {
+#pragma unroll
+  for (int o = TXW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int J, int TXW, bool BWD>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int TY = 256 / TXW;
+  const int tx = threadIdx.x % TXW, ty = threadIdx.x / TXW;
+  const int64_t w4 = a.C / 4;
+  const float invC = 1.0f / (float)a.C;
+  float4 gam[J], bet[J];
+  bool cok[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int64_t c4 = tx + (int64_t)j * TXW;
+    cok[j] = c4 < w4;
+    gam[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    bet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok[j]) {
+      if (a.gamma) gam[j] = *reinterpret_cast<const float4*>(a.gamma + c4 * 4);
+      if (!BWD && a.beta) bet[j] = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
+    }
+  }
+  float4 acc_g[J], acc_b[J];
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc_g[j] = acc_b[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t rstride = (int64_t)gridDim.x * TY;
+  int64_t r = (int64_t)blockIdx.x * TY + ty;
+  float4 xn[J], sn[J];          // x (and res / dy) of the next row
+  float4 dn[J];
+  auto issue = [&](int64_t rr) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (cok[j]) {
+        const int64_t col = (tx + (int64_t)j * TXW) * 4;
+        xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + col);
+        if (!BWD && a.res) sn[j] = *reinterpret_cast<const float4*>(a.res + rr * a.ldx + col);
+        if (BWD) {
+          sn[j] = *reinterpret_cast<const float4*>(a.dy + rr * a.ldy + col);
+          if (a.dres) dn[j] = *reinterpret_cast<const float4*>(a.dres + rr * a.ldx + col);
+        }
+      }
+    }
+  };
+  // forward: one-row software prefetch.  backward: no prefetch copy -- it holds three more accumulator/operand sets per
+  // column and the extra registers cost a wave per SIMD, which hides more latency than the prefetch does
+  if (!BWD && r < a.R) issue(r);
+  for (; r < a.R; r += rstride) {
+    if (BWD) issue(r);
+    float4 xv[J], sv[J], dv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      xv[j] = cok[j] ? xn[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      sv[j] = cok[j] ? sn[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD) dv[j] = cok[j] ? dn[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mu = 0.f, rs = 0.f;
+    if (BWD) { mu = a.mean[r]; rs = a.rstd[r]; }
+    if (!BWD && r + rstride < a.R) issue(r + rstride);
+    if (!BWD) {
+      if (a.res) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          xv[j].x += sv[j].x; xv[j].y += sv[j].y; xv[j].z += sv[j].z; xv[j].w += sv[j].w;
+        }
+      }
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) s1 += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+      mu = ln_row_sum<TXW>(s1) * invC;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (!cok[j]) continue;
+        const float d0 = xv[j].x - mu, d1 = xv[j].y - mu, d2 = xv[j].z - mu, d3 = xv[j].w - mu;
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      const float var = ln_row_sum<TXW>(s2) * invC;
+      rs = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (!cok[j]) continue;
+        const int64_t col = (tx + (int64_t)j * TXW) * 4;
+        float4 o;
+        o.x = (xv[j].x - mu) * rs * gam[j].x + bet[j].x;
+        o.y = (xv[j].y - mu) * rs * gam[j].y + bet[j].y;
+        o.z = (xv[j].z - mu) * rs * gam[j].z + bet[j].z;
+        o.w = (xv[j].w - mu) * rs * gam[j].w + bet[j].w;
+        *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
+        if (a.res) *reinterpret_cast<float4*>(a.xs + r * a.ldx + col) = xv[j];
+      }
+      if (tx == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
+    } else {
+      float4 xh[J], g[J];
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+        g[j] = make_float4(sv[j].x * gam[j].x, sv[j].y * gam[j].y, sv[j].z * gam[j].z, sv[j].w * gam[j].w);
+        if (!cok[j]) continue;
+        sa += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        sb += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+        acc_g[j].x += sv[j].x * xh[j].x; acc_g[j].y += sv[j].y * xh[j].y;
+        acc_g[j].z += sv[j].z * xh[j].z; acc_g[j].w += sv[j].w * xh[j].w;
+        acc_b[j].x += sv[j].x; acc_b[j].y += sv[j].y; acc_b[j].z += sv[j].z; acc_b[j].w += sv[j].w;
+      }
+      const float ma = ln_row_sum<TXW>(sa) * invC, mb = ln_row_sum<TXW>(sb) * invC;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if (!cok[j]) continue;
+        const int64_t col = (tx + (int64_t)j * TXW) * 4;
+        float4 o;
+        o.x = rs * (g[j].x - ma - xh[j].x * mb);
+        o.y = rs * (g[j].y - ma - xh[j].y * mb);
+        o.z = rs * (g[j].z - ma - xh[j].z * mb);
+        o.w = rs * (g[j].w - ma - xh[j].w * mb);
+        if (a.dres) { o.x += dv[j].x; o.y += dv[j].y; o.z += dv[j].z; o.w += dv[j].w; }
+        *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = o;
+      }
+    }
+  }
+  if (!BWD) return;
+  // column partials: [TY][2][ncol] through LDS, summed over the row lanes in a fixed order
+  const int ncol = TXW * J * 4;
+  float* base = red + (size_t)ty * 2 * ncol;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = (tx + j * TXW) * 4;
+    base[c] = acc_g[j].x; base[c + 1] = acc_g[j].y; base[c + 2] = acc_g[j].z; base[c + 3] = acc_g[j].w;
+    base[ncol + c] = acc_b[j].x; base[ncol + c + 1] = acc_b[j].y; base[ncol + c + 2] = acc_b[j].z; base[ncol + c + 3] = acc_b[j].w;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * ncol; idx += 256) {
+    const int c = idx % ncol, ac = idx / ncol;
+    if (c >= a.C) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TY; ++t) s += red[((size_t)t * 2 + ac) * ncol + c];
+    a.colpart[((int64_t)blockIdx.x * 2 + ac) * a.C + c] = s;
+  }
+}
+
+struct LnGeom { int TX, J, gx; };
+
+static int ln_geom(int64_t R, int64_t C, LnGeom* g) {
+  if (R <= 0 || C <= 0 || (C & 3) || C > 2048) return OFQ_EINVAL;
+  const int64_t w4 = C / 4;
+  g->TX = w4 <= 128 ? 32 : 64;
+  g->J = (int)ceil_div(w4, g->TX);               // <= 4 (TX 32) or <= 8 (TX 64)
+  const int TY = 256 / g->TX;
+  int64_t gx = ceil_div(R, TY);
+  if (gx > 1024) gx = 1024;
+  g->gx = (int)gx;
+  return 0;
+}
+
+template <bool BWD>
+static int ln_launch(const LnGeom& g, const LnArgs& a, hipStream_t st) {
+  const size_t lds = BWD ? (size_t)(256 / g.TX) * 2 * g.TX * g.J * 4 * sizeof(float) : 0;
+  dim3 grid(g.gx), block(256);
+#define LN_CASE(JJ, TXW) hipLaunchKernelGGL((layernorm_kernel<JJ, TXW, BWD>), grid, block, lds, st, a); break
+  if (g.TX == 32) {
+    switch (g.J) {
+      case 1: LN_CASE(1, 32);
+      case 2: LN_CASE(2, 32);
+      case 3: LN_CASE(3, 32);
+      default: LN_CASE(4, 32);
+    }
+  } else {
+    switch (g.J) {
+      case 3: LN_CASE(3, 64);
+      case 4: LN_CASE(4, 64);
+      case 5: LN_CASE(5, 64);
+      case 6: LN_CASE(6, 64);
+      case 7: LN_CASE(7, 64);
+      default: LN_CASE(8, 64);
+    }
+  }
+#undef LN_CASE
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ofq_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                 float* xsum, float* mean, float* rstd, int64_t R, int64_t C, int64_t ldx, int64_t ldy,
+                                 float eps, ofq_stream_t stream) {
+  if (!x || !y || !mean || !rstd || (res && !xsum)) return OFQ_EINVAL;
+  if (ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
+  LnGeom g;
+  int rc = ln_geom(R, C, &g);
+  if (rc) return rc;
+  LnArgs a = {};
+  a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xs = xsum; a.mean = mean; a.rstd = rstd;
+  a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX; a.eps = eps;
+  return ln_launch<false>(g, a, (hipStream_t)stream);
+}
+
+extern "C" size_t ofq_layernorm_bwd_ws_bytes(int64_t R, int64_t C) {
+  LnGeom g;
+  if (ln_geom(R, C, &g)) return 0;
+  return (size_t)g.gx * 2 * C * sizeof(float);
+}
+
+extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, int64_t R, int64_t C,
+                                 int64_t ldx, int64_t ldy, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!dy || !x || !mean || !rstd || !dx || !ws) return OFQ_EINVAL;
+  if (ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
+  LnGeom g;
+  int rc = ln_geom(R, C, &g);
+  if (rc) return rc;
+  if (ws_bytes < ofq_layernorm_bwd_ws_bytes(R, C)) return OFQ_ENOWS;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dres = dres; a.dx = dx;
+  a.colpart = (float*)ws;
+  a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX;
+  hipStream_t st = (hipStream_t)stream;
+  rc = ln_launch<true>(g, a, st);
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    SumJobs jobs = {};
+    if (dgamma) jobs.j[0] = {a.colpart, dgamma, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
+    if (dbeta) jobs.j[1] = {a.colpart + C, dbeta, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
+    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(C, OFQ_SUM_COLS), 2), dim3(1024), 0, st, jobs);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -6,4 +6,5 @@ extern "C" int ofq_abi_version(void) { return OFQ_ABI_VERSION; }
 #include "softmax_lsq.hip"
 #include "gemm_f32.hip"
 #include "qgemm.hip"
+#include "layernorm.hip"
 #include "misc.hip"

@@ -76,7 +76,7 @@ struct LsqArgs {
 #ifndef LSQ_WAVES_PER_EU
 #define LSQ_WAVES_PER_EU
 #endif
-template <int J, bool BWD>
+template <int J, bool BWD, bool COLMODE, bool GELU>
 __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int TX = a.TX, TY = a.TY;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
       int64_t bo = (int64_t)ph * a.inner + c4 * 4;
       if (a.b4) b4v[j] = *reinterpret_cast<const float4*>(a.b4 + bo);
       if (!BWD && a.baft) bav[j] = *reinterpret_cast<const float4*>(a.baft + bo);
-      if (a.colmode) {
+      if (COLMODE) {
         float4 t = *reinterpret_cast<const float4*>(a.s + c4 * 4);
         sv[j] = make_float4(ofq_lsq_eff_scale(t.x, a.gscale), ofq_lsq_eff_scale(t.y, a.gscale),
                             ofq_lsq_eff_scale(t.z, a.gscale), ofq_lsq_eff_scale(t.w, a.gscale));
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
     if (r < a.R) issue(r);
     for (; r < a.R; r += rstride) {
       float arow = 1.f;
-      if (!a.colmode) arow = ofq_lsq_eff_scale(a.s[r % a.S], a.gscale);
+      if (!COLMODE) arow = ofq_lsq_eff_scale(a.s[r % a.S], a.gscale);
       float4 xv[J], gv[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
           signed char cd[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float xe = a.prologue == 1 ? ofq_gelu(xin[e]) : xin[e];
-            float al = a.colmode ? sc[e] : arow;
+            float xe = GELU ? ofq_gelu(xin[e]) : xin[e];
+            float al = COLMODE ? sc[e] : arow;
             float q, v;
             float yi = ofq_lsq_quant(__fadd_rn(xe, bb[e]), al, lo, hi, q, v);
             out[e] = __fadd_rn(__fmul_rn(yi, al), ba[e]);
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
           float dxo[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float xe = a.prologue == 1 ? ofq_gelu(xin[e]) : xin[e];
-            float al = a.colmode ? sc[e] : arow;
+            float xe = GELU ? ofq_gelu(xin[e]) : xin[e];
+            float al = COLMODE ? sc[e] : arow;
             float q, v;
             ofq_lsq_quant(__fadd_rn(xe, bb[e]), al, lo, hi, q, v);
             bool inr = (v >= lo) && (v <= hi);
@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
             float dsc = ge[e] * (inr ? (q - v) : q);                    // q == clamp(v) when out of range
             acc_b4[j][e] += dq;
             acc_ba[j][e] += ge[e];
-            if (a.colmode) acc_ds[j][e] += dsc; else rowds += dsc;
-            dxo[e] = a.prologue == 1 ? dq * ofq_gelu_grad(xin[e]) : dq;
+            if (COLMODE) acc_ds[j][e] += dsc; else rowds += dsc;
+            dxo[e] = GELU ? dq * ofq_gelu_grad(xin[e]) : dq;
           }
           *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
         }
       }
-      if (BWD && !a.colmode) {
+      if (BWD && !COLMODE) {
         int w = TX < 64 ? TX : 64;
         for (int o = w / 2; o > 0; o >>= 1) rowds += __shfl_xor(rowds, o, 64);
         if ((tx & 63) == 0 || (TX < 64 && tx == 0))
@@ -252,12 +252,21 @@ template <bool BWD>
 static int lsq_launch(const LsqGeom& g, const LsqArgs& a, hipStream_t st) {
   dim3 grid(g.gx, g.gy), block(g.TX * g.TY);
   size_t lds = BWD ? lsq_lds_bytes(g, a.nacc) : 0;
+  const bool cm = a.colmode != 0, ge = a.prologue == 1;
+#define LSQ_LAUNCH_J(JJ)                                                                                     \
+  do {                                                                                                      \
+    if (cm && ge) hipLaunchKernelGGL((lsq_kernel<JJ, BWD, true, true>), grid, block, lds, st, a);           \
+    else if (cm) hipLaunchKernelGGL((lsq_kernel<JJ, BWD, true, false>), grid, block, lds, st, a);           \
+    else if (ge) hipLaunchKernelGGL((lsq_kernel<JJ, BWD, false, true>), grid, block, lds, st, a);           \
+    else hipLaunchKernelGGL((lsq_kernel<JJ, BWD, false, false>), grid, block, lds, st, a);                  \
+  } while (0)
   switch (g.J) {
-    case 1: hipLaunchKernelGGL((lsq_kernel<1, BWD>), grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL((lsq_kernel<2, BWD>), grid, block, lds, st, a); break;
-    case 3: hipLaunchKernelGGL((lsq_kernel<3, BWD>), grid, block, lds, st, a); break;
-    default: hipLaunchKernelGGL((lsq_kernel<4, BWD>), grid, block, lds, st, a); break;
+    case 1: LSQ_LAUNCH_J(1); break;
+    case 2: LSQ_LAUNCH_J(2); break;
+    case 3: LSQ_LAUNCH_J(3); break;
+    default: LSQ_LAUNCH_J(4); break;
   }
+#undef LSQ_LAUNCH_J
   OFQ_LAUNCH_CHECK();
   return 0;
 }

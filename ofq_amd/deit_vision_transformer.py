@@ -2,12 +2,15 @@
 src/deit_vision_transformer.py (Mlp :53, Attention :85, Block :132, VisionTransformer :168) with the same
 attribute / state-dict names, so checkpoints and `replace_module_by_qmodule_deit` name lists carry over.
 timm is not a dependency: PatchEmbed / to_2tuple / trunc_normal_ are the few lines needed from it.
-LayerNorm, residual adds, token concat and the un-quantised teacher run on stock PyTorch-ROCm ops."""
+LayerNorm (fused with the residual add in front of norm2) runs on the HIP kernels of csrc/layernorm.hip for device
+tensors; token concat and the un-quantised teacher's GEMMs run on stock PyTorch-ROCm ops."""
 import math
 from functools import partial
 
 import torch
 import torch.nn as nn
+
+from . import functional as F_ofq
 
 
 def to_2tuple(x):
@@ -97,9 +100,9 @@ class Block(nn.Module):
         self.qqkkvv = qqkkvv
 
     def forward(self, x):
-        y, info = self.attn(self.norm1(x))
-        x = x + y
-        x = x + self.mlp(self.norm2(x))
+        y, info = self.attn(F_ofq.layer_norm(self.norm1, x))
+        x, n2 = F_ofq.add_layer_norm(self.norm2, x, y)          # x = x + y; n2 = norm2(x), one pass
+        x = x + self.mlp(n2)
         return x, info
 
 
@@ -173,7 +176,7 @@ class VisionTransformer(nn.Module):
             x, a = blk(x)
             attn_matrixs.append(a)
             feats.append(x)
-        x = self.norm(x)
+        x = F_ofq.layer_norm(self.norm, x)
         if self.dist_token is None:
             return self.pre_logits(x[:, 0]), attn_matrixs, feats
         return x[:, 0], x[:, 1], attn_matrixs, feats

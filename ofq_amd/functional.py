@@ -392,3 +392,75 @@ class PVCodesFn(torch.autograd.Function):
         dP = ops.qattn_dp(dO, aux["vcodes"], av_eff, w, B, H, N, d, Np)
         dV = ops.qattn_dv(dO, aux["pcodes"], aux["sp"], aux["gp"], B, H, N, d, Np)
         return dP, dV, None
+
+
+# =====================================================================================================
+# LayerNorm (Block.norm1 / norm2, deit_vision_transformer.py:91-102), optionally fused with the residual add before it
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) over the last dimension (nn.LayerNorm semantics, biased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        shp = x.shape
+        x2d = x.reshape(-1, shp[-1])
+        if x2d.stride(-1) != 1 or (x2d.stride(0) & 3):
+            x2d = x2d.contiguous()
+        y, _, mean, rstd = ops.layernorm_fwd(x2d, weight, bias, eps)
+        ctx.save_for_backward(x2d, mean, rstd, weight)
+        ctx.shape = shp
+        ctx.affine = weight is not None
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, mean, rstd, weight = ctx.saved_tensors
+        dy2d = dy.reshape(x2d.shape)
+        if dy2d.stride(-1) != 1 or (dy2d.stride(0) & 3):
+            dy2d = dy2d.contiguous()
+        dx, dg, db = ops.layernorm_bwd(dy2d, x2d, mean, rstd, weight, want_affine_grads=ctx.affine)
+        return dx.view(ctx.shape), dg, db, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """(xs, y) = (x + res, LayerNorm(x + res)): the residual add of a block fused with the norm that follows it; the
+    backward adds the gradient arriving on xs (the residual stream) to the LayerNorm input gradient in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        shp = x.shape
+        x2d = x.reshape(-1, shp[-1]).contiguous()
+        r2d = res.reshape(-1, shp[-1]).contiguous()
+        y, xs, mean, rstd = ops.layernorm_fwd(x2d, weight, bias, eps, res2d=r2d)
+        ctx.save_for_backward(xs, mean, rstd, weight)
+        ctx.shape = shp
+        ctx.affine = weight is not None
+        ctx.set_materialize_grads(False)
+        return xs.view(shp), y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dxs, dy):
+        xs, mean, rstd, weight = ctx.saved_tensors
+        if dy is None:
+            return dxs, dxs, None, None, None
+        dy2d = dy.reshape(xs.shape).contiguous()
+        dres = None if dxs is None else dxs.reshape(xs.shape).contiguous()
+        dx, dg, db = ops.layernorm_bwd(dy2d, xs, mean, rstd, weight, dres2d=dres, want_affine_grads=ctx.affine)
+        dx = dx.view(ctx.shape)
+        return dx, dx, dg, db, None
+
+
+def layer_norm(norm, x):
+    """nn.LayerNorm module -> the HIP LayerNorm on device tensors (stock op for the CPU-side fp32 skeleton tests)."""
+    if isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and len(norm.normalized_shape) == 1 \
+            and norm.normalized_shape[0] % 4 == 0 and norm.normalized_shape[0] <= 2048 and x.dtype == torch.float32:
+        return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
+def add_layer_norm(norm, x, res):
+    """(x + res, norm(x + res)) in one pass."""
+    if isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and len(norm.normalized_shape) == 1 \
+            and norm.normalized_shape[0] % 4 == 0 and norm.normalized_shape[0] <= 2048 and x.dtype == torch.float32:
+        return AddLayerNormFn.apply(x, res, norm.weight, norm.bias, norm.eps)
+    xs = x + res
+    return xs, norm(xs)

@@ -412,6 +412,36 @@ def colsum(x2d):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x2d, gamma, beta, eps, res2d=None):
+    """y = LN(x [+ res]); returns (y, xsum or None, mean, rstd)"""
+    _dev(x2d, "x")
+    rows, cols = x2d.shape
+    dev = x2d.device
+    y = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    xsum = torch.empty((rows, cols), dtype=torch.float32, device=dev) if res2d is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    _chk(lib().ofq_layernorm_fwd(x2d.data_ptr(), _p(res2d), _p(gamma), _p(beta), y.data_ptr(), _p(xsum), mean.data_ptr(),
+                                 rstd.data_ptr(), rows, cols, x2d.stride(0), cols, float(eps), _stream()),
+         "ofq_layernorm_fwd")
+    return y, xsum, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres2d=None, want_affine_grads=True):
+    """returns (dx [+ dres], dgamma, dbeta)"""
+    rows, cols = x2d.shape
+    dev = x2d.device
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    dg = torch.empty(cols, dtype=torch.float32, device=dev) if want_affine_grads else None
+    db = torch.empty(cols, dtype=torch.float32, device=dev) if want_affine_grads else None
+    ws = workspace(lib().ofq_layernorm_bwd_ws_bytes(rows, cols), dev)
+    _chk(lib().ofq_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(dres2d),
+                                 dx.data_ptr(), _p(dg), _p(db), rows, cols, x2d.stride(0), dy2d.stride(0), ws.data_ptr(),
+                                 ws.numel(), _stream()), "ofq_layernorm_bwd")
+    return dx, dg, db
+
+
 # ------------------------------------------------------------------------------------------------ CGA
 def cga_freeze_mask(W, bits, boundary_range):
     _dev(W, "weight")

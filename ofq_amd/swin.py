@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as F_ofq
+
 
 class MLP(nn.Sequential):
     """torchvision.ops.misc.MLP layout: Linear, act, Dropout, Linear, Dropout  (indices 0..4)."""
@@ -44,7 +46,7 @@ class PatchMerging(nn.Module):
         H, W, _ = fx.shape[-3:]
         fx = F.pad(fx, (0, 0, 0, W % 2, 0, H % 2))
         fx = torch.cat([fx[..., 0::2, 0::2, :], fx[..., 1::2, 0::2, :], fx[..., 0::2, 1::2, :], fx[..., 1::2, 1::2, :]], -1)
-        return self.reduction(self.norm(fx)), info
+        return self.reduction(F_ofq.layer_norm(self.norm, fx)), info
 
 
 def relative_position_index(window_size):
@@ -174,9 +176,9 @@ class SwinTransformerBlock(nn.Module):
 
     def forward(self, x):
         x = x[0]
-        y, info = self.attn(self.norm1(x))
-        x = x + y
-        x = x + self.mlp(self.norm2(x))
+        y, info = self.attn(F_ofq.layer_norm(self.norm1, x))
+        x, n2 = F_ofq.add_layer_norm(self.norm2, x, y)
+        x = x + self.mlp(n2)
         return x, info
 
 
@@ -229,7 +231,7 @@ class SwinTransformer(nn.Module):
 
     def forward(self, x):
         x, infos = self.forward_features(x)
-        x = self.norm(x).permute(0, 3, 1, 2)
+        x = F_ofq.layer_norm(self.norm, x).permute(0, 3, 1, 2)
         x = torch.flatten(self.avgpool(x), 1)
         return self.head(x), infos
 

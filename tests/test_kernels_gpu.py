@@ -485,3 +485,66 @@ def test_softmax_lsq_codes_and_rowsums(ops):
     dS, ds, rs = ops.softmax_lsq_bwd(g.cuda(), prob, s.cuda(), B * H * N, N, ld, N, 0.125, hi, M, inplace=False, want_rowsum=True)
     assert torch.allclose(rs.cpu().view(B, H, N), dS.cpu().sum(-1), atol=1e-6)
     assert float(dS.cpu()[..., N:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("shape", [(2 * 198, 384), (3 * 197, 192), (50, 768), (33, 96), (7, 1536), (5, 2048), (300, 100)])
+@pytest.mark.parametrize("fused_add", [False, True])
+def test_layernorm_fwd_bwd_vs_fp64(ops, shape, fused_add):
+    """csrc/layernorm.hip against nn.LayerNorm semantics (deit_vision_transformer.py Block.norm1/norm2) in fp64;
+    tolerance 2e-6 relative on the outputs, 1e-5 on gradients (fp32 row reductions in a different order)."""
+    R, C = shape
+    x = T(det_normalish((R, C), 301, 1.0)) * 3.0 + 0.5
+    res = T(det_normalish((R, C), 302, 1.0)) if fused_add else None
+    gamma = T(det_uniform((C,), 303, 0.5, 1.5))
+    beta = T(det_uniform((C,), 304, -0.2, 0.2))
+    dy = T(det_normalish((R, C), 305, 1.0)) * 1e-2
+    dres = T(det_normalish((R, C), 306, 1.0)) * 1e-2 if fused_add else None
+    eps = 1e-6
+    y, xs, mean, rstd = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), eps, res2d=None if res is None else res.cuda())
+    xd = (x.double() + (res.double() if fused_add else 0.0)).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (C,), gd, bd, eps)
+    assert rel_err(y.cpu(), ref.detach().float()) < 2e-6
+    if fused_add:
+        assert torch.equal(xs.cpu(), x + res)
+    ref.backward(dy.double())
+    xin = xs if fused_add else x.cuda()
+    dx, dg, db = ops.layernorm_bwd(dy.cuda(), xin, mean, rstd, gamma.cuda(), dres2d=None if dres is None else dres.cuda())
+    dxr = xd.grad + (dres.double() if fused_add else 0.0)
+    assert rel_err(dx.cpu(), dxr.float()) < 1e-5
+    assert rel_err(dg.cpu(), gd.grad.float()) < 1e-5
+    assert rel_err(db.cpu(), bd.grad.float()) < 1e-5
+
+
+def test_layernorm_autograd_functions_match_torch(ops):
+    from ofq_amd import functional as Fq
+    torch.manual_seed(0)
+    B, N, C = 4, 197, 384
+    norm = torch.nn.LayerNorm(C, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    r = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    w = torch.randn(B, N, C, device="cuda")
+    xs, y = Fq.add_layer_norm(norm, x, r)
+    (xs * w + y * w.flip(0)).sum().backward()
+    got = [x.grad.clone(), r.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    for t in (x, r, norm.weight, norm.bias):
+        t.grad = None
+    xs2 = x + r
+    y2 = norm(xs2)
+    (xs2 * w + y2 * w.flip(0)).sum().backward()
+    assert rel_err(y, y2) < 2e-6 and torch.equal(xs, xs2)
+    for a, b in zip(got, [x.grad, r.grad, norm.weight.grad, norm.bias.grad]):
+        assert rel_err(a, b) < 1e-5
+    # plain LayerNorm, non-affine
+    norm2 = torch.nn.LayerNorm(C, eps=1e-5, elementwise_affine=False).cuda()
+    x.grad = None
+    y = Fq.layer_norm(norm2, x)
+    (y * w).sum().backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    (norm2(x) * w).sum().backward()
+    assert rel_err(g1, x.grad) < 1e-5
