@@ -105,6 +105,18 @@ class Block(nn.Module):
         x = x + self.mlp(n2)
         return x, info
 
+    def forward_fused(self, x, pending):
+        """forward() with the residual adds folded into the norms: `pending` is the previous block's MLP output, still to be
+        added to x (done in the same pass as norm1); this block's own MLP output is returned un-added.
+        Returns (x after the attention residual, info, mlp_out, block input with `pending` added)."""
+        if pending is None:
+            xin, n1 = x, F_ofq.layer_norm(self.norm1, x)
+        else:
+            xin, n1 = F_ofq.add_layer_norm(self.norm1, x, pending)
+        y, info = self.attn(n1)
+        x, n2 = F_ofq.add_layer_norm(self.norm2, xin, y)
+        return x, info, self.mlp(n2), xin
+
 
 def _init_vit_weights(module):
     if isinstance(module, nn.Linear):
@@ -172,11 +184,17 @@ class VisionTransformer(nn.Module):
     def forward_features(self, x):
         x = self._tokens(x)
         attn_matrixs, feats = [], []
-        for blk in self.blocks:
-            x, a = blk(x)
+        pending = None
+        for i, blk in enumerate(self.blocks):
+            x, a, pending, xin = blk.forward_fused(x, pending)      # same values as x, a = blk(x), adds fused into norms
             attn_matrixs.append(a)
-            feats.append(x)
-        x = F_ofq.layer_norm(self.norm, x)
+            if i > 0:
+                feats.append(xin)
+        x = x + pending
+        feats.append(x)
+        # LayerNorm is per token and only the class / distillation tokens are read: norm those rows only
+        ntok = 1 if self.dist_token is None else 2
+        x = F_ofq.layer_norm(self.norm, x[:, :ntok])
         if self.dist_token is None:
             return self.pre_logits(x[:, 0]), attn_matrixs, feats
         return x[:, 0], x[:, 1], attn_matrixs, feats
