@@ -72,27 +72,30 @@ __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { retur
 struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; int64_t col_div, col_mul; };
 struct SumJobs { SumJob j[3]; };
 
-// 1024 threads = 64 columns (one 256-B line per row) x 16 row lanes, four independent accumulators per lane: the
-// partials are few hundred rows deep, so the kernel is a chain of dependent L2 round trips unless many are in flight.
+// 1024 threads = CPB columns x (1024 / CPB) row lanes, four independent accumulators per lane: the partials are a few
+// hundred rows deep, so the kernel is a chain of dependent L2 round trips unless many loads are in flight.  CPB = 64
+// (one 256-B line per row) for wide jobs, 16 when the job has few columns, so that enough workgroups exist.
 #define OFQ_SUM_COLS 64
-__global__ __launch_bounds__(1024) void strided_sum_kernel(SumJobs jobs) {
+template <int CPB>
+__global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
+  constexpr int RL = 1024 / CPB;
   const SumJob jb = jobs.j[blockIdx.y];
-  __shared__ float part[16][OFQ_SUM_COLS + 1];
-  const int cx = threadIdx.x & (OFQ_SUM_COLS - 1), py = threadIdx.x / OFQ_SUM_COLS;
-  const int64_t c = (int64_t)blockIdx.x * OFQ_SUM_COLS + cx;
+  __shared__ float part[RL][CPB + 1];
+  const int cx = threadIdx.x % CPB, py = threadIdx.x / CPB;
+  const int64_t c = (int64_t)blockIdx.x * CPB + cx;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (jb.dst && c < jb.ncols) {
     const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
     const float* base = jb.src + co;
     int64_t r = py;
-    for (; r + 48 < jb.nrows; r += 64) {
+    for (; r + 3 * RL < jb.nrows; r += 4 * RL) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float* p = base + (r + 16 * u) * jb.row_stride;
+        const float* p = base + (r + RL * u) * jb.row_stride;
         for (int t = 0; t < jb.cnt; ++t) acc[u] += p[t];
       }
     }
-    for (; r < jb.nrows; r += 16) {
+    for (; r < jb.nrows; r += RL) {
       const float* p = base + r * jb.row_stride;
       for (int t = 0; t < jb.cnt; ++t) acc[0] += p[t];
     }
@@ -102,8 +105,15 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel(SumJobs jobs) {
   if (py == 0 && jb.dst && c < jb.ncols) {
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s += part[t][cx];
+    for (int t = 0; t < RL; ++t) s += part[t][cx];
     jb.dst[c] = s * jb.scale;
   }
+}
+
+static inline void strided_sum_launch(const SumJobs& jobs, int64_t maxcols, int njobs, hipStream_t st) {
+  if (maxcols > 2048)
+    hipLaunchKernelGGL(strided_sum_kernel_t<64>, dim3((unsigned)ceil_div(maxcols, 64), njobs), dim3(1024), 0, st, jobs);
+  else
+    hipLaunchKernelGGL(strided_sum_kernel_t<16>, dim3((unsigned)ceil_div(maxcols, 16), njobs), dim3(1024), 0, st, jobs);
 }
 

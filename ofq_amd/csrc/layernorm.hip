@@ -250,7 +250,7 @@ extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* m
     SumJobs jobs = {};
     if (dgamma) jobs.j[0] = {a.colpart, dgamma, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
     if (dbeta) jobs.j[1] = {a.colpart + C, dbeta, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
-    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(C, OFQ_SUM_COLS), 2), dim3(1024), 0, st, jobs);
+    strided_sum_launch(jobs, C, 2, st);
     OFQ_LAUNCH_CHECK();
   }
   return 0;

@@ -350,7 +350,7 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
     if (dbaft) { jobs.j[2] = {a.colpart + blen, dbaft, blen, g.gx, (int64_t)nacc * blen, 1, 1.0f, 0, 0}; if (blen > maxc) maxc = blen; }
   }
   if (maxc > 0) {
-    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(maxc, OFQ_SUM_COLS), 3), dim3(1024), 0, st, jobs);
+    strided_sum_launch(jobs, maxc, 3, st);
     OFQ_LAUNCH_CHECK();
   }
   return 0;

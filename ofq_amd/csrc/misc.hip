@@ -34,7 +34,7 @@ extern "C" int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols
   OFQ_LAUNCH_CHECK();
   SumJobs jobs = {};
   jobs.j[0] = {(const float*)ws, out, cols, CS_GY, cols, 1, 1.0f, 0, 0};
-  hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(cols, OFQ_SUM_COLS), 1), dim3(1024), 0, st, jobs);
+  strided_sum_launch(jobs, cols, 1, st);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -1175,6 +1175,30 @@ __global__ __launch_bounds__(256) void rowdot_i8_kernel(const int8_t* __restrict
   if (lane == 0) out[n] = acc;
 }
 
+// same, 16 codes per load: a row is owned by 16 lanes (K % 16 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vec,
+                                                            float* __restrict__ out, int N, int K) {
+  const int l16 = threadIdx.x & 15;
+  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
+  float acc = 0.f;
+  if (n < N) {
+    const int8_t* row = codes + (int64_t)n * K;
+    for (int k = l16 * 16; k < K; k += 256) {
+      const i32x4 c = *reinterpret_cast<const i32x4*>(row + k);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(vec + k + 4 * w);
+        const int word = c[w];
+        acc += v.x * (float)(signed char)(word & 0xff) + v.y * (float)(signed char)((word >> 8) & 0xff) +
+               v.z * (float)(signed char)((word >> 16) & 0xff) + v.w * (float)(word >> 24);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (n < N && l16 == 0) out[n] = acc;
+}
+
 extern "C" int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream) {
   if (!codes || !out_bf16 || rows <= 0 || cols <= 0) return OFQ_EINVAL;
   hipLaunchKernelGGL(codes_transpose_bf16_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
@@ -1186,8 +1210,12 @@ extern "C" int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int
 extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols,
                              ofq_stream_t stream) {
   if (!codes || !vec || !out || rows <= 0 || cols <= 0) return OFQ_EINVAL;
-  hipLaunchKernelGGL(rowdot_i8_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vec, out,
-                     (int)rows, (int)cols);
+  if ((cols & 15) == 0 && al16(codes) && al16(vec))
+    hipLaunchKernelGGL(rowdot_i8_v16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, codes, vec,
+                       out, (int)rows, (int)cols);
+  else
+    hipLaunchKernelGGL(rowdot_i8_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vec, out,
+                       (int)rows, (int)cols);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

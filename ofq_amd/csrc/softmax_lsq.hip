@@ -132,7 +132,7 @@ extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const floa
   if (ds) {
     SumJobs jobs = {};
     jobs.j[0] = {(const float*)ws, ds, S, rows / S, S, 1, gscale, 0, 0};
-    hipLaunchKernelGGL(strided_sum_kernel, dim3((unsigned)ceil_div(S, OFQ_SUM_COLS), 1), dim3(1024), 0, st, jobs);
+    strided_sum_launch(jobs, S, 1, st);
     OFQ_LAUNCH_CHECK();
   }
   return 0;
