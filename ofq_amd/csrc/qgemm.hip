@@ -149,6 +149,18 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   int ncol[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) ncol[j] = n0 + wn * 64 + j * 32 + l31;
+  // per-row epilogue terms of the 128 tile rows go through LDS once (the k-loop's last barrier has released smem):
+  // row_a = effective LSQ step of the row, row_b = the row's offset term (u / rp); every lane then reads 32 of them as
+  // broadcasts instead of issuing 32 dependent global loads + integer modulos
+  float* row_a = reinterpret_cast<float*>(&smem[0][0]);
+  float* row_b = row_a + BM;
+  if (tid < BM) {
+    const int m = min(m0 + tid, p.M - 1);
+    row_a[tid] = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+    if (EPI == 1) row_b[tid] = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+    if (EPI == 2) row_b[tid] = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+  }
+  __syncthreads();
   if (EPI == 0) {
     // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
     float csn[2], rn[2], bz[2];
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
-        const float ae = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+        const float ae = row_a[m - m0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (ncol[j] < p.N)
@@ -188,8 +200,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
-        const float ax = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
-        const float uu = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+        const float ax = row_a[m - m0];
+        const float uu = row_b[m - m0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (ncol[j] < p.N)
@@ -211,8 +223,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
-        const float ap = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
-        const float rpm = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+        const float ap = row_a[m - m0];
+        const float rpm = row_b[m - m0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (ncol[j] < p.N)
