@@ -5,7 +5,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(512) void k(float* out, int nm, int nv, int mode, int vkind) {
+__global__ __launch_bounds__(512) void k_(float* out, int nm, int nv, int mode, int vkind) {
   const int wid = threadIdx.x >> 6;
   float r = 0.f;
   bool do_m = (mode == 0) ? (wid < 4) : (mode == 1 ? (wid < 4) : (mode == 3));
@@ -13,6 +13,31 @@ __global__ __launch_bounds__(512) void k(float* out, int nm, int nv, int mode, i
   if (mode == 4 || mode == 5) { do_m = wid >= 4; do_v = wid < 4; }       // roles swapped: MFMA on the younger waves
   if (mode == 5 && do_v) __builtin_amdgcn_s_setprio(3);
   if (mode == 6) { do_m = wid < 4; do_v = wid >= 4; if (do_v) __builtin_amdgcn_s_setprio(3); }
+  if (mode == 7) {     // every wave: the same MFMA count as mode 3 (nm each), with `vkind` fp32 VALU ops after every MFMA in program order
+    f32x16 acc[6];
+    for (int i = 0; i < 6; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x + e); b[e] = (__bf16)(float)(e + 1); }
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = (float)(threadIdx.x * 8 + i) * 1e-3f;
+    for (int it = 0; it < nm / 6; ++it) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < vkind) {
+            const float h = __uint_as_float(__float_as_uint(x[u]) & 0xffff0000u);
+            x[u] = __fsub_rn(x[u], h) + 1.0f;
+          }
+        }
+      }
+    }
+    for (int i = 0; i < 6; ++i) r += acc[i][0];
+    for (int i = 0; i < 8; ++i) r += x[i];
+    out[blockIdx.x * 512 + threadIdx.x] = r;
+    return;
+  }
   if (do_m) {
     f32x16 acc[6];
     for (int i = 0; i < 6; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
@@ -77,12 +102,22 @@ int main() {
     for (int mode = 0; mode < 7; ++mode) {
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, nullptr, out, nm, nv, mode, vkind);
+        hipLaunchKernelGGL(k_, dim3(256), dim3(512), 0, nullptr, out, nm, nv, mode, vkind);
         hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("%-36s %8.1f us\n", names[mode], ms * 1e3);
     }
+  }
+  printf("-- every wave (2 per SIMD): %d MFMAs, k x 3 fp32 VALU instructions after each MFMA in program order\n", nm);
+  for (int k = 0; k <= 8; k += 2) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, nullptr);
+      hipLaunchKernelGGL(k_, dim3(256), dim3(512), 0, nullptr, out, nm, nv, 7, k);
+      hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("k = %d (%2d VALU per MFMA)               %8.1f us\n", k, 3 * k, ms * 1e3);
   }
   return 0;
 }
