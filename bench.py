@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
 
 
@@ -90,6 +92,27 @@ def cpu_baseline(model, args):
                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR", B, args.cpu_steps, cores)}
 
 
+class _c_stdout_to_stderr:
+    """RCCL printf()s its NCCL_DEBUG=VERSION banner (exported on this pool) to the C stdout, which would land next to the
+    one JSON line this program owes on stdout: point fd 1 at stderr while the communicator is created, flush libc's
+    buffer, and put fd 1 back."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,9 +123,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dp:
+        # RCCL writes its NCCL_DEBUG output (the pool exports NCCL_DEBUG=VERSION) to stdout by default; stdout carries
+        # exactly one JSON line here, so send the library's chatter to stderr
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        with _c_stdout_to_stderr():
+            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.barrier()                                  # creates the communicator (and prints RCCL's banner) now
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -125,7 +155,7 @@ def main():
     torch.cuda.synchronize()
     say("setup_alpha done")
     model.train()
-    dp = parallel.DataParallel(model, bucket_mb=24.0) if world > 1 else None
+    dp = parallel.DataParallel(model, bucket_mb=24.0, force_sync=args.force_dp) if (world > 1 or args.force_dp) else None
     opt = engine.make_optimizer(model, lr=5.47e-4, weight_decay=0.05)
     cga = engine.CGAHooks(model, args.wbits, 0.005, qk_reparam=not args.no_qkr) if args.cga else None
     loss_fn = KDLossSoftandHard()
@@ -190,7 +220,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

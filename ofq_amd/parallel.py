@@ -6,8 +6,9 @@ broadcast (which is what makes rank 0's data-dependent LSQ step sizes, created b
 the global ones).  Design notes for MI355X:
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so few, large
     messages beat many small ones.  DeiT-S QKR has 90.8 MB of fp32 gradients: 4 buckets of ~24 MB by default.
-  * gradients live in flat bucket buffers (p.grad are views), so a bucket is reduced in place with no pack /
-    unpack copies, and AdamW reads the averaged values straight from the views.
+  * each bucket is one flat buffer: when its last gradient lands the gradients are packed with ONE multi-tensor copy
+    (not one accumulate kernel per parameter), reduced in place (RCCL AVG), and p.grad is re-pointed at the slices,
+    so AdamW reads the averaged values with no unpack.
   * buckets are filled in reverse parameter order (heads and last blocks finish first in backward) and each is
     launched from an autograd post-accumulate hook as soon as its last gradient lands.
 StatsQ statistics need no collective: s = 2*mean|W| is a pure function of replica-identical weights
@@ -18,7 +19,7 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    __slots__ = ("flat", "params", "pending", "work")
+    __slots__ = ("flat", "params", "pending", "work", "views")
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
@@ -27,13 +28,15 @@ class GradBucket:
 
 
 class DataParallel(torch.nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=24.0, broadcast=True):
+    def __init__(self, module, process_group=None, bucket_mb=24.0, broadcast=True, force_sync=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_sync: run the hooks / collectives even in a one-rank group (exercises the RCCL path on a 1-GPU box)
+        self.sync = self.world > 1 or (force_sync and dist.is_initialized())
         self._hooks = []
-        if broadcast and self.world > 1:
+        if broadcast and self.sync:
             self.broadcast_parameters()
         self._build_buckets(bucket_mb)
 
@@ -68,18 +71,21 @@ class DataParallel(torch.nn.Module):
         for grp in groups:
             n = sum(p.numel() for p in grp)
             flat = torch.zeros(n, dtype=grp[0].dtype, device=grp[0].device)
-            off = 0
-            for p in grp:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
             b = GradBucket(flat, grp)
+            off = 0
+            b.views = []
+            for p in grp:
+                b.views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
             self.buckets.append(b)
             for p in grp:
                 self._bucket_of[p] = b
-        if self.world > 1:
+        if self.sync:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self._reset()
+        backend = dist.get_backend(self.group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"                 # RCCL averages in the collective; gloo (CPU tests) sums, then divides
+        self.zero_grad()
 
     def _reset(self):
         for b in self.buckets:
@@ -87,37 +93,39 @@ class DataParallel(torch.nn.Module):
             b.work = None
 
     def _launch(self, b):
-        # async all-reduce: the collective's stream waits for the gradient kernels already queued on the
-        # current (backward) stream, then runs concurrently with the rest of backward
-        b.flat.div_(self.world)
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        """Pack the bucket's gradients into its flat buffer with one multi-tensor copy, start the asynchronous
+        all-reduce (its stream waits for the kernels queued so far, then runs next to the rest of backward) and point
+        every p.grad at its slice, which will hold the averaged value once the work completes."""
+        have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
+        if len(have) < len(b.params):
+            b.flat.zero_()                            # parameters that took no part in this step contribute zeros
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(b.views, b.params):
+            p.grad = v
+        if self._avg:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:
+            b.flat.div_(self.world)
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
-        if p.grad.data_ptr() != b.flat.data_ptr() + 4 * self._offset(b, p):
-            # autograd replaced the view (first accumulation into an undefined grad): copy back into the bucket
-            view = b.flat[self._offset(b, p):self._offset(b, p) + p.numel()].view_as(p)
-            view.copy_(p.grad)
-            p.grad = view
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
-    def _offset(self, b, p):
-        off = 0
-        for q in b.params:
-            if q is p:
-                return off
-            off += q.numel()
-        raise KeyError
-
     def zero_grad(self):
+        """Gradients are produced into fresh tensors by autograd (no accumulate-into-view kernels) and packed per bucket
+        in _launch, so 'zeroing' is dropping the references."""
         for b in self.buckets:
-            b.flat.zero_()
+            for p in b.params:
+                p.grad = None
+        self._reset()
 
     def finish_gradient_sync(self):
         """Call after loss.backward() and before optimizer.step()."""
-        if self.world > 1:
+        if self.sync:
             for b in self.buckets:
                 if b.work is None:                      # bucket with parameters that got no gradient this step
                     self._launch(b)
