@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--with-teacher", action="store_true",
+                    help="second line of SURVEY 8(d): add the fp32 teacher forward (no_grad, same architecture, random init) "
+                         "that produces the KD soft targets to every step (train.py:906-910)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -160,8 +163,20 @@ def main():
     cga = engine.CGAHooks(model, args.wbits, 0.005, qk_reparam=not args.no_qkr) if args.cga else None
     loss_fn = KDLossSoftandHard()
 
+    teacher = None
+    if args.with_teacher:
+        from ofq_amd.deit import create_model
+        teacher = create_model(args.model, num_classes=1000).to(dev).eval()      # train.py:428-437 (fp32, frozen)
+        for p_ in teacher.parameters():
+            p_.requires_grad_(False)
+
     def step():
-        return engine.train_step(model, opt, images, target, soft, loss_fn, dp=dp, cga=cga)
+        s_t = soft
+        if teacher is not None:
+            with torch.no_grad():
+                t_out, _ = teacher(images)                    # eval mode: (cls + dist) / 2 logits
+                s_t = t_out
+        return engine.train_step(model, opt, images, target, s_t, loss_fn, dp=dp, cga=cga)
 
     for i in range(args.warmup):
         step()
@@ -212,9 +227,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s W%dA%d%s%s QAT step (student fwd + KD loss + bwd + AdamW), %d img/GPU, "
-                                      "198 tokens, fp32, teacher logits synthetic"
+                                      "198 tokens, fp32, %s"
                                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
-                                         " + CGA hooks" if args.cga else "", B),
+                                         " + CGA hooks" if args.cga else "", B,
+                                         "fp32 teacher forward in the step" if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss.detach())},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
