@@ -68,10 +68,13 @@ def build_student(model_name="deit_small_distilled_patch16_224", wbits=2, abits=
     if depth is not None:
         kw["depth"] = depth
     model = create_model(model_name, **kw)
-    args = SimpleNamespace(qmodules=default_qmodules(len(model.blocks)), wq_mode="statsq", wq_enable=True,
+    is_swin = hasattr(model, "features")                        # torchvision-style Swin skeleton (swin.py)
+    qmodules = (default_qmodules_swin([len(st) for st in model.features[1::2]]) if is_swin
+                else default_qmodules(len(model.blocks)))
+    args = SimpleNamespace(qmodules=qmodules, wq_mode="statsq", wq_enable=True,
                            wq_bitw=wbits, aq_enable=True, aq_mode="lsq", aq_bitw=abits, wq_per_channel=True,
                            aq_per_channel=True, aq_clip_learnable=True, wq_clip_learnable=False, act_layer="gelu",
-                           model_type="deit", pretrained_initialized=True, qk_reparam=qk_reparam,
+                           model_type="swin" if is_swin else "deit", pretrained_initialized=True, qk_reparam=qk_reparam,
                            qk_reparam_type=qk_reparam_type, boundaryRange=boundary_range)
     return get_qat_model(model, args)
 
