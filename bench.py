@@ -213,10 +213,17 @@ def main():
             sm = sums[name]
             peak = [v for k, v in PEAKS.items() if name.startswith(k)][0]
             achieved = sm["total_units"] / (sm["total_ms"] * 1e-3) / 1e12 if sm["total_ms"] > 0 else 0.0
+            traffic = None                       # HBM bytes per launch of this kernel class from the committed PMC passes
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                    traffic = json.load(fh).get(name.split(" ")[0], {}).get("traffic_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over the "
-                            "timed steps; for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact)",
+                            "timed steps; for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "
+                            "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/r01_traffic.json)",
                     "launches_per_step": sm["launches"] / args.steps, "avg_launch_ms": round(sm["avg_ms"], 4),
                     "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
                     "ms_per_step": round(sm["total_ms"] / args.steps, 3),
