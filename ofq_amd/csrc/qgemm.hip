@@ -40,6 +40,12 @@ struct QGemmArgs {
   int M, N, K, S, nb1;
   int tiles_m, tiles_n, accumulate, b_is_i8;
   float gscale, gscale2, alpha;
+  // i8 linear, optional by-product: the int8 codes of the NEXT layer's input quantiser applied to this output,
+  //   q = LSQ([gelu](y) + qb4[n]; step qs[m % qS]) -- what ofq_lsq_fwd would compute from the stored y, bit for bit
+  int8_t* qout; const float* qs; const float* qb4;
+  int64_t ldq;
+  int qS, qgelu;
+  float qgscale, qlo, qhi;
 };
 
 __device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& tn) {
@@ -157,19 +163,22 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   if (tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     row_a[tid] = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
+    if (EPI == 0 && p.qout) row_b[tid] = ofq_lsq_eff_scale(p.qs[m % p.qS], p.qgscale);
     if (EPI == 1) row_b[tid] = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
     if (EPI == 2) row_b[tid] = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
   }
   __syncthreads();
   if (EPI == 0) {
     // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
-    float csn[2], rn[2], bz[2];
+    float csn[2], rn[2], bz[2], qb[2];
+    signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [128][128] codes, behind row_a / row_b
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int nc = min(ncol[j], p.N - 1);
       csn[j] = p.cs[nc] * p.alpha;
       rn[j] = p.r ? p.r[nc] : 0.f;
       bz[j] = p.bias ? p.bias[nc] : 0.f;
+      qb[j] = (p.qout && p.qb4) ? p.qb4[nc] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -180,10 +189,30 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
         const float ae = row_a[m - m0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          if (ncol[j] < p.N)
-            Cb[(int64_t)m * p.ldc + ncol[j]] =
-                __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+          if (ncol[j] < p.N) {
+            const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+            Cb[(int64_t)m * p.ldc + ncol[j]] = yv;
+            if (p.qout) {
+              const float xe = p.qgelu ? ofq_gelu(yv) : yv;
+              float q, v;
+              ofq_lsq_quant(__fadd_rn(xe, qb[j]), row_b[m - m0], p.qlo, p.qhi, q, v);
+              ctile[(m - m0) * BN + (ncol[j] - n0)] = (signed char)(int)q;
+            }
+          }
       }
+    if (p.qout) {       // the code tile goes out in 64-byte row pieces (two threads per row) instead of single bytes
+      __syncthreads();
+      const int row = tid >> 1, c0 = (tid & 1) * 64;
+      if (m0 + row < p.M) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int n = n0 + c0 + 16 * q4;
+          if (n < p.N)       // N % 16 == 0 (host check)
+            *reinterpret_cast<i32x4*>(p.qout + (int64_t)(m0 + row) * p.ldq + n) =
+                *reinterpret_cast<const i32x4*>(ctile + row * BN + c0 + 16 * q4);
+        }
+      }
+    }
   } else if (EPI == 1) {
     // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
     float aq[2], tqa[2];
@@ -1232,19 +1261,41 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
   return 0;
 }
 
-extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
-                               float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,
-                               int64_t N, int64_t K,
-                               int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream) {
+static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
+                           float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qout, int64_t ldq, const float* q_s,
+                           int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu,
+                           ofq_stream_t stream) {
   if (!A || !B || !C || !col_scale || !lsq_s || M <= 0 || N <= 0 || K <= 0 || S <= 0) return OFQ_EINVAL;
   if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30)) return OFQ_EINVAL;
+  if (qout && (!q_s || q_S <= 0 || (N & 15) || (ldq & 15) || ldq < N || !al16(qout) || q_lo < -128 || q_hi > 255)) return OFQ_EINVAL;
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  a.qout = qout; a.ldq = ldq; a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4;
+  a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu;
   hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
+                               float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,
+                               int64_t N, int64_t K,
+                               int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream) {
+  return qgemm_i8_linear(A, B, C, bias, col_scale, col_mult, r, lsq_s, S, gscale, M, N, K, lda, ldb, ldc, nullptr, 0, nullptr, 0,
+                         0.f, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
+                                 float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,
+                                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qcodes, int64_t ldq,
+                                 const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
+                                 int q_gelu, ofq_stream_t stream) {
+  if (!qcodes) return OFQ_EINVAL;
+  return qgemm_i8_linear(A, B, C, bias, col_scale, col_mult, r, lsq_s, S, gscale, M, N, K, lda, ldb, ldc, qcodes, ldq, q_s, q_S,
+                         q_gscale, q_b4, q_lo, q_hi, q_gelu, stream);
 }
 
 // Wide input-gradient kernel for the linear layers: 8 waves own a 128 x (128*NJ) tile of dX, so a row panel of dY is

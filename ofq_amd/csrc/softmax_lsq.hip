@@ -104,14 +104,151 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
   }
 }
 
+// ---- float4 variants (ld % 4 == 0, ld <= 256): lane l owns columns 4l..4l+3, so a row is one 16-byte load / store per
+// lane and tensor instead of four strided dwords; same arithmetic per element, same wave reductions
+#define SM_RPW 4      // rows per wave: their loads are all issued before the first row is processed (bytes in flight)
+__global__ __launch_bounds__(256) void softmax_lsq_fwd_v4_kernel(const float* __restrict__ sc, const float* __restrict__ s,
+                                                                 float* __restrict__ prob, float* __restrict__ y,
+                                                                 int64_t rows, int n, int64_t ld, int64_t S, float alpha,
+                                                                 float hi, float gscale, unsigned char* __restrict__ codes,
+                                                                 float* __restrict__ code_rowsum, const float* __restrict__ addend,
+                                                                 int64_t add_period) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_RPW;
+  if (r0 >= rows) return;
+  const int c0 = lane * 4;
+  const bool act = c0 < ld;
+  float4 vin[SM_RPW], ain[SM_RPW];
+#pragma unroll
+  for (int i = 0; i < SM_RPW; ++i) {
+    const int64_t r = min(r0 + i, rows - 1);
+    vin[i] = ain[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+      vin[i] = *reinterpret_cast<const float4*>(sc + r * ld + c0);
+      if (addend) ain[i] = *reinterpret_cast<const float4*>(addend + (((r / S) % add_period) * S + (r % S)) * ld + c0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SM_RPW; ++i) {
+    const int64_t r = r0 + i;
+    if (r >= rows) break;
+    float t[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const float vv[4] = {vin[i].x, vin[i].y, vin[i].z, vin[i].w}, aa[4] = {ain[i].x, ain[i].y, ain[i].z, ain[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < n) {
+        t[e] = __fmul_rn(vv[e], alpha);
+        if (addend) t[e] = __fadd_rn(t[e], aa[e]);
+      }
+    float m = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+    m = ofq_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = (c0 + e < n) ? expf(t[e] - m) : 0.f;
+      sum += t[e];
+    }
+    sum = ofq_wave_sum(sum);
+    const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+    float qsum = 0.f;
+    if (act) {
+      float p[4] = {0.f, 0.f, 0.f, 0.f}, out[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < n) {
+          p[e] = ofq_div(t[e], sum);
+          float v;
+          const float yi = ofq_lsq_quant(p[e], a, 0.f, hi, q[e], v);
+          out[e] = __fmul_rn(yi, a);
+          qsum += q[e];
+        }
+      *reinterpret_cast<float4*>(prob + r * ld + c0) = make_float4(p[0], p[1], p[2], p[3]);
+      if (y) *reinterpret_cast<float4*>(y + r * ld + c0) = make_float4(out[0], out[1], out[2], out[3]);
+      if (codes)
+        *reinterpret_cast<uchar4*>(codes + r * ld + c0) =
+            make_uchar4((unsigned char)(int)q[0], (unsigned char)(int)q[1], (unsigned char)(int)q[2], (unsigned char)(int)q[3]);
+    }
+    if (code_rowsum) {
+      qsum = ofq_wave_sum(qsum);
+      if (lane == 0) code_rowsum[r] = qsum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __restrict__ g, const float* __restrict__ prob,
+                                                                 const float* __restrict__ s, float* __restrict__ dsc,
+                                                                 float* __restrict__ rowpart, int64_t rows, int n,
+                                                                 int64_t ld, int64_t S, float alpha, float hi,
+                                                                 float gscale, float* __restrict__ ds_rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_RPW;
+  if (r0 >= rows) return;
+  const int c0 = lane * 4;
+  const bool act = c0 < ld;
+  float4 pin[SM_RPW], gin[SM_RPW];
+#pragma unroll
+  for (int i = 0; i < SM_RPW; ++i) {
+    const int64_t r = min(r0 + i, rows - 1);
+    pin[i] = gin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+      pin[i] = *reinterpret_cast<const float4*>(prob + r * ld + c0);
+      gin[i] = *reinterpret_cast<const float4*>(g + r * ld + c0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SM_RPW; ++i) {
+    const int64_t r = r0 + i;
+    if (r >= rows) break;
+    const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+    float p[4] = {0.f, 0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float rowds = 0.f, dot = 0.f;
+    const float pp[4] = {pin[i].x, pin[i].y, pin[i].z, pin[i].w}, gg[4] = {gin[i].x, gin[i].y, gin[i].z, gin[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (act && c0 + e < n) {
+        p[e] = pp[e];
+        float q, v;
+        ofq_lsq_quant(p[e], a, 0.f, hi, q, v);
+        const bool inr = (v >= 0.f) && (v <= hi);
+        dq[e] = inr ? ofq_div(__fmul_rn(gg[e], a), a) : 0.f;
+        rowds += gg[e] * (inr ? (q - v) : q);
+        dot += dq[e] * p[e];
+      }
+    rowds = ofq_wave_sum(rowds);
+    dot = ofq_wave_sum(dot);
+    if (lane == 0) rowpart[r] = rowds;
+    float rsum = 0.f;
+    if (act) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (c0 + e < n) ? (dq[e] - dot) * p[e] * alpha : 0.f;
+        rsum += o[e];
+      }
+      *reinterpret_cast<float4*>(dsc + r * ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (ds_rowsum) {
+      rsum = ofq_wave_sum(rsum);
+      if (lane == 0) ds_rowsum[r] = rsum;
+    }
+  }
+}
+
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
                                    int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes,
                                    float* code_rowsum, const float* addend, int64_t add_period, ofq_stream_t stream) {
   if (!scores || !s || !prob || (!y && !codes) || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
     return OFQ_EINVAL;
-  hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                     scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
-                     add_period > 0 ? add_period : 1);
+  const bool v4 = (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0 && ((uintptr_t)prob & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0) &&
+                  (!codes || ((uintptr_t)codes & 3) == 0) && (!addend || ((uintptr_t)addend & 15) == 0);
+  if (v4)
+    hipLaunchKernelGGL(softmax_lsq_fwd_v4_kernel, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, (hipStream_t)stream,
+                       scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
+                       add_period > 0 ? add_period : 1);
+  else
+    hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
+                       add_period > 0 ? add_period : 1);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -126,8 +263,12 @@ extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const floa
     return OFQ_EINVAL;
   if (ws_bytes < (size_t)rows * sizeof(float)) return OFQ_ENOWS;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
-                     (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+  if ((ld & 3) == 0 && (((uintptr_t)g | (uintptr_t)prob | (uintptr_t)dscores) & 15) == 0)
+    hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, st, g, prob, s, dscores,
+                       (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+  else
+    hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
+                       (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
   OFQ_LAUNCH_CHECK();
   if (ds) {
     SumJobs jobs = {};

@@ -53,7 +53,7 @@ class CodesLinearFn(torch.autograd.Function):
         x2d = xq.reshape(-1, K)
         r = ops.rowdot_i8(aux["wcodes"], aux["baft"]) if aux["baft"] is not None else None
         y = ops.qgemm_i8_nt(aux["xcodes"].view(-1, K), aux["wcodes"], bias, aux["w_scale"], aux["w_mult"], r,
-                            aux["act_s"], aux["act_S"], aux["act_gscale"])
+                            aux["act_s"], aux["act_S"], aux["act_gscale"], fuse=aux.get("fuse"))
         ctx.codes_only = xq.stride(-1) == 0           # x_hat exists only as codes (placeholder carrier tensor)
         ctx.save_for_backward(*(() if ctx.codes_only else (x2d,)))
         ctx.aux = aux
@@ -95,13 +95,14 @@ def codes_linear_ok(in_features, wquant, act_quant):
     return (in_features % 16 == 0 and wquant.num_bits <= 7 and act_quant.thd_neg >= -128 and act_quant.thd_pos <= 127)
 
 
-def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias):
-    """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True)."""
+def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None):
+    """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True).
+    `fuse`: see ops.qgemm_i8_nt (the next layer's input codes as a by-product of this GEMM's epilogue)."""
     Wq = wquant(weight, want_codes=True)
     aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev,
            "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
-           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale}
+           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 

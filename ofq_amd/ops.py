@@ -273,15 +273,26 @@ def rowdot_i8(codes, vec):
     return out
 
 
-def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale):
-    """y = col_mult*col_scale[n]*(a_eff[m % S]*(xcodes @ wcodes^T) + r[n]) + bias[n]"""
+def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, fuse=None):
+    """y = col_mult*col_scale[n]*(a_eff[m % S]*(xcodes @ wcodes^T) + r[n]) + bias[n]
+    fuse (optional): LsqGeom-like description of the next layer's input quantiser {s, S, gscale, b4, lo, hi, gelu};
+    the kernel then also emits that quantiser's int8 codes of y into fuse["codes_out"]."""
     M, K = xcodes.shape
     N = wcodes.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=xcodes.device)
     with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * M * N * K):
-        _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
-                                   col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
-                                   wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
+        if fuse is None:
+            _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
+                                       col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
+                                       wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
+        else:
+            qc = torch.empty((M, N), dtype=torch.int8, device=xcodes.device)
+            _chk(lib().ofq_qgemm_i8_nt_q(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
+                                         col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
+                                         wcodes.stride(0), N, qc.data_ptr(), N, fuse["s"].data_ptr(), fuse["S"],
+                                         fuse["gscale"], _p(fuse["b4"]), fuse["lo"], fuse["hi"], int(fuse["gelu"]),
+                                         _stream()), "ofq_qgemm_i8_nt_q")
+            fuse["codes_out"] = qc
     return y
 
 

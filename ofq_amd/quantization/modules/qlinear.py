@@ -2,6 +2,8 @@
 src/quantization/modules/qlinear.py (:28, :89, :12, :138, :193): same class names, constructor
 signatures, parameter names and shapes (= checkpoint format), same error behaviour.
 Every forward is a short chain of HIP kernels: StatsQ / LSQ-weight -> fused offset+LSQ+offset -> MFMA GEMM."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -16,6 +18,8 @@ from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
 # Exact integer-code GEMMs (int8 forward, bf16-split dX) instead of the fp32-MFMA GEMM on fake-quant values.
 # Same mathematical function; toggled off by the parity tests that compare the two paths.
 USE_CODE_GEMM = True
+# fc1's GEMM epilogue emits fc2's input codes (A/B switch for bench runs: OFQ_NO_EPILOGUE_FUSE=1)
+FUSE_NEXT_CODES = os.environ.get("OFQ_NO_EPILOGUE_FUSE") is None
 
 
 class LSQ_input(nn.Module):
@@ -63,15 +67,27 @@ class QLinear(nn.Linear):
         self.move_aft = LearnableBias(self.weight.shape[1])
         self._prologue = 0          # 1: exact GELU fused in front of the input quantiser (set by QMLP for fc2)
 
-    def forward(self, input):
+    def code_path(self):
+        return USE_CODE_GEMM and codes_linear_ok(self.in_features, self.statsq_fn, self.input_quant_fn)
+
+    def input_fuse_spec(self, in_shape):
+        """What a producer's GEMM epilogue needs to emit this layer's input codes itself (None: not possible)."""
+        if not (self.code_path() and codes_only_ok(self.in_features, self.out_features)):
+            return None
+        return self.input_quant_fn.fusable(in_shape, self.move_b4.bias, self._prologue)
+
+    def forward(self, input, fuse_next=None, pre_codes=None):
+        """fuse_next: input_fuse_spec() of the layer consuming this output (its codes come back in fuse_next["codes_out"]);
+        pre_codes: this layer's own input codes when a producer already computed them."""
         if self.weight_quant_method != "statsq":
             raise ValueError("Unknown quant_method")
-        if USE_CODE_GEMM and codes_linear_ok(self.in_features, self.statsq_fn, self.input_quant_fn):
+        if self.code_path():
             xq, xcodes, geom = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias,
                                                          prologue=self._prologue, want_codes=True,
-                                                         need_values=not codes_only_ok(self.in_features, self.out_features))
+                                                         need_values=not codes_only_ok(self.in_features, self.out_features),
+                                                         pre_codes=pre_codes)
             return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
-                                self.statsq_fn, self.bias)
+                                self.statsq_fn, self.bias, fuse=fuse_next)
         weight = self.statsq_fn(self.weight)                                     # qlinear.py:62
         xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, prologue=self._prologue)
         return LinearFn.apply(xq, weight, self.bias)                             # qlinear.py:69-71
@@ -109,6 +125,12 @@ class QMLP(Mlp):
         self.fc2._prologue = 1 if self._fuse_gelu else 0
 
     def forward(self, x):
+        if FUSE_NEXT_CODES and self._fuse_gelu and self.fc1.code_path():
+            # fc1's GEMM epilogue also applies GELU + fc2's offset and LSQ, so fc2 never re-reads the fp32 activation
+            spec = self.fc2.input_fuse_spec(tuple(x.shape[:-1]) + (self.fc1.out_features,))
+            h = self.fc1(x, fuse_next=spec)
+            x = self.fc2(h, pre_codes=None if spec is None else spec.get("codes_out"))
+            return self.drop2(x)
         x = self.fc1(x)
         if not self._fuse_gelu:
             x = self.drop1(self.act(x))

@@ -26,8 +26,13 @@ class _LsqFn(torch.autograd.Function):
     """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
 
     @staticmethod
-    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True):
-        y, codes = ops.lsq_fwd(x, s, b4, baft, geom, want_codes=want_codes, need_values=need_values)
+    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True, pre_codes=None):
+        if pre_codes is not None:
+            # the producer GEMM's epilogue already applied this quantiser (ofq_qgemm_i8_nt_q): same codes, no second pass
+            assert want_codes and not need_values
+            y, codes = ops.placeholder((geom.outer * geom.S, geom.ldy), x.device), pre_codes
+        else:
+            y, codes = ops.lsq_fwd(x, s, b4, baft, geom, want_codes=want_codes, need_values=need_values)
         ctx.save_for_backward(x, s, b4)
         ctx.geom = geom
         ctx.has_bias = b4 is not None
@@ -40,12 +45,12 @@ class _LsqFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gcodes):
         if gy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, s, b4 = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx.view(x.shape), ds, db4, dbaft, None, None, None
+        return dx.view(x.shape), ds, db4, dbaft, None, None, None, None
 
 
 class _LsqBase(nn.Module):
@@ -73,8 +78,19 @@ class _LsqBase(nn.Module):
         self.s = nn.Parameter(init_val.to(xin.device).float().contiguous().clone(), requires_grad=bool(self.learnable))
         self.initialized_alpha = True
 
+    def fusable(self, shape, b4, prologue):
+        """Description of this quantiser for a producer GEMM epilogue (ops.qgemm_i8_nt fuse=...), or None when it cannot
+        be applied there (not initialised yet, per-channel scale, several offset phases)."""
+        if not self.initialized_alpha or self.s is None or b4 is None:
+            return None
+        geom = self._geom(tuple(shape), b4.numel(), prologue, None, None)
+        if geom.mode != 0 or geom.bias_len != geom.inner or geom.inner % 16:
+            return None
+        return {"s": self.s.detach(), "S": geom.S, "gscale": geom.gscale, "b4": b4.detach(), "lo": geom.lo, "hi": geom.hi,
+                "gelu": prologue == 1}
+
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
-              want_codes=False, need_values=True):
+              want_codes=False, need_values=True, pre_codes=None):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
         is a strided column slice)."""
         if not x.is_cuda:
@@ -90,7 +106,9 @@ class _LsqBase(nn.Module):
                 xin = self._add_bias_for_init(xin, b4.detach())
             self.init_from(xin)
         geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
-        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values)
+        if pre_codes is not None and (need_values or not want_codes):
+            pre_codes = None
+        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values, pre_codes)
         y = y.view(out_shape if out_shape is not None else shp)
         if want_codes:
             return y, codes, geom

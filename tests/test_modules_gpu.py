@@ -304,3 +304,36 @@ def test_swin_tiny_full_step_golden(env):
                     bad[pn] = e
                 n += 1
         assert n > 80 and not bad, bad
+
+
+def test_qmlp_fused_input_codes_are_bit_identical(env):
+    """fc1's GEMM epilogue emits fc2's input codes (ofq_qgemm_i8_nt_q): same codes, outputs and gradients as the
+    separate LSQ pass, bit for bit."""
+    from ofq_amd.quantization.modules.qlinear import QMLP
+    from ofq_amd.deit_vision_transformer import Mlp
+    torch.manual_seed(3)
+    B, N, C, Hd = 3, 197, 192, 768
+    q = QMLP(m=Mlp(in_features=C, hidden_features=Hd, act_layer=nn.GELU), weight_bits=2, input_bits=2,
+             act_layer=nn.GELU, pretrained_initialized=True).cuda().train()
+    x = torch.randn(B, N, C, device="cuda")
+    with torch.no_grad():
+        q(x)                                  # lazy LSQ init
+        q.fc2.move_b4.bias.uniform_(-0.05, 0.05)
+        q.fc1.bias.uniform_(-0.5, 0.5)
+    w = torch.randn(B, N, C, device="cuda")
+
+    def run():
+        for p in q.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = q(xg)
+        (y * w).sum().backward()
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in q.parameters() if p.grad is not None]
+
+    assert q.fc2.input_fuse_spec((B, N, Hd)) is not None
+    fused = run()
+    q.fc2.input_fuse_spec = lambda shape: None
+    plain = run()
+    assert len(fused) == len(plain)
+    for a, b in zip(fused, plain):
+        assert torch.equal(a, b)
