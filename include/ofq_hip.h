@@ -120,12 +120,15 @@ int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const float* bia
                     int64_t K, int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream);
 /*  Same GEMM with a by-product: the int8 codes of the NEXT layer's input quantiser applied to this output,
  *  qcodes[m][n] = LSQ([gelu](y[m][n]) + q_b4[n]; step q_s[m % q_S], range [q_lo, q_hi]) -- bit for bit what ofq_lsq_fwd
- *  computes from the stored y (qlinear.py:123-136: fc1 -> GELU -> fc2's offset + LSQ), so the consumer does not
- *  read y again.  N % 16 == 0. */
+ *  computes from the stored y (qlinear.py:123-136: fc1 -> GELU -> fc2's offset + LSQ; attention.py:201-206: qkx, one
+ *  step per (token, head); :184 v, one step per channel), so the consumer does not read y again.  N % 16 == 0.
+ *  q_colmode 0: step index (m * q_rowmul + n / q_coldiv) % q_S  (q_rowmul = quantiser rows per output row, q_coldiv =
+ *  their width, a multiple of 128 when q_rowmul > 1);  q_colmode 1: step index n (q_S == N). */
 int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
                       float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N,
                       int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qcodes, int64_t ldq, const float* q_s,
-                      int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu, ofq_stream_t stream);
+                      int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu, int q_rowmul,
+                      int64_t q_coldiv, int q_colmode, ofq_stream_t stream);
 /*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
  *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.
  *            K % 8 == 0, lda % 4 == 0, ldb % 8 == 0. */

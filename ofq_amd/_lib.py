@@ -37,7 +37,7 @@ SIGNATURES = {
     "ofq_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
     "ofq_qgemm_i8_nt": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64, vp]),
     "ofq_qgemm_i8_nt_q": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64,
-                                vp, i64, vp, i64, f32, vp, i32, i32, i32, vp]),
+                                vp, i64, vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp]),
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
     "ofq_qgemm_bf16s_tn_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]),

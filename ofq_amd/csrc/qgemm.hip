@@ -42,9 +42,11 @@ struct QGemmArgs {
   float gscale, gscale2, alpha;
   // i8 linear, optional by-product: the int8 codes of the NEXT layer's input quantiser applied to this output,
   //   q = LSQ([gelu](y) + qb4[n]; step qs[m % qS]) -- what ofq_lsq_fwd would compute from the stored y, bit for bit
+  //   per-row step (qcolmode 0): index (m * qrowmul + n0 / qcoldiv) % qS -- qrowmul > 1 when the output row holds
+  //   qrowmul quantiser rows side by side (qkx: heads); per-column step (qcolmode 1): index n
   int8_t* qout; const float* qs; const float* qb4;
   int64_t ldq;
-  int qS, qgelu;
+  int qS, qgelu, qrowmul, qcoldiv, qcolmode;
   float qgscale, qlo, qhi;
 };
 
@@ -163,14 +165,15 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   if (tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     row_a[tid] = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
-    if (EPI == 0 && p.qout) row_b[tid] = ofq_lsq_eff_scale(p.qs[m % p.qS], p.qgscale);
+    if (EPI == 0 && p.qout && !p.qcolmode)
+      row_b[tid] = ofq_lsq_eff_scale(p.qs[((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS], p.qgscale);
     if (EPI == 1) row_b[tid] = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
     if (EPI == 2) row_b[tid] = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
   }
   __syncthreads();
   if (EPI == 0) {
     // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
-    float csn[2], rn[2], bz[2], qb[2];
+    float csn[2], rn[2], bz[2], qb[2], qsc[2];
     signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [128][128] codes, behind row_a / row_b
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
       rn[j] = p.r ? p.r[nc] : 0.f;
       bz[j] = p.bias ? p.bias[nc] : 0.f;
       qb[j] = (p.qout && p.qb4) ? p.qb4[nc] : 0.f;
+      qsc[j] = (p.qout && p.qcolmode) ? ofq_lsq_eff_scale(p.qs[nc], p.qgscale) : 1.f;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
             if (p.qout) {
               const float xe = p.qgelu ? ofq_gelu(yv) : yv;
               float q, v;
-              ofq_lsq_quant(__fadd_rn(xe, qb[j]), row_b[m - m0], p.qlo, p.qhi, q, v);
+              ofq_lsq_quant(__fadd_rn(xe, qb[j]), p.qcolmode ? qsc[j] : row_b[m - m0], p.qlo, p.qhi, q, v);
               ctile[(m - m0) * BN + (ncol[j] - n0)] = (signed char)(int)q;
             }
           }
@@ -1264,17 +1268,20 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
 static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
                            float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qout, int64_t ldq, const float* q_s,
-                           int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu,
-                           ofq_stream_t stream) {
+                           int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu, int q_rowmul,
+                           int64_t q_coldiv, int q_colmode, ofq_stream_t stream) {
   if (!A || !B || !C || !col_scale || !lsq_s || M <= 0 || N <= 0 || K <= 0 || S <= 0) return OFQ_EINVAL;
   if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30)) return OFQ_EINVAL;
-  if (qout && (!q_s || q_S <= 0 || (N & 15) || (ldq & 15) || ldq < N || !al16(qout) || q_lo < -128 || q_hi > 255)) return OFQ_EINVAL;
+  if (qout && (!q_s || q_S <= 0 || (N & 15) || (ldq & 15) || ldq < N || !al16(qout) || q_lo < -128 || q_hi > 255 || q_rowmul < 1 ||
+               q_coldiv < 1 || (q_rowmul > 1 && (q_coldiv % 128 || q_rowmul * q_coldiv != N)) || (q_colmode && q_S != N)))
+    return OFQ_EINVAL;
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
   a.qout = qout; a.ldq = ldq; a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4;
-  a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu;
+  a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu; a.qrowmul = q_rowmul;
+  a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
   hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
@@ -1285,17 +1292,17 @@ extern "C" int ofq_qgemm_i8_nt(const int8_t* A, const int8_t* B, float* C, const
                                int64_t N, int64_t K,
                                int64_t lda, int64_t ldb, int64_t ldc, ofq_stream_t stream) {
   return qgemm_i8_linear(A, B, C, bias, col_scale, col_mult, r, lsq_s, S, gscale, M, N, K, lda, ldb, ldc, nullptr, 0, nullptr, 0,
-                         0.f, nullptr, 0, 0, 0, stream);
+                         0.f, nullptr, 0, 0, 0, 1, 1, 0, stream);
 }
 
 extern "C" int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
                                  float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M,
                                  int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qcodes, int64_t ldq,
                                  const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
-                                 int q_gelu, ofq_stream_t stream) {
+                                 int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, ofq_stream_t stream) {
   if (!qcodes) return OFQ_EINVAL;
   return qgemm_i8_linear(A, B, C, bias, col_scale, col_mult, r, lsq_s, S, gscale, M, N, K, lda, ldb, ldc, qcodes, ldq, q_s, q_S,
-                         q_gscale, q_b4, q_lo, q_hi, q_gelu, stream);
+                         q_gscale, q_b4, q_lo, q_hi, q_gelu, q_rowmul, q_coldiv, q_colmode, stream);
 }
 
 // Wide input-gradient kernel for the linear layers: 8 waves own a 128 x (128*NJ) tile of dX, so a row panel of dY is

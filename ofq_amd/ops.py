@@ -291,6 +291,7 @@ def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, 
                                          col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
                                          wcodes.stride(0), N, qc.data_ptr(), N, fuse["s"].data_ptr(), fuse["S"],
                                          fuse["gscale"], _p(fuse["b4"]), fuse["lo"], fuse["hi"], int(fuse["gelu"]),
+                                         int(fuse.get("rowmul", 1)), int(fuse.get("coldiv", N)), int(fuse.get("colmode", 0)),
                                          _stream()), "ofq_qgemm_i8_nt_q")
             fuse["codes_out"] = qc
     return y

@@ -175,20 +175,26 @@ def qkr_attention_core(self, x, scale, addend=None):
         if use_codes:
             # with the attention core on codes too, no consumer reads the fp32 x_hat / v_hat / qkx_hat values
             xq, xcodes, xgeom = xin(x, want_codes=True, need_values=not attn_codes)   # attention.py:177
+            # the v / qkx quantisers are applied by the epilogue of the GEMM that produces their input (same codes)
+            fuse_ok = attn_codes and _ql.FUSE_NEXT_CODES
+            vspec = self.quan_a_v_fn.fusable((B, N, C), self.move_v_b4.bias, 0) if fuse_ok else None
+            qspec = self.quan_a_qkx_fn.fusable((B, N * H, C), self.move_qkx_b4.bias, 0) if fuse_ok else None
             v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
-                             self.v.bias)                                        # :179-181
+                             self.v.bias, fuse=vspec)                            # :179-181
         else:
             xq = xin(x)
             v = LinearFn.apply(xq, self.v_quant(self.v.weight), self.v.bias)
         if attn_codes:
             v, vcodes, vgeom = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias, want_codes=True,
-                                                      need_values=False)
+                                                      need_values=False,
+                                                      pre_codes=None if vspec is None else vspec.get("codes_out"))
         else:
             v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
         Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
         if use_codes:
-            qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None)
+            qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None,
+                               fuse=qspec)
         else:
             qkx = LinearFn.apply(xq, self.qk_quant(Wqk_fp), None)                # (B, N, H*C)   einsum :200
         if not attn_codes:
@@ -200,7 +206,8 @@ def qkr_attention_core(self, x, scale, addend=None):
         else:
             qkx, qcodes, qgeom = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
                                                           shape=(B, N * H, C), out_shape=(B, N, H, C), want_codes=True,
-                                                          need_values=False)
+                                                          need_values=False,
+                                                          pre_codes=None if qspec is None else qspec.get("codes_out"))
             link = {}
             S = QKRScoresCodesFn.apply(xq, qkx, {
                 "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,

@@ -80,14 +80,25 @@ class _LsqBase(nn.Module):
 
     def fusable(self, shape, b4, prologue):
         """Description of this quantiser for a producer GEMM epilogue (ops.qgemm_i8_nt fuse=...), or None when it cannot
-        be applied there (not initialised yet, per-channel scale, several offset phases)."""
+        be applied there (not initialised yet, unsupported geometry).  `shape` is the shape quant() would be given."""
         if not self.initialized_alpha or self.s is None or b4 is None:
             return None
         geom = self._geom(tuple(shape), b4.numel(), prologue, None, None)
-        if geom.mode != 0 or geom.bias_len != geom.inner or geom.inner % 16:
+        if geom.inner % 16 or geom.bias_len % geom.inner:
             return None
-        return {"s": self.s.detach(), "S": geom.S, "gscale": geom.gscale, "b4": b4.detach(), "lo": geom.lo, "hi": geom.hi,
-                "gelu": prologue == 1}
+        k = geom.bias_len // geom.inner                   # offset phases = quantiser rows per producer output row
+        if geom.mode == 0:
+            if k > 1 and (geom.inner % 128 or geom.S % k):
+                return None
+            extra = {"rowmul": k, "coldiv": geom.inner, "colmode": 0}
+        elif geom.mode == 1 and k == 1:
+            extra = {"rowmul": 1, "coldiv": geom.inner, "colmode": 1}
+        else:
+            return None
+        spec = {"s": self.s.detach(), "S": geom.S if geom.mode == 0 else geom.inner, "gscale": geom.gscale,
+                "b4": b4.detach(), "lo": geom.lo, "hi": geom.hi, "gelu": prologue == 1}
+        spec.update(extra)
+        return spec
 
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
               want_codes=False, need_values=True, pre_codes=None):

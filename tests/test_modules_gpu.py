@@ -337,3 +337,41 @@ def test_qmlp_fused_input_codes_are_bit_identical(env):
     assert len(fused) == len(plain)
     for a, b in zip(fused, plain):
         assert torch.equal(a, b)
+
+
+def test_qkr_attention_fused_quantiser_epilogues_are_bit_identical(env):
+    """v and qkx codes from the producing GEMM's epilogue (per-channel step / one step per (token, head)) against the
+    separate LSQ kernels: identical outputs and gradients."""
+    from ofq_amd.quantization.modules import qlinear as ql
+    from ofq_amd.quantization.modules.attention import QAttention_qkreparam
+    from ofq_amd.deit_vision_transformer import Attention
+    torch.manual_seed(5)
+    B, N, C, H = 3, 198, 384, 6
+    q = QAttention_qkreparam(m=Attention(dim=C, num_heads=H, qkv_bias=True), weight_bits=2, input_bits=2,
+                             pretrained_initialized=True).cuda().train()
+    x = torch.randn(B, N, C, device="cuda")
+    with torch.no_grad():
+        q(x)
+        for nme, p in q.named_parameters():
+            if "move_" in nme:
+                p.uniform_(-0.05, 0.05)
+    w = torch.randn(B, N, C, device="cuda")
+
+    def run():
+        for p in q.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = q(xg)[0]
+        (y * w).sum().backward()
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in q.parameters() if p.grad is not None]
+
+    assert ql.FUSE_NEXT_CODES
+    fused = run()
+    ql.FUSE_NEXT_CODES = False
+    try:
+        plain = run()
+    finally:
+        ql.FUSE_NEXT_CODES = True
+    assert len(fused) == len(plain)
+    for a, b in zip(fused, plain):
+        assert torch.equal(a, b)
