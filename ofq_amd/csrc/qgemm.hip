@@ -1018,9 +1018,15 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
   static const bool narrow_only = getenv("OFQ_TN_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
-  if (N % 384 == 0 && !narrow_only && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {          // wide tile: one dY split feeds three 128-column blocks
-    a.tiles_n = (int)(N / 384);
-    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+  if (N > 128 && (N & 7) == 0 && !narrow_only && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {
+    // wide tile: one dY split feeds three (two when N is not a multiple of 384) 128-column blocks
+    if (N % 384 == 0) {
+      a.tiles_n = (int)(N / 384);
+      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+    } else {
+      a.tiles_n = (int)ceil_div(N, 256);
+      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<2>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   }

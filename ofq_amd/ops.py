@@ -315,8 +315,8 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     Ktok, M = dy2d.shape
     N = xcodes2d.shape[1]
     if split is None:
-        if N % 384 == 0:       # wide 128x384 tiles, one 512-thread workgroup per CU
-            tiles = ((M + 127) // 128) * (N // 384)
+        if N > 128 and N % 8 == 0:       # wide 128x384 (128x256) tiles, one 512-thread workgroup per CU
+            tiles = ((M + 127) // 128) * (N // 384 if N % 384 == 0 else (N + 255) // 256)
             split = max(1, min(256 // tiles, (Ktok + 31) // 32 // 4))
         else:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)

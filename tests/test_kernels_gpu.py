@@ -379,7 +379,8 @@ def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)
 
 
-@pytest.mark.parametrize("shape", [(792, 384, 384), (1188, 1536, 384), (396, 384, 1536), (500, 72, 48), (2000, 2304, 384)])
+@pytest.mark.parametrize("shape", [(792, 384, 384), (1188, 1536, 384), (396, 384, 1536), (500, 72, 48), (2000, 2304, 384),
+                                   (700, 96, 192), (640, 384, 768), (900, 200, 144)])
 def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
     Ktok, Mo, Nc = shape
     rs = np.random.RandomState(5)
