@@ -135,6 +135,16 @@ int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, const float* b
 int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha, int accumulate,
                        int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                        ofq_stream_t stream);
+/*  dX GEMM fused with the backward of the layer's own input quantiser (qlinear.py:66-69: x -> move_b4 -> LSQ -> move_aft
+ *  -> F.linear): dX_hat = alpha * (dY * k_scale) @ B never leaves the kernel; its epilogue applies ofq_lsq_bwd's
+ *  arithmetic (per-token step lsq_s[m % S], offset b4[n], optional GELU prologue) and writes dx[M][N] (ld ldx), and
+ *  through a fixed-order second stage ds[S], db4[N], dbaft[N] (each optional).  x is the quantiser's fp32 input
+ *  [M][N] (ld ldx).  N > 128, M % S == 0. */
+size_t ofq_qgemm_bf16s_nt_lsq_ws_bytes(int64_t M, int64_t N);
+int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const float* k_scale, float alpha, const float* x,
+                           const float* lsq_s, int64_t S, float gscale, const float* b4, int lo, int hi, int gelu,
+                           float* dx, float* ds, float* db4, float* dbaft, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, ofq_stream_t stream);
 /*  weight gradient: dW[o,c] = sum_m (dY[m,o] * a_eff[m % S]) * codes[m,c] + db[o]*baft[c]  (= dY^T @ X_hat with
  *            X_hat = a_eff*codes + baft).  dY fp32 [Ktok][M], codes int8 [Ktok][N]; three bf16 pieces of dY*a_eff,
  *            LDS transpose reads, split-K over tokens with a deterministic reduction.  M % 4 == 0, N % 16 == 0.

@@ -39,6 +39,9 @@ SIGNATURES = {
     "ofq_qgemm_i8_nt_q": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64,
                                 vp, i64, vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp]),
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
+    "ofq_qgemm_bf16s_nt_lsq_ws_bytes": (sz, [i64, i64]),
+    "ofq_qgemm_bf16s_nt_lsq": (i32, [vp, vp, vp, f32, vp, vp, i64, f32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i64, i64, i64,
+                                     i64, i64, vp, sz, vp]),
     "ofq_qgemm_bf16s_tn_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),

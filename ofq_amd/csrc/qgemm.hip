@@ -44,6 +44,11 @@ struct QGemmArgs {
   //   q = LSQ([gelu](y) + qb4[n]; step qs[m % qS]) -- what ofq_lsq_fwd would compute from the stored y, bit for bit
   //   per-row step (qcolmode 0): index (m * qrowmul + n0 / qcoldiv) % qS -- qrowmul > 1 when the output row holds
   //   qrowmul quantiser rows side by side (qkx: heads); per-column step (qcolmode 1): index n
+  // bf16s-nt wide, optional fused LSQ backward of the layer's input quantiser (see qgemm_bf16s_nt_wide_kernel<NJ, true>)
+  const float* lx; const float* ls; const float* lb4; float* lrow; float* lcol;
+  int64_t ldlx;
+  int lS, lgelu;
+  float lgscale, llo, lhi;
   int8_t* qout; const float* qs; const float* qb4;
   int64_t ldq;
   int qS, qgelu, qrowmul, qcoldiv, qcolmode;
@@ -1315,7 +1320,11 @@ extern "C" int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, con
 // scaled and split into its three bf16 planes once per NJ column blocks (once in total when N <= 384, the qkv / fc1 /
 // proj case) instead of once per 128 columns.  Same pipeline as the wide dW kernel: double-buffered LDS, one LDS-only
 // barrier per k-step, two register prefetch slots.
-template <int NJ>
+// LSQ = true: the epilogue is the backward of the layer's own input quantiser (ofq_lsq_bwd's arithmetic, element for
+// element) applied to the dX tile while it is still in registers: dx, the per-row step-gradient partials [M][tiles_n]
+// and the per-column offset-gradient partials [tiles_m][2][N] are written instead of dX, so dX never travels to HBM and
+// back (8 of the 16 B/element of the unfused pair).
+template <int NJ, bool LSQ>
 __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128 * NJ, NS = 3;
   constexpr int PLANE = BM * QBS_LD;
@@ -1466,22 +1475,103 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     if (kt + 1 < nkt) step(kt + 1, smem + STAGE, smem, Slot0());
   }
 
+  if constexpr (!LSQ) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n0 + wn * 32 * NJ + j * 32 + l31;
-    if (n >= p.N) continue;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M) {
+            float* dst = p.C + (int64_t)m * p.ldc + n;
+            float v = acc[i][j][e] * p.alpha;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+    }
+  } else {
+    float* fsm = reinterpret_cast<float*>(smem);       // the k-loop's last barrier has released the staging buffers
+    float* row_a = fsm;                                // [128]  effective LSQ step of the tile rows
+    float* rowred = fsm + BM;                          // [4][128] step-gradient partials per column-wave
+    float* colred = fsm + 5 * BM;                      // [2][2][BN] offset-gradient partials per row-wave
+    if (tid < BM) row_a[tid] = ofq_lsq_eff_scale(p.ls[min(m0 + tid, p.M - 1) % p.lS], p.lgscale);
+    __syncthreads();
+    int ncol[NJ];
+    bool nok[NJ];
+    float b4v[NJ], cb4[NJ], cg[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      ncol[j] = n0 + wn * 32 * NJ + j * 32 + l31;
+      nok[j] = ncol[j] < p.N;
+      b4v[j] = (nok[j] && p.lb4) ? p.lb4[ncol[j]] : 0.f;
+      cb4[j] = cg[j] = 0.f;
+    }
+    int ncc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ncc[j] = min(ncol[j], p.N - 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.M) {
-          float* dst = p.C + (int64_t)m * p.ldc + n;
-          float v = acc[i][j][e] * p.alpha;
-          if (p.accumulate) v += *dst;
-          *dst = v;
+      for (int eb = 0; eb < 4; ++eb) {
+        // the 4 x NJ inputs of this row quad are loaded unconditionally (clamped addresses) before any of them is used:
+        // a load behind a per-element condition would cost one memory round trip per element
+        float xv[4][NJ];
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh, p.M - 1);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) xv[ee][j] = p.lx[(int64_t)mc * p.ldlx + ncc[j]];
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int e = eb * 4 + ee;
+          const int ml = wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
+          const int m = m0 + ml;
+          const bool mok = m < p.M;
+          const float al = row_a[ml];
+          float rds = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const bool ok = mok && nok[j];
+            const float ge = ok ? acc[i][j][e] * p.alpha : 0.f;
+            const float xin = xv[ee][j];
+            const float xe = p.lgelu ? ofq_gelu(xin) : xin;
+            float q, v;
+            ofq_lsq_quant(__fadd_rn(xe, b4v[j]), al, p.llo, p.lhi, q, v);
+            const bool inr = (v >= p.llo) && (v <= p.lhi);
+            const float dq = inr ? ofq_div(__fmul_rn(ge, al), al) : 0.f;       // autograd order: (g*a)/a
+            rds += ge * (inr ? (q - v) : q);
+            cb4[j] += dq;
+            cg[j] += ge;
+            if (ok) p.C[(int64_t)m * p.ldc + ncol[j]] = p.lgelu ? dq * ofq_gelu_grad(xin) : dq;
+          }
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) rds += __shfl_xor(rds, o, 64);      // the 32 lanes of this half-wave share the row
+          if (l31 == 0) rowred[wn * BM + ml] = rds;
         }
       }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      cb4[j] += __shfl_xor(cb4[j], 32, 64);
+      cg[j] += __shfl_xor(cg[j], 32, 64);
+      if (lh == 0) {
+        const int nl = wn * 32 * NJ + j * 32 + l31;
+        colred[(wm * 2 + 0) * BN + nl] = cb4[j];
+        colred[(wm * 2 + 1) * BN + nl] = cg[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M)
+      p.lrow[(int64_t)(m0 + tid) * p.tiles_n + tn] = (rowred[tid] + rowred[BM + tid]) + (rowred[2 * BM + tid] + rowred[3 * BM + tid]);
+    for (int idx = tid; idx < 2 * BN; idx += 512) {
+      const int ac = idx / BN, nl = idx - ac * BN;
+      if (n0 + nl < p.N)
+        p.lcol[((int64_t)tm * 2 + ac) * p.N + n0 + nl] = colred[ac * BN + nl] + colred[(2 + ac) * BN + nl];
+    }
   }
 }
 
@@ -1501,8 +1591,8 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
     const int nj = N > 256 ? 3 : 2;
     a.tiles_n = (int)ceil_div(N, 128 * nj);
     dim3 gridw((unsigned)(a.tiles_m * a.tiles_n));
-    if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3>), gridw, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
     OFQ_LAUNCH_CHECK();
     return 0;
   }
@@ -1510,6 +1600,57 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// dX GEMM + backward of the layer's input quantiser in one kernel (QLinear: x -> move_b4 -> LSQ -> move_aft -> linear,
+// qlinear.py:66-69; backward = dX_hat = dY @ W_hat, then lsq.py:571-602's autograd on (x, s, b4, baft)).
+static void nt_lsq_tiles(int64_t M, int64_t N, int64_t* tm, int64_t* tn) {
+  *tm = ceil_div(M, 128);
+  *tn = ceil_div(N, N > 256 ? 384 : 256);
+}
+
+extern "C" size_t ofq_qgemm_bf16s_nt_lsq_ws_bytes(int64_t M, int64_t N) {
+  int64_t tm, tn;
+  nt_lsq_tiles(M, N, &tm, &tn);
+  return (size_t)(M * tn + tm * 2 * N) * sizeof(float);
+}
+
+extern "C" int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const float* k_scale, float alpha, const float* x,
+                                      const float* lsq_s, int64_t S, float gscale, const float* b4, int lo, int hi, int gelu,
+                                      float* dx, float* ds, float* db4, float* dbaft, int64_t M, int64_t N, int64_t K,
+                                      int64_t lda, int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!dY || !B_bf16 || !x || !lsq_s || !dx || !ws || M <= 0 || N <= 128 || K <= 0 || S <= 0) return OFQ_EINVAL;
+  if ((K & 7) || (lda & 3) || (ldb & 7) || ldx < N || !al16(dY) || !al16(B_bf16) || (k_scale && !al16(k_scale)) ||
+      M >= (1ll << 30) || N >= (1ll << 30))
+    return OFQ_EINVAL;
+  if (ws_bytes < ofq_qgemm_bf16s_nt_lsq_ws_bytes(M, N)) return OFQ_ENOWS;
+  int64_t tm, tn;
+  nt_lsq_tiles(M, N, &tm, &tn);
+  QGemmArgs a = {};
+  a.A = dY; a.B = B_bf16; a.C = dx; a.s = k_scale;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldx; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn; a.alpha = alpha; a.nb1 = 1;
+  a.lx = x; a.ldlx = ldx; a.ls = lsq_s; a.lS = (int)S; a.lgscale = gscale; a.lb4 = b4; a.llo = (float)lo; a.lhi = (float)hi;
+  a.lgelu = gelu; a.lrow = (float*)ws; a.lcol = (float*)ws + (size_t)M * tn;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(tm * tn));
+  if (N > 256) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, true>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, true>), grid, dim3(512), 0, st, a);
+  OFQ_LAUNCH_CHECK();
+  SumJobs jobs = {};
+  int64_t maxc = 0;
+  if (ds) {
+    if (M % S) return OFQ_EINVAL;
+    jobs.j[0] = {a.lrow, ds, S, M / S, S * tn, (int)tn, gscale, 0, 0};
+    maxc = S;
+  }
+  if (db4) { jobs.j[1] = {a.lcol, db4, N, tm, 2 * N, 1, 1.0f, 0, 0}; if (N > maxc) maxc = N; }
+  if (dbaft) { jobs.j[2] = {a.lcol + N, dbaft, N, tm, 2 * N, 1, 1.0f, 0, 0}; if (N > maxc) maxc = N; }
+  if (maxc > 0) {
+    strided_sum_launch(jobs, maxc, 3, st);
+    OFQ_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -69,7 +69,17 @@ class CodesLinearFn(torch.autograd.Function):
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         dx = None
-        if ctx.needs_input_grad[0]:
+        link = aux.get("lsq_link")
+        if ctx.needs_input_grad[0] and link and "geom" in link and ctx.codes_only:
+            # the input quantiser's backward runs in the dX GEMM's epilogue; its four gradients wait in the link for
+            # _LsqFn.backward, the carrier tensor gets a zero-stride dummy gradient
+            x_in = link["x"]
+            x2 = x_in.reshape(-1, ctx.in_shape[-1])
+            res = ops.qgemm_bf16s_nt_lsq(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"], x2, link["s"], link["b4"],
+                                         link["geom"])
+            link["done"] = (res[0].view(x_in.shape), res[1], res[2], res[3])
+            dx = ops.placeholder(ctx.in_shape, dy2d.device)
+        elif ctx.needs_input_grad[0]:
             dx = ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"]).view(ctx.in_shape)
         need_db = (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None
         dW = db = None
@@ -95,14 +105,14 @@ def codes_linear_ok(in_features, wquant, act_quant):
     return (in_features % 16 == 0 and wquant.num_bits <= 7 and act_quant.thd_neg >= -128 and act_quant.thd_pos <= 127)
 
 
-def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None):
+def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None, lsq_link=None):
     """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True).
     `fuse`: see ops.qgemm_i8_nt (the next layer's input codes as a by-product of this GEMM's epilogue)."""
     Wq = wquant(weight, want_codes=True)
     aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev,
            "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
-           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse}
+           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 

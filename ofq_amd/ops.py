@@ -310,6 +310,26 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     return out
 
 
+def qgemm_bf16s_nt_lsq(dy2d, B_bf16, k_scale, alpha, x2d, s, b4, g, want_bias_grads=True):
+    """dX GEMM + LSQ backward of the layer's input quantiser in one kernel; returns (dx, ds, db4, dbaft) like lsq_bwd.
+    g: the quantiser's LsqGeom (per-token step, one offset phase)."""
+    M, K = dy2d.shape
+    N = B_bf16.shape[0]
+    dev = dy2d.device
+    dx = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ds = torch.empty_like(s)
+    has_bias = b4 is not None and want_bias_grads
+    db4 = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
+    dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
+    ws = workspace(lib().ofq_qgemm_bf16s_nt_lsq_ws_bytes(M, N), dev)
+    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+        _chk(lib().ofq_qgemm_bf16s_nt_lsq(dy2d.data_ptr(), B_bf16.data_ptr(), _p(k_scale), alpha, x2d.data_ptr(), s.data_ptr(),
+                                          g.S, g.gscale, _p(b4), g.lo, g.hi, int(g.prologue == 1), dx.data_ptr(), ds.data_ptr(),
+                                          _p(db4), _p(dbaft), M, N, K, dy2d.stride(0), B_bf16.stride(0), x2d.stride(0),
+                                          ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_lsq")
+    return dx, ds, db4, dbaft
+
+
 def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False):
     """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c];  compute_db: also returns db = colsum(dy)"""
     Ktok, M = dy2d.shape

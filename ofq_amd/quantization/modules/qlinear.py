@@ -20,6 +20,11 @@ from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
 USE_CODE_GEMM = True
 # fc1's GEMM epilogue emits fc2's input codes (A/B switch for bench runs: OFQ_NO_EPILOGUE_FUSE=1)
 FUSE_NEXT_CODES = os.environ.get("OFQ_NO_EPILOGUE_FUSE") is None
+# The input quantiser's backward can run in the epilogue of the layer's dX GEMM (ofq_qgemm_bf16s_nt_lsq: dX never
+# goes to HBM).  Correct and tested, but OFF by default: measured on MI355X it loses -- the 2-waves-per-SIMD GEMM kernel
+# executes the division-heavy LSQ arithmetic at a fraction of the rate of the 5-waves-per-SIMD elementwise kernel
+# (+75 us per GEMM launch vs 51 us for the separate kernel).  OFQ_LSQ_BWD_FUSE=1 turns it on.
+FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None
 
 
 class LSQ_input(nn.Module):
@@ -82,12 +87,14 @@ class QLinear(nn.Linear):
         if self.weight_quant_method != "statsq":
             raise ValueError("Unknown quant_method")
         if self.code_path():
+            # this quantiser has exactly one consumer (the GEMM below): its backward can ride in the dX GEMM's epilogue
+            link = {} if FUSE_LSQ_BWD else None
             xq, xcodes, geom = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias,
                                                          prologue=self._prologue, want_codes=True,
                                                          need_values=not codes_only_ok(self.in_features, self.out_features),
-                                                         pre_codes=pre_codes)
+                                                         pre_codes=pre_codes, link=link)
             return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
-                                self.statsq_fn, self.bias, fuse=fuse_next)
+                                self.statsq_fn, self.bias, fuse=fuse_next, lsq_link=link)
         weight = self.statsq_fn(self.weight)                                     # qlinear.py:62
         xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias, prologue=self._prologue)
         return LinearFn.apply(xq, weight, self.bias)                             # qlinear.py:69-71

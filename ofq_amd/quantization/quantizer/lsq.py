@@ -26,7 +26,12 @@ class _LsqFn(torch.autograd.Function):
     """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
 
     @staticmethod
-    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True, pre_codes=None):
+    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True, pre_codes=None, link=None):
+        # link: dict shared with the single consumer of the codes (CodesLinearFn); when its backward fuses this
+        # quantiser's backward into the dX GEMM epilogue it leaves the four gradients in link["done"]
+        ctx.link = link
+        if link is not None:
+            link.update(x=x, s=s, b4=b4, geom=geom)
         if pre_codes is not None:
             # the producer GEMM's epilogue already applied this quantiser (ofq_qgemm_i8_nt_q): same codes, no second pass
             assert want_codes and not need_values
@@ -44,13 +49,19 @@ class _LsqFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gcodes):
+        if ctx.link is not None and "done" in ctx.link:
+            dx, ds, db4, dbaft = ctx.link.pop("done")
+            ctx.link.clear()
+            return dx, ds, db4, dbaft, None, None, None, None, None
+        if ctx.link is not None:
+            ctx.link.clear()
         if gy is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         x, s, b4 = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx.view(x.shape), ds, db4, dbaft, None, None, None, None
+        return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None
 
 
 class _LsqBase(nn.Module):
@@ -101,7 +112,7 @@ class _LsqBase(nn.Module):
         return spec
 
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
-              want_codes=False, need_values=True, pre_codes=None):
+              want_codes=False, need_values=True, pre_codes=None, link=None):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
         is a strided column slice)."""
         if not x.is_cuda:
@@ -119,7 +130,10 @@ class _LsqBase(nn.Module):
         geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
         if pre_codes is not None and (need_values or not want_codes):
             pre_codes = None
-        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values, pre_codes)
+        if link is not None and (need_values or not want_codes or geom.mode != 0 or geom.bias_len not in (0, geom.inner)
+                                 or geom.inner <= 128 or ldx is not None or not torch.is_grad_enabled()):
+            link = None                       # the fused backward needs codes-only output, per-token step, one offset phase
+        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values, pre_codes, link)
         y = y.view(out_shape if out_shape is not None else shp)
         if want_codes:
             return y, codes, geom

@@ -375,3 +375,48 @@ def test_qkr_attention_fused_quantiser_epilogues_are_bit_identical(env):
     assert len(fused) == len(plain)
     for a, b in zip(fused, plain):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(3, 197, 384, 1536), (2, 198, 192, 768), (1, 50, 384, 384)])
+def test_qmlp_lsq_backward_in_dx_gemm_epilogue(env, dims):
+    """The input quantisers' backward fused into the dX GEMM epilogues (ofq_qgemm_bf16s_nt_lsq) against the separate
+    GEMM + ofq_lsq_bwd pair: dx bit-identical (same per-element arithmetic), the reduced gradients (ds, offsets) to
+    2e-6 (different summation order)."""
+    from ofq_amd.quantization.modules import qlinear as ql
+    from ofq_amd.quantization.modules.qlinear import QMLP
+    from ofq_amd.deit_vision_transformer import Mlp
+    torch.manual_seed(11)
+    B, N, C, Hd = dims
+    q = QMLP(m=Mlp(in_features=C, hidden_features=Hd, act_layer=nn.GELU), weight_bits=2, input_bits=2,
+             act_layer=nn.GELU, pretrained_initialized=True).cuda().train()
+    x = torch.randn(B, N, C, device="cuda")
+    with torch.no_grad():
+        q(x)
+        for nme, p in q.named_parameters():
+            if "move_" in nme:
+                p.uniform_(-0.05, 0.05)
+    w = torch.randn(B, N, C, device="cuda")
+
+    def run():
+        for p in q.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = q(xg)
+        (y * w).sum().backward()
+        return {"y": y.detach().clone(), "dx": xg.grad.clone(), **{n: p.grad.clone() for n, p in q.named_parameters()
+                                                                  if p.grad is not None}}
+
+    prev = ql.FUSE_LSQ_BWD
+    try:
+        ql.FUSE_LSQ_BWD = True
+        fused = run()
+        ql.FUSE_LSQ_BWD = False
+        plain = run()
+    finally:
+        ql.FUSE_LSQ_BWD = prev
+    assert fused.keys() == plain.keys()
+    assert torch.equal(fused["y"], plain["y"])
+    if C > 128:
+        assert torch.equal(fused["dx"], plain["dx"])
+    for k in fused:
+        assert rel_err(fused[k], plain[k]) < 2e-6, k
