@@ -55,12 +55,24 @@ struct QGemmArgs {
   float qgscale, qlo, qhi;
 };
 
-__device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& tn) {
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int tile = blockIdx.x;
-  const int q = ntiles >> 3, r = ntiles & 7;
-  const int xcd = tile & 7, loc = tile >> 3;
-  tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+// Hardware dispatch order is x-fastest and workgroup w lands on XCD w % 8 (each XCD has its own L2).  Give each XCD a
+// contiguous run of the (batch, tile) sequence, so that workgroups which share operands -- the tiles of one batch
+// element, the column tiles of one row panel -- run on the same XCD at about the same time and hit its L2 instead
+// of fetching the shared operand once per XCD (the attention dxq GEMM fetched 3x its algorithmic bytes before this).
+__device__ __forceinline__ void xcd_remap_grid(int& bx, int& by) {
+  const int nx = gridDim.x;
+  const int total = nx * gridDim.y;
+  int L = blockIdx.y * nx + blockIdx.x;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = L & 7, loc = L >> 3;
+  L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  bx = L % nx;
+  by = L / nx;
+}
+
+__device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& tn, int& by) {
+  int tile;
+  xcd_remap_grid(tile, by);
   tm = tile / p.tiles_n;
   tn = tile % p.tiles_n;
 }
@@ -74,13 +86,13 @@ template <int EPI>
 __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
-  int tm, tn;
-  qgemm_tile_id(p, tm, tn);
+  int tm, tn, gby;
+  qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
   const unsigned char* B = (const unsigned char*)p.B + b0 * p.sB0 + b1 * p.sB1;
   const int K = p.K;
@@ -292,13 +304,13 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSPLIT * PLANE + BN * QBS_LD];
-  int tm, tn;
-  qgemm_tile_id(p, tm, tn);
+  int tm, tn, gby;
+  qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const float* A = (const float*)p.A + b0 * p.sA0 + b1 * p.sA1;
   const unsigned short* B = (const unsigned short*)p.B + (B_I8 ? 0 : b0 * p.sB0 + b1 * p.sB1);
   const signed char* B8 = (const signed char*)p.B + b0 * p.sB0 + b1 * p.sB1;
@@ -487,20 +499,15 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   const int ntiles = p.tiles_m * p.tiles_n;
   // XCD-aware order: block b runs on XCD b % 8; give each XCD a contiguous run of logical ids so that the tiles which
   // share one dY panel (same split, same tm, all tn) hit the same L2 instead of re-fetching the panel per XCD
-  int lid = blockIdx.x;
-  {
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = lid & 7, loc = lid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
+  int lid, gby;
+  xcd_remap_grid(lid, gby);
   const int tile = lid % ntiles, sidx = lid / ntiles;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const bool direct = p.C != nullptr;
 
   const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
@@ -708,13 +715,8 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   constexpr int CPR = BN / 8;                 // 8-byte code chunks per k row
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int ntiles = p.tiles_m * p.tiles_n;
-  int lid = blockIdx.x;
-  {
-    const int total = gridDim.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = lid & 7, loc = lid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
+  int lid, gby;
+  xcd_remap_grid(lid, gby);
   const int tile = lid % ntiles, sidx = lid / ntiles;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   const int tps = (nkt + p.split - 1) / p.split;
   const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
 
-  const int b0 = blockIdx.y / p.nb1, b1 = blockIdx.y % p.nb1;
+  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const bool direct = p.C != nullptr;                       // batched, un-split: C written here (attention dqkx)
   const int a_k = tid >> 5, a_t = (tid & 31) * 4;          // rows a_k, a_k + 16
   const bool a_ok = (m0 + a_t) < p.M;
@@ -1060,10 +1062,10 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
   constexpr int PLANE_A = BM * QBS_LD;              // [row][k] bf16, 80 B rows
   constexpr int PLANE_B = QTN_BK * QTN_LD;          // [k][c]  bf16, 320 B rows
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + PLANE_B];
-  const int tile = blockIdx.x;
+  int tile, b0;
+  xcd_remap_grid(tile, b0);
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * 128;
-  const int b0 = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -1331,8 +1333,8 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   constexpr int STAGE = NS * PLANE + BN * QBS_LD;
   constexpr int NB = NJ;                               // 16-byte chunks of the weight tile per thread (BN*4/512)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  int tm, tn;
-  qgemm_tile_id(p, tm, tn);
+  int tm, tn, gby;
+  qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
