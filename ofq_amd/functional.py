@@ -139,9 +139,12 @@ class WqkFn(torch.autograd.Function):
         dWq = torch.empty_like(Wq)
         dWk = torch.empty_like(Wk)
         # dWq[h][j,c] = sum_c' Wk[h][j,c'] g[h][c,c']      (NT)
-        ops.gemm(Wk, g, dWq, d, C, C, C, C, C, transB=True, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0))
+        # d = 64 rows per head: 64x64 tiles (the 128x128 default leaves half of every tile empty: 43 -> 17 us each)
+        ops.gemm(Wk, g, dWq, d, C, C, C, C, C, transB=True, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
         # dWk[h][j,c'] = sum_c Wq[h][j,c] g[h][c,c']       (NN)
-        ops.gemm(Wq, g, dWk, d, C, C, C, C, C, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0))
+        ops.gemm(Wq, g, dWk, d, C, C, C, C, C, nb0=H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
         return dWq, dWk, None
 
 
