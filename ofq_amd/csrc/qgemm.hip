@@ -1670,6 +1670,40 @@ __global__ __launch_bounds__(256) void rowdot_i8_multi_kernel(const int8_t* __re
   }
 }
 
+// same, 16 lanes per row and 16 codes per load; the row's codes stay in registers for all V vectors (K <= 512)
+__global__ __launch_bounds__(256) void rowdot_i8_multi_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vecs,
+                                                                  float* __restrict__ out, int R, int K, int V) {
+  const int l16 = threadIdx.x & 15;
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool rok = r < R;
+  i32x4 c[2];
+  bool cok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = (l16 + 16 * u) * 16;
+    cok[u] = rok && k < K;
+    c[u] = cok[u] ? *reinterpret_cast<const i32x4*>(codes + (int64_t)r * K + k) : i32x4{0, 0, 0, 0};
+  }
+  for (int v = 0; v < V; ++v) {
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!cok[u]) continue;
+      const float* vp = vecs + (int64_t)v * K + (l16 + 16 * u) * 16;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 f = *reinterpret_cast<const float4*>(vp + 4 * w);
+        const int word = c[u][w];
+        acc += f.x * (float)(signed char)(word & 0xff) + f.y * (float)(signed char)((word >> 8) & 0xff) +
+               f.z * (float)(signed char)((word >> 16) & 0xff) + f.w * (float)(word >> 24);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (rok && l16 == 0) out[(int64_t)r * V + v] = acc;
+  }
+}
+
 // out[r][h] = sum_{c<d} x[r][h*d + c] * vec[h*d + c]      (per-head dot of an fp32 row with an offset vector)
 __global__ __launch_bounds__(256) void rowdot_f32_seg_kernel(const float* __restrict__ x, const float* __restrict__ vec,
                                                              float* __restrict__ out, int R, int H, int d, int64_t ld) {
@@ -1706,8 +1740,12 @@ __global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* _
 extern "C" int ofq_rowdot_i8_multi(const int8_t* codes, const float* vecs, float* out, int64_t rows, int64_t cols, int nvec,
                                    ofq_stream_t stream) {
   if (!codes || !vecs || !out || rows <= 0 || cols <= 0 || nvec <= 0) return OFQ_EINVAL;
-  hipLaunchKernelGGL(rowdot_i8_multi_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vecs,
-                     out, (int)rows, (int)cols, nvec);
+  if ((cols & 15) == 0 && cols <= 512 && al16(codes) && al16(vecs))
+    hipLaunchKernelGGL(rowdot_i8_multi_v16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, codes,
+                       vecs, out, (int)rows, (int)cols, nvec);
+  else
+    hipLaunchKernelGGL(rowdot_i8_multi_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vecs,
+                       out, (int)rows, (int)cols, nvec);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
