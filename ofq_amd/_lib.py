@@ -80,6 +80,10 @@ def load():
         except Exception as e:  # noqa: BLE001
             raise RuntimeError("ofq_amd: %s is missing and could not be built (%s). "
                                "Run `python -m ofq_amd.build`; there is no CPU fallback." % (LIB_PATH, e))
+    # PyTorch-ROCm ships its own libamdhip64; it has to be in the process BEFORE this library is mapped, otherwise the
+    # loader binds our kernels to /opt/rocm's copy and every launch fails with hipErrorNoDevice (two HIP runtimes, the
+    # streams and allocations belong to torch's).  Importing torch first makes the soname resolve to the loaded one.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
