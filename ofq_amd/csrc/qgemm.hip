@@ -1184,20 +1184,45 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
     __syncthreads();
   }
   float* Cb = p.C + b0 * p.sC0;
+  if (!p.accumulate) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= p.N) continue;
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M) Cb[(int64_t)m * p.ldc + n] = acc[i][j][e];
+        }
+    }
+  } else {      // old values fetched unconditionally on clamped addresses, eight at a time (see the wide dX kernel)
+    int ncc[2];
+    bool nok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      nok[j] = n < p.N;
+      ncc[j] = min(n, p.N - 1);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.M) {
-          float* dst = Cb + (int64_t)m * p.ldc + n;
-          float v = acc[i][j][e];
-          if (p.accumulate) v += *dst;
-          *dst = v;
+      for (int eb = 0; eb < 4; ++eb) {
+        float old[4][2];
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh, p.M - 1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) old[ee][j] = Cb[(int64_t)mc * p.ldc + ncc[j]];
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (m < p.M && nok[j]) Cb[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] + old[ee][j];
         }
       }
   }
@@ -1478,20 +1503,47 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   }
 
   if constexpr (!LSQ) {
+    if (!p.accumulate) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * 32 * NJ + j * 32 + l31;
-      if (n >= p.N) continue;
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[i][j][e] * p.alpha;
+          }
+      }
+    } else {
+      // C += ...: the old values are fetched unconditionally (clamped addresses), a quad of rows at a time, so that no
+      // load sits behind a per-element condition (that costs one memory round trip per element)
+      int ncc[NJ];
+      bool nok[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + l31;
+        nok[j] = n < p.N;
+        ncc[j] = min(n, p.N - 1);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m < p.M) {
-            float* dst = p.C + (int64_t)m * p.ldc + n;
-            float v = acc[i][j][e] * p.alpha;
-            if (p.accumulate) v += *dst;
-            *dst = v;
+        for (int eb = 0; eb < 4; ++eb) {
+          float old[4][NJ];
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee) {
+            const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) old[ee][j] = p.C[(int64_t)mc * p.ldc + ncc[j]];
+          }
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee) {
+            const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * p.alpha + old[ee][j];
           }
         }
     }

@@ -39,6 +39,22 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(ctx.in_shape) if dx is not None else None), dW, db
 
 
+def _shared_grad(acc, shape, device):
+    """Gradient buffer of a tensor with several consumers (x_hat of the QKR attention feeds the v GEMM, the W_qk GEMM and
+    the scores): the first backward to run allocates it and returns it to autograd, the later ones accumulate into it
+    in place (their GEMMs have an accumulate flag) and return None, so autograd never launches an add kernel.
+    Returns (buffer, accumulate, value_to_return).  acc is a per-forward dict or None."""
+    if acc is None:
+        buf = torch.empty(shape, dtype=torch.float32, device=device)
+        return buf, False, buf
+    buf = acc.get("buf")
+    if buf is None:
+        buf = torch.empty(shape, dtype=torch.float32, device=device)
+        acc["buf"] = buf
+        return buf, False, buf
+    return buf, True, None
+
+
 class CodesLinearFn(torch.autograd.Function):
     """Same function as LinearFn, computed on the integer codes: forward is one exact int8-MFMA GEMM with the
     scales applied in the epilogue (ofq_qgemm_i8_nt), dX is the 3-way bf16-split GEMM against the transposed
@@ -80,7 +96,10 @@ class CodesLinearFn(torch.autograd.Function):
             link["done"] = (res[0].view(x_in.shape), res[1], res[2], res[3])
             dx = ops.placeholder(ctx.in_shape, dy2d.device)
         elif ctx.needs_input_grad[0]:
-            dx = ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"]).view(ctx.in_shape)
+            K_in0 = ctx.in_shape[-1]
+            buf, accumulate, dx = _shared_grad(aux.get("xgrad_acc"), ctx.in_shape, dy2d.device)
+            ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"], out=buf.view(-1, K_in0),
+                               accumulate=accumulate)
         need_db = (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None
         dW = db = None
         N_out, K_in = dy2d.shape[1], ctx.in_shape[-1]
@@ -105,14 +124,14 @@ def codes_linear_ok(in_features, wquant, act_quant):
     return (in_features % 16 == 0 and wquant.num_bits <= 7 and act_quant.thd_neg >= -128 and act_quant.thd_pos <= 127)
 
 
-def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None, lsq_link=None):
+def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None, lsq_link=None, xgrad_acc=None):
     """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True).
     `fuse`: see ops.qgemm_i8_nt (the next layer's input codes as a by-product of this GEMM's epilogue)."""
     Wq = wquant(weight, want_codes=True)
     aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev,
            "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
-           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link}
+           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 
@@ -341,13 +360,14 @@ class QKRScoresCodesFn(torch.autograd.Function):
         B, H, N, C, Np = ctx.dims
         dS = dS.contiguous()
         dqkx = ops.qattn_dqkx(dS, aux["xcodes"], aux["sx"], aux["gx"], aux["bax"], B, H, N, C, Np)
-        dxq = ops.qattn_dxq(dS, aux["qcodes"], aux["sq"], aux["gq"], B, H, N, C, Np)
+        dxq, accumulate, ret = _shared_grad(aux.get("xgrad_acc"), (B, N, C), dS.device)
+        ops.qattn_dxq(dS, aux["qcodes"], aux["sq"], aux["gq"], B, H, N, C, Np, out=dxq, accumulate=accumulate)
         rs = aux["link"].pop("ds_rowsum", None)
         if rs is None:
             rs = dS[..., :N].sum(-1).reshape(-1)
         # + sum_h rowsum_m(dS)[b,h,n] * baq[h,c]   (zero in exact arithmetic)
         dxq.view(B * N, C).addmm_(rs.view(B, H, N).permute(0, 2, 1).reshape(B * N, H), aux["baq"].view(H, C))
-        return dxq, dqkx, None
+        return ret, dqkx, None
 
 
 class SoftmaxLsqCodesFn(torch.autograd.Function):

@@ -179,8 +179,10 @@ def qkr_attention_core(self, x, scale, addend=None):
             fuse_ok = attn_codes and _ql.FUSE_NEXT_CODES
             vspec = self.quan_a_v_fn.fusable((B, N, C), self.move_v_b4.bias, 0) if fuse_ok else None
             qspec = self.quan_a_qkx_fn.fusable((B, N * H, C), self.move_qkx_b4.bias, 0) if fuse_ok else None
+            # x_hat has three consumers (v GEMM, W_qk GEMM, scores): their backward passes accumulate into one buffer
+            xacc = {} if (attn_codes and torch.is_grad_enabled()) else None
             v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
-                             self.v.bias, fuse=vspec)                            # :179-181
+                             self.v.bias, fuse=vspec, xgrad_acc=xacc)            # :179-181
         else:
             xq = xin(x)
             v = LinearFn.apply(xq, self.v_quant(self.v.weight), self.v.bias)
@@ -194,7 +196,7 @@ def qkr_attention_core(self, x, scale, addend=None):
         Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
         if use_codes:
             qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None,
-                               fuse=qspec)
+                               fuse=qspec, xgrad_acc=xacc)
         else:
             qkx = LinearFn.apply(xq, self.qk_quant(Wqk_fp), None)                # (B, N, H*C)   einsum :200
         if not attn_codes:
@@ -212,7 +214,7 @@ def qkr_attention_core(self, x, scale, addend=None):
             S = QKRScoresCodesFn.apply(xq, qkx, {
                 "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,
                 "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
-                "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link})   # :210
+                "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link, "xgrad_acc": xacc})   # :210
             sm = self.quan_a_softmax_fn
             addend = _fit_addend(addend, S)
             _softmax_init(sm, S, N, scale, addend)
