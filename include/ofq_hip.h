@@ -38,6 +38,11 @@ int ofq_abi_version(void);
  *  the exact integer operand of ofq_qgemm_i8_nt.  Backward is the identity (STE, statsq.py:148): no kernel. */
 int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
                    int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream);
+/*  The code path of the quantised linear layers in one launch: scale, the odd int8 codes 2L+1 [rows][cols], optionally
+ *  the fake-quant values (out may be NULL), the codes transposed as bf16 [cols][rows] (operand of the dX GEMM) and
+ *  rout[row] = sum_k rvec[k] * code[row][k] (the offset term of ofq_qgemm_i8_nt: rvec = the layer's move_aft). */
+int ofq_statsq_codes_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* codes,
+                         void* codesT_bf16, const float* rvec, float* rout, ofq_stream_t stream);
 
 /* ---- K3/K5  LSQ activation quantiser with its LearnableBias sandwich:
  *  LsqQuantizer.forward lsq.py:571-602 (+ :72-101, :336-373, :419-437, :489-505), LsqQuantizer4v.forward

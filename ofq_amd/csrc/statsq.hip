@@ -8,7 +8,9 @@
 __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict__ W, int64_t rows, int64_t cols,
                                                          float n, float* __restrict__ out,
                                                          float* __restrict__ scale, int8_t* __restrict__ levels,
-                                                         int scale_given, int odd_codes) {
+                                                         int scale_given, int odd_codes,
+                                                         unsigned short* __restrict__ codesT, const float* __restrict__ rvec,
+                                                         float* __restrict__ rout) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -35,8 +37,13 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
     if (lane == 0) scale[row] = s;
   }
   const float cmax = 1.0f - 1e-6f;                  // (clip_val/2) - 1e-6 in fp32      statsq.py:145
-  float* o = out + row * cols;
+  float* o = out ? out + row * cols : nullptr;
   int8_t* lv = levels ? levels + row * cols : nullptr;
+  float racc = 0.f;                                 // sum_k rvec[k] * code[row][k]  (offset term of the int8 GEMM)
+  auto side = [&](int64_t k, float code) {          // by-products of the code path: transposed bf16 codes, row dot
+    if (codesT) codesT[k * rows + row] = (unsigned short)(__float_as_uint(code) >> 16);   // small integers: exact in bf16
+    if (rvec) racc += rvec[k] * code;
+  };
   auto q1 = [&](float wv, float& L) -> float {
     float v = ofq_div(wv, s);                       // statsq.py:144
     float c = fminf(fmaxf(v, -1.0f), cmax);         // :145
@@ -51,30 +58,52 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
       float4 t = w4[i], r;
       float L0, L1, L2, L3;
       r.x = q1(t.x, L0); r.y = q1(t.y, L1); r.z = q1(t.z, L2); r.w = q1(t.w, L3);
-      o4[i] = r;
+      if (o) o4[i] = r;
       if (lv) {
         if (odd_codes) { L0 = 2.f * L0 + 1.f; L1 = 2.f * L1 + 1.f; L2 = 2.f * L2 + 1.f; L3 = 2.f * L3 + 1.f; }
         char4 c4 = make_char4((signed char)L0, (signed char)L1, (signed char)L2, (signed char)L3);
         reinterpret_cast<char4*>(lv)[i] = c4;
+        side(4 * i, L0); side(4 * i + 1, L1); side(4 * i + 2, L2); side(4 * i + 3, L3);
       }
     }
   } else {
     for (int64_t i = lane; i < cols; i += 64) {
       float L;
-      o[i] = q1(w[i], L);
-      if (lv) lv[i] = (int8_t)(odd_codes ? 2.f * L + 1.f : L);
+      const float wq = q1(w[i], L);
+      if (o) o[i] = wq;
+      if (lv) {
+        const float code = odd_codes ? 2.f * L + 1.f : L;
+        lv[i] = (int8_t)code;
+        side(i, code);
+      }
     }
+  }
+  if (rout) {
+    racc = ofq_wave_sum(racc);
+    if (lane == 0) rout[row] = racc;
   }
 }
 
-extern "C" int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
-                              int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream) {
-  if (!W || !out || !scale || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
+static int statsq_launch(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* levels,
+                         int scale_given, int odd_codes, void* codesT, const float* rvec, float* rout, ofq_stream_t stream) {
+  if (!W || !scale || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
   if (odd_codes && bits > 7) return OFQ_EINVAL;       // 2L+1 must fit int8
   float n = (float)(1 << (bits - 1));
   dim3 grid((unsigned)((rows + 3) / 4));
   hipLaunchKernelGGL(statsq_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, rows, cols, n, out, scale,
-                     levels, scale_given, odd_codes);
+                     levels, scale_given, odd_codes, (unsigned short*)codesT, rvec, rout);
   OFQ_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
+                              int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream) {
+  if (!out) return OFQ_EINVAL;
+  return statsq_launch(W, rows, cols, bits, out, scale, levels, scale_given, odd_codes, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ofq_statsq_codes_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
+                                    int8_t* codes, void* codesT_bf16, const float* rvec, float* rout, ofq_stream_t stream) {
+  if (!codes || (rvec && !rout)) return OFQ_EINVAL;
+  return statsq_launch(W, rows, cols, bits, out, scale, codes, 0, 1, codesT_bf16, rvec, rout, stream);
 }

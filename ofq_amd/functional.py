@@ -67,7 +67,9 @@ class CodesLinearFn(torch.autograd.Function):
         shp = xq.shape
         K = shp[-1]
         x2d = xq.reshape(-1, K)
-        r = ops.rowdot_i8(aux["wcodes"], aux["baft"]) if aux["baft"] is not None else None
+        r = aux.get("r")
+        if r is None and aux["baft"] is not None:
+            r = ops.rowdot_i8(aux["wcodes"], aux["baft"])
         y = ops.qgemm_i8_nt(aux["xcodes"].view(-1, K), aux["wcodes"], bias, aux["w_scale"], aux["w_mult"], r,
                             aux["act_s"], aux["act_S"], aux["act_gscale"], fuse=aux.get("fuse"))
         ctx.codes_only = xq.stride(-1) == 0           # x_hat exists only as codes (placeholder carrier tensor)
@@ -127,8 +129,9 @@ def codes_linear_ok(in_features, wquant, act_quant):
 def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=None, lsq_link=None, xgrad_acc=None):
     """y = xq @ StatsQ(weight)^T + bias on the integer codes.  xq/xcodes/geom come from LsqQuantizer.quant(want_codes=True).
     `fuse`: see ops.qgemm_i8_nt (the next layer's input codes as a by-product of this GEMM's epilogue)."""
-    Wq = wquant(weight, want_codes=True)
-    aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev,
+    bvec = baft.detach() if baft is not None else None
+    Wq = wquant(weight, want_codes=True, rvec=bvec, need_values=False)
+    aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev, "r": wquant._r,
            "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
            "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc}

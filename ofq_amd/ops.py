@@ -124,6 +124,25 @@ def statsq_fwd(W, bits, want_levels=False, scale=None, odd_codes=False):
     return out, s, lv
 
 
+def statsq_codes_fwd(W, bits, rvec=None, need_values=True, want_T=True):
+    """One launch for the code path of a quantised linear layer: returns (Wq or placeholder, scale, codes int8 [out][in],
+    codesT bf16 [in][out] or None, r[out] = codes @ rvec or None)."""
+    _dev(W, "weight")
+    W = W.contiguous()
+    rows, cols = W.shape
+    dev = W.device
+    out = torch.empty_like(W) if need_values else None
+    s = torch.empty(rows, dtype=torch.float32, device=dev)
+    codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+    codesT = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev) if want_T else None
+    r = torch.empty(rows, dtype=torch.float32, device=dev) if rvec is not None else None
+    _chk(lib().ofq_statsq_codes_fwd(W.data_ptr(), rows, cols, bits, _p(out), s.data_ptr(), codes.data_ptr(), _p(codesT),
+                                    _p(rvec), _p(r), _stream()), "ofq_statsq_codes_fwd")
+    if out is None:
+        out = placeholder((rows, cols), dev)
+    return out, s, codes, codesT, r
+
+
 # ------------------------------------------------------------------------------------------------ LSQ
 class LsqGeom:
     """How a tensor maps onto the kernel's [outer][S][inner] view (include/ofq_hip.h, ofq_lsq_fwd)."""

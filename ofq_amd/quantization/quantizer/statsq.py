@@ -9,7 +9,15 @@ from ... import ops
 
 class _StatsQFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, bits, holder, want_codes):
+    def forward(ctx, weight, bits, holder, want_codes, rvec=None, need_values=True, want_T=False):
+        holder._r = None
+        if want_codes and (rvec is not None or not need_values):
+            # code path of a linear layer: scale, codes, transposed bf16 codes and the offset row-dot in ONE launch;
+            # the fp32 fake-quant values are not written (nothing reads them), a zero-stride tensor carries the edge
+            out, s, codes, codesT, r = ops.statsq_codes_fwd(weight, bits, rvec=rvec, need_values=need_values,
+                                                            want_T=want_T)
+            holder._s_dev, holder._codes, holder._codesT, holder._r = s, codes, codesT, r
+            return out
         out, s, codes = ops.statsq_fwd(weight, bits, want_levels=want_codes, odd_codes=want_codes)
         holder._s_dev = s
         holder._codes = codes                      # int8 (2L+1), [out][in]: operand of the exact i8 forward GEMM
@@ -18,7 +26,7 @@ class _StatsQFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, None, None, None    # statsq.py:148: Wq.detach() - W.detach() + W  => dW = g
+        return g, None, None, None, None, None, None    # statsq.py:148: Wq.detach() - W.detach() + W  => dW = g
 
 
 class StatsQuantizer(nn.Module):
@@ -29,6 +37,7 @@ class StatsQuantizer(nn.Module):
         self._s_dev = None
         self._codes = None
         self._codesT = None
+        self._r = None
 
     def codes_T(self):
         """Weight codes transposed to [in][out] as bf16 (exact small integers) for dX = dY @ W_hat."""
@@ -42,10 +51,14 @@ class StatsQuantizer(nn.Module):
         call, statsq.py:143; here the copy happens only when somebody reads it)."""
         return None if self._s_dev is None else self._s_dev.detach().cpu()
 
-    def forward(self, weight, want_codes=False):
+    def forward(self, weight, want_codes=False, rvec=None, need_values=True):
+        """rvec / need_values: only meaningful with want_codes (see _StatsQFn.forward)."""
         if weight.dim() != 2:
             raise ValueError("StatsQuantizer: only 2-D weights are on the hot path (statsq.py:137-138)")
-        return _StatsQFn.apply(weight, self.num_bits, self, bool(want_codes) and self.num_bits <= 7)
+        wc = bool(want_codes) and self.num_bits <= 7
+        # (grad mode is off inside Function.forward, so whether the backward operand is wanted is decided here)
+        return _StatsQFn.apply(weight, self.num_bits, self, wc, rvec if wc else None, need_values or not wc,
+                               torch.is_grad_enabled())
 
     def extra_repr(self):
         return "num_bits=%d" % self.num_bits
