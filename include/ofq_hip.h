@@ -208,6 +208,16 @@ int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
                       const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, int64_t ldx,
                       int64_t ldy, void* ws, size_t ws_bytes, ofq_stream_t stream);
 
+/* ---- AdamW over many tensors in one launch (train.py:662, :933: timm create_optimizer_v2 -> torch.optim.AdamW), with
+ *  the CGA freeze folded in (cga.py:962-964, :994-997): where frozen[i] != 0 the gradient is masked before the moment
+ *  updates and the weight is left untouched.  `tensors` is a HOST array of n_tensors entries
+ *  {float* p; const float* g; float* m; float* v; const float* frozen_or_NULL; int64_t n} (device pointers inside); the
+ *  descriptors travel in kernel arguments, 40 tensors per launch.  Per element:
+ *  p *= 1 - lr*wd; m += (g - m)(1 - b1); v = b2 v + (1 - b2) g^2; p -= (lr / bc1) m / (sqrt(v)/sqrt(bc2) + eps). */
+int64_t ofq_adamw_tensor_entry_bytes(void);
+int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps, float weight_decay,
+                    double bias_correction1, double bias_correction2, ofq_stream_t stream);
+
 /* ---- K16  CGA: freeze_outside_boundary_weight_idx cga.py:450-469 and the step hooks cga.py:962-964,
  *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */
 int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, int bits, float boundary_range,

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFQ_HIP_LIB") or os.path.join(_HERE, "lib", "libofq_hip.so")   # override: kernel experiments only
 
 i64, i32, f32, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+f64 = C.c_double
 
 
 class GemmDesc(C.Structure):
@@ -61,6 +62,8 @@ SIGNATURES = {
     "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp]),
     "ofq_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp]),
+    "ofq_adamw_tensor_entry_bytes": (i64, []),
+    "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
     "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
     "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),

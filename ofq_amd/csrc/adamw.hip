@@ -1,0 +1,100 @@
+// AdamW step over many tensors in one launch (timm create_optimizer_v2 -> torch.optim.AdamW,
+// train.py:662, 933), with the CGA weight freeze folded in (cga.py:953-1013): where frozen[i] != 0 the gradient is
+// masked before the moment updates (cga.py:962) and the weight keeps its value (save :964 + restore :994-997 = no write).
+// HBM-bound: 16 B read + 12 B written per parameter (p, g, m, v -> p, m, v).
+//
+// torch.optim.AdamW (single-tensor form, amsgrad = maximize = False), per element:
+//   p <- p * (1 - lr * wd);  m <- m + (g - m) * (1 - b1);  v <- b2 * v + (1 - b2) * g * g;
+//   p <- p - (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),   bc1 = 1 - b1^t, bc2 = 1 - b2^t
+#include "common.h"
+
+struct AdamWTensor {       // one entry per parameter tensor (host array handed to ofq_adamw_multi)
+  float* p; const float* g; float* m; float* v; const float* frozen;
+  int64_t n;
+};
+
+#define ADAMW_CHUNK 16384          // elements per workgroup
+#define ADAMW_PACK 40              // tensors per launch: their descriptors travel in the kernel arguments (no device table,
+                                   // no host-to-device copy, nothing to keep alive)
+struct AdamWPack {
+  AdamWTensor t[ADAMW_PACK];
+  int32_t first_chunk[ADAMW_PACK + 1];     // prefix sums of the chunk counts
+  int32_t n;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, float lr, float omb1, float b2, float omb2, float eps,
+                                                          float wd, float bc1, float sqrt_bc2) {
+  int ti = 0;
+  while (ti + 1 < pk.n && (int)blockIdx.x >= pk.first_chunk[ti + 1]) ++ti;
+  const AdamWTensor t = pk.t[ti];
+  const int64_t start = (int64_t)((int)blockIdx.x - pk.first_chunk[ti]) * ADAMW_CHUNK;
+  const int64_t end = min(t.n, start + (int64_t)ADAMW_CHUNK);
+  const float decay = 1.0f - lr * wd;
+  const float step = lr / bc1;
+  // omb1 = 1 - beta1, omb2 = 1 - beta2 are formed in double on the host (1.0f - 0.999f is off by 5e-5 relative)
+  const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v | (uintptr_t)t.frozen) & 15) == 0;
+  auto one = [&](float& p, float g, float& m, float& v, float f) {
+    const bool frz = f != 0.f;
+    if (frz) g = 0.f;                                    // grad * (1 - frozen), frozen in {0, 1}
+    m = m + (g - m) * omb1;
+    v = b2 * v + omb2 * g * g;
+    if (!frz) {
+      const float pd = p * decay;
+      p = pd - step * (m / (sqrtf(v) / sqrt_bc2 + eps));
+    }
+  };
+  if (vec) {
+    const int64_t n4 = (end - start) / 4;
+    float4* p4 = reinterpret_cast<float4*>(t.p + start);
+    const float4* g4 = reinterpret_cast<const float4*>(t.g + start);
+    float4* m4 = reinterpret_cast<float4*>(t.m + start);
+    float4* v4 = reinterpret_cast<float4*>(t.v + start);
+    const float4* f4 = t.frozen ? reinterpret_cast<const float4*>(t.frozen + start) : nullptr;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+      const float4 f = f4 ? f4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      one(p.x, g.x, m.x, v.x, f.x); one(p.y, g.y, m.y, v.y, f.y); one(p.z, g.z, m.z, v.z, f.z); one(p.w, g.w, m.w, v.w, f.w);
+      p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    for (int64_t i = start + n4 * 4 + threadIdx.x; i < end; i += 256) {
+      float p = t.p[i], m = t.m[i], v = t.v[i];
+      one(p, t.g[i], m, v, t.frozen ? t.frozen[i] : 0.f);
+      t.p[i] = p; t.m[i] = m; t.v[i] = v;
+    }
+  } else {
+    for (int64_t i = start + threadIdx.x; i < end; i += 256) {
+      float p = t.p[i], m = t.m[i], v = t.v[i];
+      one(p, t.g[i], m, v, t.frozen ? t.frozen[i] : 0.f);
+      t.p[i] = p; t.m[i] = m; t.v[i] = v;
+    }
+  }
+}
+
+extern "C" int64_t ofq_adamw_tensor_entry_bytes(void) { return (int64_t)sizeof(AdamWTensor); }
+
+// tensors: HOST array of n_tensors entries {p, g, m, v, frozen (or NULL), n} with device pointers inside
+extern "C" int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps,
+                               float weight_decay, double bias_correction1, double bias_correction2, ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
+  const AdamWTensor* ts = (const AdamWTensor*)tensors;
+  const float sq2 = (float)sqrt(bias_correction2);
+  for (int64_t base = 0; base < n_tensors; base += ADAMW_PACK) {
+    AdamWPack pk = {};
+    pk.n = (int32_t)((n_tensors - base < ADAMW_PACK) ? (n_tensors - base) : ADAMW_PACK);
+    int64_t chunks = 0;
+    for (int i = 0; i < pk.n; ++i) {
+      pk.t[i] = ts[base + i];
+      if (!pk.t[i].p || !pk.t[i].g || !pk.t[i].m || !pk.t[i].v || pk.t[i].n < 0) return OFQ_EINVAL;
+      pk.first_chunk[i] = (int32_t)chunks;
+      chunks += ceil_div(pk.t[i].n, ADAMW_CHUNK);
+      if (chunks >= (1ll << 31)) return OFQ_EINVAL;
+    }
+    pk.first_chunk[pk.n] = (int32_t)chunks;
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, pk, lr,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay,
+                       (float)bias_correction1, sq2);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}

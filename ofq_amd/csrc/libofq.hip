@@ -8,3 +8,4 @@ extern "C" int ofq_abi_version(void) { return OFQ_ABI_VERSION; }
 #include "qgemm.hip"
 #include "layernorm.hip"
 #include "misc.hip"
+#include "adamw.hip"

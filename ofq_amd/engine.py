@@ -3,6 +3,8 @@ train.py:386-426), setup_alpha (train.py:997-1010), optimizer with timm's no-wei
 (create_optimizer_v2, train.py:662), one training step (train.py:893-933) and the CGA hooks (cga.py:953-1013)."""
 from types import SimpleNamespace
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -103,10 +105,18 @@ def param_groups_weight_decay(model, weight_decay, skip=()):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-def make_optimizer(model, lr=5.47e-4, weight_decay=0.05, fused=None):
+def make_optimizer(model, lr=5.47e-4, weight_decay=0.05, fused=None, hip=None):
+    """AdamW with timm's no-decay split.  On a HIP device the multi-tensor kernel of csrc/adamw.hip (ofq_amd.optim.FusedAdamW,
+    same rule / state dict as torch.optim.AdamW, CGA freeze folded in); hip=False selects torch's own fused AdamW."""
     groups = param_groups_weight_decay(model, weight_decay)
+    on_dev = next(model.parameters()).is_cuda
+    if hip is None:
+        hip = on_dev and os.environ.get("OFQ_TORCH_ADAMW") is None
+    if hip:
+        from .optim import FusedAdamW
+        return FusedAdamW(groups, lr=lr, weight_decay=weight_decay)
     if fused is None:
-        fused = next(model.parameters()).is_cuda
+        fused = on_dev
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
@@ -136,17 +146,27 @@ class CGAHooks:
         self.state = {}
 
     @torch.no_grad()
-    def before_step(self):
+    def before_step(self, optimizer=None):
+        """optimizer: a FusedAdamW takes the masks itself (gradient mask + weight restore inside its one pass); any other
+        optimizer gets the reference's three-kernel sequence around its step."""
+        self._folded = optimizer is not None and hasattr(optimizer, "set_frozen")
         for k, m in self.mods:
             frz = ops.cga_freeze_mask(m.weight.data, self.bits, self.br)           # cga.py:960
-            saved = ops.cga_mask_grad_save(m.weight.grad, m.weight.data, frz)      # :962-964
-            self.state[k] = (frz, saved)
+            if self._folded:
+                optimizer.set_frozen(m.weight, frz)
+                self.state[k] = (frz, None)
+            else:
+                saved = ops.cga_mask_grad_save(m.weight.grad, m.weight.data, frz)  # :962-964
+                self.state[k] = (frz, saved)
 
     @torch.no_grad()
-    def after_step(self):
+    def after_step(self, optimizer=None):
         for k, m in self.mods:
             frz, saved = self.state[k]
-            ops.cga_restore(m.weight.data, frz, saved)                             # :994-997
+            if saved is not None:
+                ops.cga_restore(m.weight.data, frz, saved)                         # :994-997
+        if getattr(self, "_folded", False) and optimizer is not None:
+            optimizer.clear_frozen()
         self.state.clear()
 
 
@@ -163,8 +183,8 @@ def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=N
     if dp is not None:
         dp.finish_gradient_sync()
     if cga is not None:
-        cga.before_step()
+        cga.before_step(optimizer)
     optimizer.step()
     if cga is not None:
-        cga.after_step()
+        cga.after_step(optimizer)
     return loss

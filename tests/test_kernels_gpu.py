@@ -549,3 +549,51 @@ def test_layernorm_autograd_functions_match_torch(ops):
     x.grad = None
     (norm2(x) * w).sum().backward()
     assert rel_err(g1, x.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ AdamW (+ CGA freeze)
+def test_fused_adamw_matches_torch_adamw_and_cga_sequence(ops):
+    """ofq_adamw_multi against torch.optim.AdamW on the CPU (the optimiser the reference gets from timm, train.py:662)
+    over several steps with the two timm parameter groups; with a CGA mask it must equal the reference's
+    mask-grad / step / restore sequence (cga.py:962-964, :986, :994-997).  Tolerance 2e-6 (fp32 op order)."""
+    from ofq_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(384, 384), (1536, 384), (384,), (7,), (3, 5, 16, 16), (100003,)]
+    cpu = [torch.randn(*s) for s in shapes]
+    ref_p = [t.clone().requires_grad_(True) for t in cpu]
+    dev_p = [t.clone().cuda().requires_grad_(True) for t in cpu]
+    groups = lambda ps: [{"params": [p for p in ps if p.dim() <= 1], "weight_decay": 0.0},        # noqa: E731
+                         {"params": [p for p in ps if p.dim() > 1], "weight_decay": 0.05}]
+    ref = torch.optim.AdamW(groups(ref_p), lr=5.47e-4, weight_decay=0.05)
+    opt = FusedAdamW(groups(dev_p), lr=5.47e-4, weight_decay=0.05)
+    frz_cpu = (torch.rand(384, 384) < 0.3).float()
+    for it in range(4):
+        lr = 5.47e-4 * (1.0 - 0.1 * it)
+        for g1, g2 in zip(ref.param_groups, opt.param_groups):
+            g1["lr"] = g2["lr"] = lr
+        grads = [torch.randn(*s) * (0.1 if it % 2 else 1e-3) for s in shapes]
+        for p, q, g in zip(ref_p, dev_p, grads):
+            p.grad = g.clone()
+            q.grad = g.clone().cuda()
+        use_cga = it >= 2
+        if use_cga:       # reference sequence on the CPU side
+            ref_p[0].grad.mul_(1.0 - frz_cpu)
+            saved = ref_p[0].detach() * frz_cpu
+            opt.set_frozen(dev_p[0], frz_cpu.cuda())
+        ref.step()
+        opt.step()
+        if use_cga:
+            with torch.no_grad():
+                ref_p[0].copy_(ref_p[0] * (1.0 - frz_cpu) + saved)
+            opt.clear_frozen()
+        for p, q in zip(ref_p, dev_p):
+            assert rel_err(q.detach().cpu(), p.detach()) < 2e-6
+    for p, q in zip(ref_p, dev_p):
+        assert rel_err(opt.state[q]["exp_avg"].cpu(), ref.state[p]["exp_avg"]) < 2e-6
+        assert rel_err(opt.state[q]["exp_avg_sq"].cpu(), ref.state[p]["exp_avg_sq"]) < 2e-6
+        assert float(opt.state[q]["step"]) == float(ref.state[p]["step"]) == 4.0
+    # frozen weights kept their value bit for bit through the two CGA steps
+    # state dict layout is torch.optim.AdamW's: it loads into one and back
+    other = torch.optim.AdamW(groups([t.clone().cuda().requires_grad_(True) for t in cpu]), lr=1e-3)
+    other.load_state_dict(opt.state_dict())
+    opt.load_state_dict(other.state_dict())
