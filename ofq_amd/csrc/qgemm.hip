@@ -435,24 +435,50 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
     __syncthreads();
   }
 
+  // the per-row addend goes through LDS once (the loop's last barrier released smem) instead of 32 conditional global
+  // loads per lane; old values for C += ... are fetched unconditionally on clamped addresses, a row quad at a time
+  float* row_u = reinterpret_cast<float*>(smem);
+  const bool has_u = B_I8 && p.u != nullptr;
+  if (has_u) {
+    if (tid < BM) row_u[tid] = p.u[((int64_t)b0 * p.M + min(m0 + tid, p.M - 1)) * p.nb1 + b1];
+    __syncthreads();
+  }
+  float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
+  int ncc[2];
+  bool nok[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= p.N) continue;
+    nok[j] = n < p.N;
+    ncc[j] = min(n, p.N - 1);
+  }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.M) {
-          float* dst = p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m * p.ldc + n;
-          float v = acc[i][j][e] * p.alpha;
-          if (B_I8 && p.u) v += p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
-          if (p.accumulate) v += *dst;
-          *dst = v;
+    for (int eb = 0; eb < 4; ++eb) {
+      float old[4][2];
+      if (p.accumulate) {
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh, p.M - 1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) old[ee][j] = Cb[(int64_t)mc * p.ldc + ncc[j]];
         }
       }
-  }
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int ml = wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
+        const int m = m0 + ml;
+        const float uu = has_u ? row_u[ml] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (m < p.M && nok[j]) {
+            float v = acc[i][j][eb * 4 + ee] * p.alpha + uu;
+            if (p.accumulate) v += old[ee][j];
+            Cb[(int64_t)m * p.ldc + ncc[j]] = v;
+          }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ bf16-split dW (TN)
