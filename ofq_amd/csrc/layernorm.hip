@@ -19,6 +19,12 @@ struct LnArgs {
   int64_t R, C, ldx, ldy;
   int TX, TY;
   float eps;
+  // fused per-token LSQ of the LayerNorm output (template flag Q): n = LN(xs) is quantised in the same pass,
+  //   codes = LSQ(n + qb4[c]; step qs[r % qS]); backward recomputes n from (xs, mean, rstd) and applies ofq_lsq_bwd's
+  //   arithmetic before the LayerNorm backward, so neither n nor its gradient ever travels through HBM
+  const float* qs; const float* qb4; int8_t* qcodes; float* rowpart;
+  int64_t qS;
+  float qgscale, qlo, qhi;
 };
 
 template <int TXW>
@@ -28,7 +34,7 @@ __device__ __forceinline__ float ln_row_sum(float v) {
   return v;
 }
 
-template <int J, int TXW, bool BWD>
+template <int J, int TXW, bool BWD, bool Q>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   constexpr int TY = 256 / TXW;
@@ -45,13 +51,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     bet[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok[j]) {
       if (a.gamma) gam[j] = *reinterpret_cast<const float4*>(a.gamma + c4 * 4);
-      if (!BWD && a.beta) bet[j] = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
+      if ((!BWD || Q) && a.beta) bet[j] = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
     }
   }
-  float4 acc_g[J], acc_b[J];
+  float4 qb4v[J];
+  if (Q) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t c4 = tx + (int64_t)j * TXW;
+      qb4v[j] = (cok[j] && a.qb4) ? *reinterpret_cast<const float4*>(a.qb4 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 acc_g[J], acc_b[J], acc_a[J];       // column sums: dgamma, dbeta (= d move_b4 when Q), d move_aft (Q)
   if (BWD) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) acc_g[j] = acc_b[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < J; ++j) acc_g[j] = acc_b[j] = acc_a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int64_t rstride = (int64_t)gridDim.x * TY;
   int64_t r = (int64_t)blockIdx.x * TY + ty;
@@ -115,13 +129,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         o.y = (xv[j].y - mu) * rs * gam[j].y + bet[j].y;
         o.z = (xv[j].z - mu) * rs * gam[j].z + bet[j].z;
         o.w = (xv[j].w - mu) * rs * gam[j].w + bet[j].w;
-        *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
+        if (!Q || a.y) *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
         if (a.res) *reinterpret_cast<float4*>(a.xs + r * a.ldx + col) = xv[j];
+        if (Q) {
+          const float al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+          float q0, q1, q2, q3, v;
+          ofq_lsq_quant(__fadd_rn(o.x, qb4v[j].x), al, a.qlo, a.qhi, q0, v);
+          ofq_lsq_quant(__fadd_rn(o.y, qb4v[j].y), al, a.qlo, a.qhi, q1, v);
+          ofq_lsq_quant(__fadd_rn(o.z, qb4v[j].z), al, a.qlo, a.qhi, q2, v);
+          ofq_lsq_quant(__fadd_rn(o.w, qb4v[j].w), al, a.qlo, a.qhi, q3, v);
+          *reinterpret_cast<char4*>(a.qcodes + r * a.C + col) =
+              make_char4((signed char)(int)q0, (signed char)(int)q1, (signed char)(int)q2, (signed char)(int)q3);
+        }
       }
       if (tx == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
     } else {
       float4 xh[J], g[J];
       float sa = 0.f, sb = 0.f;
+      if (Q) {       // sv holds the gradient of the quantised tensor: turn it into the gradient of n = LN(xs)
+        const float al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+        float rds = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          if (!cok[j]) continue;
+          const float xx[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, gg[4] = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+          const float gm[4] = {gam[j].x, gam[j].y, gam[j].z, gam[j].w}, bt[4] = {bet[j].x, bet[j].y, bet[j].z, bet[j].w};
+          const float b4[4] = {qb4v[j].x, qb4v[j].y, qb4v[j].z, qb4v[j].w};
+          float dq[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float n = (xx[e] - mu) * rs * gm[e] + bt[e];            // same expression as the forward
+            float q, v;
+            ofq_lsq_quant(__fadd_rn(n, b4[e]), al, a.qlo, a.qhi, q, v);
+            const bool inr = (v >= a.qlo) && (v <= a.qhi);
+            dq[e] = inr ? ofq_div(__fmul_rn(gg[e], al), al) : 0.f;
+            rds += gg[e] * (inr ? (q - v) : q);
+          }
+          acc_a[j].x += gg[0]; acc_a[j].y += gg[1]; acc_a[j].z += gg[2]; acc_a[j].w += gg[3];
+          sv[j] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        }
+        rds = ln_row_sum<TXW>(rds);
+        if (tx == 0) a.rowpart[r] = rds;
+      }
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
@@ -149,23 +198,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     }
   }
   if (!BWD) return;
-  // column partials: [TY][2][ncol] through LDS, summed over the row lanes in a fixed order
+  // column partials: [TY][NACC][ncol] through LDS, summed over the row lanes in a fixed order
+  constexpr int NACC = Q ? 3 : 2;
   const int ncol = TXW * J * 4;
-  float* base = red + (size_t)ty * 2 * ncol;
+  float* base = red + (size_t)ty * NACC * ncol;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int c = (tx + j * TXW) * 4;
     base[c] = acc_g[j].x; base[c + 1] = acc_g[j].y; base[c + 2] = acc_g[j].z; base[c + 3] = acc_g[j].w;
     base[ncol + c] = acc_b[j].x; base[ncol + c + 1] = acc_b[j].y; base[ncol + c + 2] = acc_b[j].z; base[ncol + c + 3] = acc_b[j].w;
+    if (Q) {
+      base[2 * ncol + c] = acc_a[j].x; base[2 * ncol + c + 1] = acc_a[j].y;
+      base[2 * ncol + c + 2] = acc_a[j].z; base[2 * ncol + c + 3] = acc_a[j].w;
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * ncol; idx += 256) {
+  for (int idx = threadIdx.x; idx < NACC * ncol; idx += 256) {
     const int c = idx % ncol, ac = idx / ncol;
     if (c >= a.C) continue;
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < TY; ++t) s += red[((size_t)t * 2 + ac) * ncol + c];
-    a.colpart[((int64_t)blockIdx.x * 2 + ac) * a.C + c] = s;
+    for (int t = 0; t < TY; ++t) s += red[((size_t)t * NACC + ac) * ncol + c];
+    a.colpart[((int64_t)blockIdx.x * NACC + ac) * a.C + c] = s;
   }
 }
 
@@ -183,11 +237,11 @@ static int ln_geom(int64_t R, int64_t C, LnGeom* g) {
   return 0;
 }
 
-template <bool BWD>
+template <bool BWD, bool Q>
 static int ln_launch(const LnGeom& g, const LnArgs& a, hipStream_t st) {
-  const size_t lds = BWD ? (size_t)(256 / g.TX) * 2 * g.TX * g.J * 4 * sizeof(float) : 0;
+  const size_t lds = BWD ? (size_t)(256 / g.TX) * (Q ? 3 : 2) * g.TX * g.J * 4 * sizeof(float) : 0;
   dim3 grid(g.gx), block(256);
-#define LN_CASE(JJ, TXW) hipLaunchKernelGGL((layernorm_kernel<JJ, TXW, BWD>), grid, block, lds, st, a); break
+#define LN_CASE(JJ, TXW) hipLaunchKernelGGL((layernorm_kernel<JJ, TXW, BWD, Q>), grid, block, lds, st, a); break
   if (g.TX == 32) {
     switch (g.J) {
       case 1: LN_CASE(1, 32);
@@ -221,7 +275,7 @@ extern "C" int ofq_layernorm_fwd(const float* x, const float* res, const float* 
   LnArgs a = {};
   a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xs = xsum; a.mean = mean; a.rstd = rstd;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX; a.eps = eps;
-  return ln_launch<false>(g, a, (hipStream_t)stream);
+  return ln_launch<false, false>(g, a, (hipStream_t)stream);
 }
 
 extern "C" size_t ofq_layernorm_bwd_ws_bytes(int64_t R, int64_t C) {
@@ -244,13 +298,73 @@ extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* m
   a.colpart = (float*)ws;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX;
   hipStream_t st = (hipStream_t)stream;
-  rc = ln_launch<true>(g, a, st);
+  rc = ln_launch<true, false>(g, a, st);
   if (rc) return rc;
   if (dgamma || dbeta) {
     SumJobs jobs = {};
     if (dgamma) jobs.j[0] = {a.colpart, dgamma, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
     if (dbeta) jobs.j[1] = {a.colpart + C, dbeta, C, g.gx, 2 * C, 1, 1.0f, 0, 0};
     strided_sum_launch(jobs, C, 2, st);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- LayerNorm fused with the per-token LSQ that consumes its output (Block.norm1 -> attention input quantiser,
+// Block.norm2 -> fc1's input quantiser: deit_vision_transformer.py:154-164 + qlinear.py:66-68 / attention.py:177)
+extern "C" int ofq_layernorm_lsq_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                     float* xsum, float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S,
+                                     float gscale, const float* b4, int lo, int hi, int64_t R, int64_t C, int64_t ldx,
+                                     float eps, ofq_stream_t stream) {
+  if (!x || !mean || !rstd || !codes || !lsq_s || S <= 0 || (res && !xsum)) return OFQ_EINVAL;
+  if (ldx < C || (ldx & 3)) return OFQ_EINVAL;
+  LnGeom g;
+  int rc = ln_geom(R, C, &g);
+  if (rc) return rc;
+  LnArgs a = {};
+  a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xs = xsum; a.mean = mean; a.rstd = rstd;
+  a.R = R; a.C = C; a.ldx = ldx; a.ldy = C; a.TX = g.TX; a.TY = 256 / g.TX; a.eps = eps;
+  a.qs = lsq_s; a.qS = S; a.qgscale = gscale; a.qb4 = b4; a.qlo = (float)lo; a.qhi = (float)hi; a.qcodes = codes;
+  return ln_launch<false, true>(g, a, (hipStream_t)stream);
+}
+
+extern "C" size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t R, int64_t C) {
+  LnGeom g;
+  if (ln_geom(R, C, &g)) return 0;
+  return ((size_t)g.gx * 3 * C + (size_t)R) * sizeof(float);
+}
+
+extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
+                                     const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* ds,
+                                     float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
+                                     ofq_stream_t stream) {
+  if (!gq || !x || !mean || !rstd || !dx || !ws || !lsq_s || S <= 0 || R % S) return OFQ_EINVAL;
+  if (ldx < C || ldg < C || (ldx & 3) || (ldg & 3)) return OFQ_EINVAL;
+  LnGeom g;
+  int rc = ln_geom(R, C, &g);
+  if (rc) return rc;
+  if (ws_bytes < ofq_layernorm_lsq_bwd_ws_bytes(R, C)) return OFQ_ENOWS;
+  LnArgs a = {};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = gq; a.dres = dres; a.dx = dx;
+  a.colpart = (float*)ws; a.rowpart = (float*)ws + (size_t)g.gx * 3 * C;
+  a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldg; a.TX = g.TX; a.TY = 256 / g.TX;
+  a.qs = lsq_s; a.qS = S; a.qgscale = gscale; a.qb4 = b4; a.qlo = (float)lo; a.qhi = (float)hi;
+  hipStream_t st = (hipStream_t)stream;
+  rc = ln_launch<true, true>(g, a, st);
+  if (rc) return rc;
+  SumJobs jobs = {};
+  if (dgamma) jobs.j[0] = {a.colpart, dgamma, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (dbeta) jobs.j[1] = {a.colpart + C, dbeta, C, g.gx, 3 * C, 1, 1.0f, 0, 0};           // = d move_b4 as well
+  if (dbaft) jobs.j[2] = {a.colpart + 2 * C, dbaft, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (dgamma || dbeta || dbaft) {
+    strided_sum_launch(jobs, C, 3, st);
+    OFQ_LAUNCH_CHECK();
+  }
+  if (ds) {
+    SumJobs j2 = {};
+    j2.j[0] = {a.rowpart, ds, S, R / S, S, 1, gscale, 0, 0};
+    strided_sum_launch(j2, S, 1, st);
     OFQ_LAUNCH_CHECK();
   }
   return 0;

@@ -109,11 +109,23 @@ class Block(nn.Module):
         """forward() with the residual adds folded into the norms: `pending` is the previous block's MLP output, still to be
         added to x (done in the same pass as norm1); this block's own MLP output is returned un-added.
         Returns (x after the attention residual, info, mlp_out, block input with `pending` added)."""
-        if pending is None:
-            xin, n1 = x, F_ofq.layer_norm(self.norm1, x)
+        # norm -> the per-token input quantiser of its only consumer in one kernel when the consumer offers it
+        spec = self.attn.fused_input_quant(tuple(x.shape)) if hasattr(self.attn, "fused_input_quant") else None
+        fused = F_ofq.norm_quant(self.norm1, spec, x, pending) if spec is not None else None
+        if fused is not None:
+            xin, pre = fused
+            y, info = self.attn(pre[0], pre_quant=pre)
         else:
-            xin, n1 = F_ofq.add_layer_norm(self.norm1, x, pending)
-        y, info = self.attn(n1)
+            if pending is None:
+                xin, n1 = x, F_ofq.layer_norm(self.norm1, x)
+            else:
+                xin, n1 = F_ofq.add_layer_norm(self.norm1, x, pending)
+            y, info = self.attn(n1)
+        spec = self.mlp.fused_input_quant(tuple(xin.shape)) if hasattr(self.mlp, "fused_input_quant") else None
+        fused = F_ofq.norm_quant(self.norm2, spec, xin, y) if spec is not None else None
+        if fused is not None:
+            x, pre = fused
+            return x, info, self.mlp(pre[0], pre_quant=pre), xin
         x, n2 = F_ofq.add_layer_norm(self.norm2, xin, y)
         return x, info, self.mlp(n2), xin
 

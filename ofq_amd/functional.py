@@ -501,3 +501,55 @@ def add_layer_norm(norm, x, res):
         return AddLayerNormFn.apply(x, res, norm.weight, norm.bias, norm.eps)
     xs = x + res
     return xs, norm(xs)
+
+
+class NormQuantFn(torch.autograd.Function):
+    """(xs, x_hat carrier, codes) = LayerNorm(x [+ res]) followed by the per-token LSQ of its only consumer, in one kernel
+    each way (csrc/layernorm.hip, template flag Q): the LayerNorm output is never written, the backward recomputes it
+    from (xs, mean, rstd) and runs the quantiser's backward in front of the LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps, s, b4, baft, geom):
+        shp = x.shape
+        C = shp[-1]
+        x2d = x.reshape(-1, C).contiguous()
+        r2d = None if res is None else res.reshape(-1, C).contiguous()
+        codes, xs, mean, rstd = ops.layernorm_lsq_fwd(x2d, weight, bias, eps, s, b4, geom, res2d=r2d)
+        xin = xs if xs is not None else x2d
+        ctx.save_for_backward(xin, mean, rstd, weight, bias, s, b4)
+        ctx.geom, ctx.shape, ctx.has_res = geom, shp, res is not None
+        ctx.mark_non_differentiable(codes)
+        ctx.set_materialize_grads(False)
+        first = xs.view(shp) if xs is not None else ops.placeholder(shp, x.device)
+        return first, ops.placeholder(shp, x.device), codes
+
+    @staticmethod
+    def backward(ctx, dxs, dxq, _gc):
+        xin, mean, rstd, weight, bias, s, b4 = ctx.saved_tensors
+        shp = ctx.shape
+        C = shp[-1]
+        if not ctx.has_res:
+            dxs = None
+        if dxq is None:
+            return dxs, dxs, None, None, None, None, None, None, None
+        gq = dxq.reshape(-1, C).contiguous()
+        dres = None if dxs is None else dxs.reshape(-1, C).contiguous()
+        dx, dg, db, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
+        dx = dx.view(shp)
+        return (dx, dx if ctx.has_res else None, dg, (db if bias is not None else None), None, ds,
+                (db.clone() if b4 is not None else None), dba, None)
+
+
+def norm_quant(norm, spec, x, res=None):
+    """spec: {"quant": LsqQuantizer, "b4": Parameter, "baft": Parameter} of the only consumer of norm(x [+ res]).
+    Returns (x [+ res], (x_hat carrier, codes, geom)) or None when the fused kernel does not apply."""
+    qz = spec["quant"]
+    C = x.shape[-1]
+    if not (isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
+            len(norm.normalized_shape) == 1 and C % 4 == 0 and C <= 2048 and qz.initialized_alpha and qz.s is not None):
+        return None
+    geom = qz._geom(tuple(x.shape), spec["b4"].numel(), 0, None, None)
+    if geom.mode != 0 or geom.bias_len != geom.inner or geom.lo < -128 or geom.hi > 127:
+        return None
+    xs, xq, codes = NormQuantFn.apply(x, res, norm.weight, norm.bias, norm.eps, qz.s, spec["b4"], spec["baft"], geom)
+    return (xs if res is not None else x), (xq, codes, geom)

@@ -501,6 +501,38 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres2d=None, want_affine_grads=T
     return dx, dg, db
 
 
+def layernorm_lsq_fwd(x2d, gamma, beta, eps, s, b4, g, res2d=None):
+    """codes = LSQ(LN(x [+ res]) + b4) without materialising the LayerNorm output; returns (codes, xsum|None, mean, rstd)."""
+    _dev(x2d, "x")
+    rows, cols = x2d.shape
+    dev = x2d.device
+    xsum = torch.empty((rows, cols), dtype=torch.float32, device=dev) if res2d is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+    _chk(lib().ofq_layernorm_lsq_fwd(x2d.data_ptr(), _p(res2d), _p(gamma), _p(beta), 0, _p(xsum), mean.data_ptr(),
+                                     rstd.data_ptr(), codes.data_ptr(), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, rows,
+                                     cols, x2d.stride(0), float(eps), _stream()), "ofq_layernorm_lsq_fwd")
+    return codes, xsum, mean, rstd
+
+
+def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None):
+    """returns (dx [+ dres], dgamma, dbeta (= db4), ds, dbaft)"""
+    rows, cols = x2d.shape
+    dev = x2d.device
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    dg = torch.empty(cols, dtype=torch.float32, device=dev) if gamma is not None else None
+    db = torch.empty(cols, dtype=torch.float32, device=dev)
+    dba = torch.empty(cols, dtype=torch.float32, device=dev)
+    ds = torch.empty_like(s)
+    ws = workspace(lib().ofq_layernorm_lsq_bwd_ws_bytes(rows, cols), dev)
+    _chk(lib().ofq_layernorm_lsq_bwd(gq2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
+                                     _p(dres2d), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, dx.data_ptr(), _p(dg),
+                                     db.data_ptr(), ds.data_ptr(), dba.data_ptr(), rows, cols, x2d.stride(0), gq2d.stride(0),
+                                     ws.data_ptr(), ws.numel(), _stream()), "ofq_layernorm_lsq_bwd")
+    return dx, dg, db, ds, dba
+
+
 # ------------------------------------------------------------------------------------------------ CGA
 def cga_freeze_mask(W, bits, boundary_range):
     _dev(W, "weight")

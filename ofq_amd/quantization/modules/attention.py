@@ -157,24 +157,45 @@ class QAttention_qkreparam(deit_attention):
     def _make_qk_quant(self, wq_learnable, boundaryRange):
         return StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
 
-    def forward(self, x):
-        return self.proj_drop(self.proj(qkr_attention_core(self, x, self.scale))), None     # attention.py:220-222
+    def fused_input_quant(self, in_shape):
+        """quant_x_4_qkv for a producer that applies it itself (LayerNorm + LSQ in one kernel); None when the attention
+        core needs the fp32 x_hat."""
+        B, N, C = in_shape
+        xin = self.quant_x_4_qkv
+        if not (_ql.FUSE_NORM_QUANT and _attn_codes_ok(self, N, C)):
+            return None
+        return {"quant": xin.input_quant_fn, "b4": xin.move_b4.bias, "baft": xin.move_aft.bias}
+
+    def forward(self, x, pre_quant=None):
+        return self.proj_drop(self.proj(qkr_attention_core(self, x, self.scale, pre_quant=pre_quant))), None   # :220-222
 
 
-def qkr_attention_core(self, x, scale, addend=None):
+def _attn_codes_ok(self, N, C):
+    """The whole attention core can run on integer codes (no consumer reads fp32 x_hat / v_hat / qkx_hat)."""
+    H = self.num_heads
+    d = C // H
+    use_codes = _ql.USE_CODE_GEMM and codes_linear_ok(C, self.v_quant, self.quant_x_4_qkv.input_quant_fn)
+    return (use_codes and C % 16 == 0 and d % 8 == 0 and N <= 256 and self.quan_a_softmax_fn.thd_pos <= 127
+            and self.quan_a_v_fn.thd_neg >= -128 and self.quan_a_qkx_fn.thd_neg >= -128)
+
+
+def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
     """Everything of QAttention_qkreparam.forward before `proj` (attention.py:177-219); also the core of the Swin
-    QKR window attention (swin_attention_and_mlp.py:374-423), which adds `addend` before the softmax."""
+    QKR window attention (swin_attention_and_mlp.py:374-423), which adds `addend` before the softmax.
+    pre_quant: (x_hat carrier, codes, geom) when the producer already applied quant_x_4_qkv (norm_quant)."""
     if True:
         B, N, C = x.shape
         H = self.num_heads
         xin = self.quant_x_4_qkv
         use_codes = _ql.USE_CODE_GEMM and codes_linear_ok(C, self.v_quant, xin.input_quant_fn)
         d = C // H
-        attn_codes = (use_codes and C % 16 == 0 and d % 8 == 0 and N <= 256 and self.quan_a_softmax_fn.thd_pos <= 127
-                      and self.quan_a_v_fn.thd_neg >= -128 and self.quan_a_qkx_fn.thd_neg >= -128)
+        attn_codes = _attn_codes_ok(self, N, C)
         if use_codes:
             # with the attention core on codes too, no consumer reads the fp32 x_hat / v_hat / qkx_hat values
-            xq, xcodes, xgeom = xin(x, want_codes=True, need_values=not attn_codes)   # attention.py:177
+            if pre_quant is not None:
+                xq, xcodes, xgeom = pre_quant
+            else:
+                xq, xcodes, xgeom = xin(x, want_codes=True, need_values=not attn_codes)   # attention.py:177
             # the v / qkx quantisers are applied by the epilogue of the GEMM that produces their input (same codes)
             fuse_ok = attn_codes and _ql.FUSE_NEXT_CODES
             vspec = self.quan_a_v_fn.fusable((B, N, C), self.move_v_b4.bias, 0) if fuse_ok else None

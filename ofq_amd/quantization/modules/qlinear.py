@@ -25,6 +25,8 @@ FUSE_NEXT_CODES = os.environ.get("OFQ_NO_EPILOGUE_FUSE") is None
 # executes the division-heavy LSQ arithmetic at a fraction of the rate of the 5-waves-per-SIMD elementwise kernel
 # (+75 us per GEMM launch vs 51 us for the separate kernel).  OFQ_LSQ_BWD_FUSE=1 turns it on.
 FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None
+# LayerNorm + the per-token LSQ of its single consumer in one kernel each way (A/B switch: OFQ_NO_NORM_QUANT_FUSE=1)
+FUSE_NORM_QUANT = os.environ.get("OFQ_NO_NORM_QUANT_FUSE") is None
 
 
 class LSQ_input(nn.Module):
@@ -81,11 +83,24 @@ class QLinear(nn.Linear):
             return None
         return self.input_quant_fn.fusable(in_shape, self.move_b4.bias, self._prologue)
 
-    def forward(self, input, fuse_next=None, pre_codes=None):
+    def fused_input_quant(self, in_shape):
+        """The input quantiser, for a producer that can apply it itself (LayerNorm + LSQ in one kernel); None if this
+        layer needs the fp32 values or is not on the code path."""
+        if not (FUSE_NORM_QUANT and self.code_path() and codes_only_ok(self.in_features, self.out_features)
+                and self._prologue == 0):
+            return None
+        return {"quant": self.input_quant_fn, "b4": self.move_b4.bias, "baft": self.move_aft.bias}
+
+    def forward(self, input, fuse_next=None, pre_codes=None, pre_quant=None):
         """fuse_next: input_fuse_spec() of the layer consuming this output (its codes come back in fuse_next["codes_out"]);
-        pre_codes: this layer's own input codes when a producer already computed them."""
+        pre_codes: this layer's own input codes when a producer already computed them;
+        pre_quant: (x_hat carrier, codes, geom) when the producer ran this layer's whole input quantiser (norm_quant)."""
         if self.weight_quant_method != "statsq":
             raise ValueError("Unknown quant_method")
+        if pre_quant is not None:
+            xq, xcodes, geom = pre_quant
+            return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
+                                self.statsq_fn, self.bias, fuse=fuse_next)
         if self.code_path():
             # this quantiser has exactly one consumer (the GEMM below): its backward can ride in the dX GEMM's epilogue
             link = {} if FUSE_LSQ_BWD else None
@@ -131,14 +146,17 @@ class QMLP(Mlp):
             and drop_probs[0] == 0
         self.fc2._prologue = 1 if self._fuse_gelu else 0
 
-    def forward(self, x):
+    def fused_input_quant(self, in_shape):
+        return self.fc1.fused_input_quant(in_shape)
+
+    def forward(self, x, pre_quant=None):
         if FUSE_NEXT_CODES and self._fuse_gelu and self.fc1.code_path():
             # fc1's GEMM epilogue also applies GELU + fc2's offset and LSQ, so fc2 never re-reads the fp32 activation
             spec = self.fc2.input_fuse_spec(tuple(x.shape[:-1]) + (self.fc1.out_features,))
-            h = self.fc1(x, fuse_next=spec)
+            h = self.fc1(x, fuse_next=spec, pre_quant=pre_quant)
             x = self.fc2(h, pre_codes=None if spec is None else spec.get("codes_out"))
             return self.drop2(x)
-        x = self.fc1(x)
+        x = self.fc1(x, pre_quant=pre_quant)
         if not self._fuse_gelu:
             x = self.drop1(self.act(x))
         x = self.fc2(x)

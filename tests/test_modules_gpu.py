@@ -420,3 +420,42 @@ def test_qmlp_lsq_backward_in_dx_gemm_epilogue(env, dims):
         assert torch.equal(fused["dx"], plain["dx"])
     for k in fused:
         assert rel_err(fused[k], plain[k]) < 2e-6, k
+
+
+def test_block_norm_quant_fusion_matches_separate_kernels(env):
+    """LayerNorm + per-token input LSQ in one kernel each way (ofq_layernorm_lsq_fwd / _bwd) against LayerNorm followed
+    by ofq_lsq_fwd / _bwd inside a quantised DeiT block pair: same codes (hence identical outputs), gradients to 1e-5."""
+    from ofq_amd import engine
+    from ofq_amd.quantization.modules import qlinear as ql
+    torch.manual_seed(7)
+    model = engine.build_student("deit_small_distilled_patch16_224", 2, 2, qk_reparam=True, depth=2).cuda().train()
+    B = 3
+    img = torch.randn(B, 3, 224, 224, device="cuda")
+    engine.setup_alpha(model, img)
+    with torch.no_grad():
+        for nme, p in model.named_parameters():
+            if "move_" in nme:
+                p.uniform_(-0.03, 0.03)
+            if "norm" in nme and nme.endswith("bias"):
+                p.uniform_(-0.1, 0.1)
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        (c, d), _ = model(img)
+        (c.square().mean() + d.square().mean()).backward()
+        return {"c": c.detach().clone(), "d": d.detach().clone(),
+                **{n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}}
+
+    prev = ql.FUSE_NORM_QUANT
+    try:
+        ql.FUSE_NORM_QUANT = True
+        fused = run()
+        ql.FUSE_NORM_QUANT = False
+        plain = run()
+    finally:
+        ql.FUSE_NORM_QUANT = prev
+    assert fused.keys() == plain.keys()
+    assert torch.equal(fused["c"], plain["c"]) and torch.equal(fused["d"], plain["d"])
+    bad = {k: rel_err(fused[k], plain[k]) for k in fused if rel_err(fused[k], plain[k]) > 1e-5 and "move_" not in k}
+    assert not bad, bad
