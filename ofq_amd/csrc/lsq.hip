@@ -49,7 +49,7 @@ static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g, bool
     else TY = (TY / (int)k) * (int)k;
   }
   int64_t gx = ceil_div(R, TY);
-  int64_t cap = (widek ? 1024 / TY : 1024) / gy;
+  int64_t cap = 1024 / gy;                       // (the wide-k partials [gx*TY][nacc][inner] stay below ~50 MB)
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   if (widek) {                                   // the row stride gx*TY must keep every lane on one bias phase

@@ -1667,8 +1667,10 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   static const bool narrow_only = getenv("OFQ_NT_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
-  if (nsplit == 3 && N > 128 && !narrow_only) {      // wide tiles: the dY panel is split once per 384 (256) columns
-    const int nj = N > 256 ? 3 : 2;
+  const int nj = N > 256 ? 3 : 2;
+  // few rows (late Swin stages): 128-column tiles give 2-3x more workgroups, which matters more than the shared split
+  const bool too_few = (int64_t)a.tiles_m * ceil_div(N, 128 * nj) < 160 && (int64_t)a.tiles_m * a.tiles_n >= 192;
+  if (nsplit == 3 && N > 128 && !narrow_only && !too_few) {      // wide tiles: the dY panel is split once per 384 (256) columns
     a.tiles_n = (int)ceil_div(N, 128 * nj);
     dim3 gridw((unsigned)(a.tiles_m * a.tiles_n));
     if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
