@@ -106,16 +106,27 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
 
 // ---- float4 variants (ld % 4 == 0, ld <= 256): lane l owns columns 4l..4l+3, so a row is one 16-byte load / store per
 // lane and tensor instead of four strided dwords; same arithmetic per element, same wave reductions
-#define SM_RPW 4      // rows per wave: their loads are all issued before the first row is processed (bytes in flight)
+#define SM_RPW 4      // row slots per lane group: their loads are all issued before the first row is processed
+
+template <int W>
+__device__ __forceinline__ float sm_group_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// LPR lanes own one row (4 columns per lane): 64 for attention rows up to 256 wide (DeiT: 198), 16 for rows up to 64
+// wide (Swin's 7x7 windows: 49), where a whole wave per row would leave 3/4 of the lanes idle.
+template <int LPR>
 __global__ __launch_bounds__(256) void softmax_lsq_fwd_v4_kernel(const float* __restrict__ sc, const float* __restrict__ s,
                                                                  float* __restrict__ prob, float* __restrict__ y,
                                                                  int64_t rows, int n, int64_t ld, int64_t S, float alpha,
                                                                  float hi, float gscale, unsigned char* __restrict__ codes,
                                                                  float* __restrict__ code_rowsum, const float* __restrict__ addend,
                                                                  int64_t add_period) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_RPW;
-  if (r0 >= rows) return;
+  constexpr int GPB = 256 / LPR;                      // lane groups per workgroup
+  const int lane = threadIdx.x % LPR;
+  const int64_t r0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / LPR) * SM_RPW;
   const int c0 = lane * 4;
   const bool act = c0 < ld;
   float4 vin[SM_RPW], ain[SM_RPW];
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_v4_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < SM_RPW; ++i) {
     const int64_t r = r0 + i;
-    if (r >= rows) break;
+    const bool rok = r < rows;                        // (no early exit: the group shuffles need every lane)
     float t[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     const float vv[4] = {vin[i].x, vin[i].y, vin[i].z, vin[i].w}, aa[4] = {ain[i].x, ain[i].y, ain[i].z, ain[i].w};
 #pragma unroll
@@ -141,17 +152,17 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_v4_kernel(const float* __
         if (addend) t[e] = __fadd_rn(t[e], aa[e]);
       }
     float m = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
-    m = ofq_wave_max(m);
+    m = sm_group_max<LPR>(m);
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       t[e] = (c0 + e < n) ? expf(t[e] - m) : 0.f;
       sum += t[e];
     }
-    sum = ofq_wave_sum(sum);
-    const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+    sum = ofq_group_sum<LPR>(sum);
+    const float a = ofq_lsq_eff_scale(s[min(r, rows - 1) % S], gscale);
     float qsum = 0.f;
-    if (act) {
+    if (act && rok) {
       float p[4] = {0.f, 0.f, 0.f, 0.f}, out[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -169,20 +180,21 @@ __global__ __launch_bounds__(256) void softmax_lsq_fwd_v4_kernel(const float* __
             make_uchar4((unsigned char)(int)q[0], (unsigned char)(int)q[1], (unsigned char)(int)q[2], (unsigned char)(int)q[3]);
     }
     if (code_rowsum) {
-      qsum = ofq_wave_sum(qsum);
-      if (lane == 0) code_rowsum[r] = qsum;
+      qsum = ofq_group_sum<LPR>(qsum);
+      if (lane == 0 && rok) code_rowsum[r] = qsum;
     }
   }
 }
 
+template <int LPR>
 __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __restrict__ g, const float* __restrict__ prob,
                                                                  const float* __restrict__ s, float* __restrict__ dsc,
                                                                  float* __restrict__ rowpart, int64_t rows, int n,
                                                                  int64_t ld, int64_t S, float alpha, float hi,
                                                                  float gscale, float* __restrict__ ds_rowsum) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_RPW;
-  if (r0 >= rows) return;
+  constexpr int GPB = 256 / LPR;
+  const int lane = threadIdx.x % LPR;
+  const int64_t r0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / LPR) * SM_RPW;
   const int c0 = lane * 4;
   const bool act = c0 < ld;
   float4 pin[SM_RPW], gin[SM_RPW];
@@ -198,8 +210,8 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < SM_RPW; ++i) {
     const int64_t r = r0 + i;
-    if (r >= rows) break;
-    const float a = ofq_lsq_eff_scale(s[r % S], gscale);
+    const bool rok = r < rows;
+    const float a = ofq_lsq_eff_scale(s[min(r, rows - 1) % S], gscale);
     float p[4] = {0.f, 0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     float rowds = 0.f, dot = 0.f;
     const float pp[4] = {pin[i].x, pin[i].y, pin[i].z, pin[i].w}, gg[4] = {gin[i].x, gin[i].y, gin[i].z, gin[i].w};
@@ -214,11 +226,11 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
         rowds += gg[e] * (inr ? (q - v) : q);
         dot += dq[e] * p[e];
       }
-    rowds = ofq_wave_sum(rowds);
-    dot = ofq_wave_sum(dot);
-    if (lane == 0) rowpart[r] = rowds;
+    rowds = ofq_group_sum<LPR>(rowds);
+    dot = ofq_group_sum<LPR>(dot);
+    if (lane == 0 && rok) rowpart[r] = rowds;
     float rsum = 0.f;
-    if (act) {
+    if (act && rok) {
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -228,8 +240,8 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
       *reinterpret_cast<float4*>(dsc + r * ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (ds_rowsum) {
-      rsum = ofq_wave_sum(rsum);
-      if (lane == 0) ds_rowsum[r] = rsum;
+      rsum = ofq_group_sum<LPR>(rsum);
+      if (lane == 0 && rok) ds_rowsum[r] = rsum;
     }
   }
 }
@@ -242,9 +254,16 @@ extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* p
   const bool v4 = (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0 && ((uintptr_t)prob & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0) &&
                   (!codes || ((uintptr_t)codes & 3) == 0) && (!addend || ((uintptr_t)addend & 15) == 0);
   if (v4)
-    hipLaunchKernelGGL(softmax_lsq_fwd_v4_kernel, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, (hipStream_t)stream,
-                       scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
-                       add_period > 0 ? add_period : 1);
+  {
+    if (ld <= 64)
+      hipLaunchKernelGGL(softmax_lsq_fwd_v4_kernel<16>, dim3((unsigned)ceil_div(rows, 16 * SM_RPW)), dim3(256), 0,
+                         (hipStream_t)stream, scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes,
+                         code_rowsum, addend, add_period > 0 ? add_period : 1);
+    else
+      hipLaunchKernelGGL(softmax_lsq_fwd_v4_kernel<64>, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0,
+                         (hipStream_t)stream, scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes,
+                         code_rowsum, addend, add_period > 0 ? add_period : 1);
+  }
   else
     hipLaunchKernelGGL(softmax_lsq_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                        scores, s, prob, y, rows, (int)n, ld, S, alpha, (float)hi, gscale, codes, code_rowsum, addend,
@@ -264,8 +283,14 @@ extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const floa
   if (ws_bytes < (size_t)rows * sizeof(float)) return OFQ_ENOWS;
   hipStream_t st = (hipStream_t)stream;
   if ((ld & 3) == 0 && (((uintptr_t)g | (uintptr_t)prob | (uintptr_t)dscores) & 15) == 0)
-    hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, st, g, prob, s, dscores,
-                       (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+  {
+    if (ld <= 64)
+      hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel<16>, dim3((unsigned)ceil_div(rows, 16 * SM_RPW)), dim3(256), 0, st, g, prob, s,
+                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+    else
+      hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel<64>, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, st, g, prob, s,
+                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+  }
   else
     hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
                        (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
