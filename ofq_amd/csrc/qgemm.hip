@@ -1668,7 +1668,8 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   static const bool narrow_only = getenv("OFQ_NT_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
   const int nj = N > 256 ? 3 : 2;
-  // few rows (late Swin stages): 128-column tiles give 2-3x more workgroups, which matters more than the shared split
+  // few rows (late Swin stages): 128-column tiles of the 4-wave kernel give 2-3x more workgroups, which matters more than
+  // the shared split (measured: 185 vs 207 us at M=6272, N=768, K=3072; an 8-wave 128x128 variant lost to it as well)
   const bool too_few = (int64_t)a.tiles_m * ceil_div(N, 128 * nj) < 160 && (int64_t)a.tiles_m * a.tiles_n >= 192;
   if (nsplit == 3 && N > 128 && !narrow_only && !too_few) {      // wide tiles: the dY panel is split once per 384 (256) columns
     a.tiles_n = (int)ceil_div(N, 128 * nj);
