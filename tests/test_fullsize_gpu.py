@@ -1,0 +1,121 @@
+"""GPU parity at BASELINE.json's full sizes (DeiT-S W2A2 QKR, 128 images): the oracle cannot run these in seconds, so the
+kernels are checked through size-independent properties of the domain -- exact integer arithmetic against int64 on row
+samples, idempotence of quantisation, linearity of the gradient GEMMs, conservation (sum) checks of the reductions --
+plus the oracle itself on randomly sampled rows.  All through the C ABI (ofq_amd.ops)."""
+import pytest
+import torch
+
+import ofq_oracle as O
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+B, N, C, H = 128, 198, 384, 6
+M = B * N
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "the -m gpu tests need a HIP device"
+    from ofq_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def test_statsq_full_size_rows_and_scale_property(ops):
+    torch.manual_seed(0)
+    W = torch.randn(H * C, C, device="cuda") * 0.02                      # W_qk: 2304 x 384 (statsq.py:138 on its rows)
+    for bits in (2, 3, 4):
+        out, s, codes, codesT, r = ops.statsq_codes_fwd(W, bits, rvec=torch.linspace(-1, 1, C, device="cuda"), need_values=True)
+        n = 2 ** (bits - 1)
+        assert rel_err(s, 2 * W.abs().double().mean(1)) < 1.2e-7            # the row mean to fp32 rounding (statsq.py:138)
+        L = (codes.float() - 1) / 2
+        assert float(L.min()) >= -n and float(L.max()) <= n - 1
+        assert torch.equal(out, (s[:, None] * ((L + 0.5) / n) - W) + W)   # value of the STE expression, elementwise
+        assert torch.equal(L, torch.round(torch.clamp(W / s[:, None], -1.0, 1.0 - 1e-6) * n - 0.5))   # levels given s
+        assert torch.equal(codesT.float(), codes.float().t())
+        assert rel_err(r, codes.double() @ torch.linspace(-1, 1, C, device="cuda").double()) < 1e-6
+        idx = torch.randint(0, H * C, (64,))
+        ref_rows = O.statsq(W[idx].cpu(), bits)[0]
+        assert rel_err(out[idx].cpu(), ref_rows) < 1e-6
+
+
+def test_lsq_full_size_codes_idempotent_and_oracle_rows(ops):
+    torch.manual_seed(1)
+    x = torch.randn(M, C, device="cuda")
+    s = torch.rand(N, device="cuda") * 0.4 + 0.3
+    b4 = torch.randn(C, device="cuda") * 0.05
+    baft = torch.randn(C, device="cuda") * 0.05
+    g = ops.LsqGeom(B, N, C, C, 0, -2, 1, B * C)
+    y, codes = ops.lsq_fwd(x, s, b4, baft, g, want_codes=True, need_values=True)
+    a_eff = O.lsq_effective_scale(s.cpu(), g.gscale).cuda()
+    rows = torch.arange(M, device="cuda") % N
+    # dequantised values are code * step + offset, bit for bit; codes stay inside the 2-bit range
+    assert torch.equal(y, codes.float() * a_eff[rows][:, None] + baft)
+    assert int(codes.min()) >= -2 and int(codes.max()) <= 1
+    # idempotence: quantising the dequantised tensor (without offsets) returns the same codes
+    y2, codes2 = ops.lsq_fwd((codes.float() * a_eff[rows][:, None]).contiguous(), s, None, None,
+                             ops.LsqGeom(B, N, C, 0, 0, -2, 1, B * C), want_codes=True, need_values=True)
+    assert torch.equal(codes2, codes)
+    # oracle on one sampled image
+    b = 77
+    ref = O._lsq_core(x[b * N:(b + 1) * N].cpu()[None] + b4.cpu(), s.cpu().unsqueeze(-1), -2, 1, g.gscale) + baft.cpu()
+    assert torch.equal(y[b * N:(b + 1) * N].cpu(), ref[0].detach())
+
+
+def test_int8_linear_full_size_is_exact_on_sampled_rows(ops):
+    torch.manual_seed(2)
+    for (n_out, k_in) in ((H * C, C), (4 * C, C), (C, 4 * C)):
+        qa = torch.randint(-2, 2, (M, k_in), dtype=torch.int8, device="cuda")
+        qw = (2 * torch.randint(-2, 2, (n_out, k_in), device="cuda") + 1).to(torch.int8)
+        s = torch.rand(N, device="cuda") + 0.1
+        cs = torch.rand(n_out, device="cuda")
+        bias = torch.rand(n_out, device="cuda")
+        r = torch.rand(n_out, device="cuda")
+        y = ops.qgemm_i8_nt(qa, qw, bias, cs, 0.25, r, s, N, 0.01)
+        idx = torch.randint(0, M, (256,), device="cuda")
+        I = (qa[idx].cpu().long() @ qw.cpu().long().t()).cuda()            # exact integer products
+        ae = O.lsq_effective_scale(s.cpu(), 0.01).cuda()[idx % N]
+        ref = (cs * 0.25) * (ae[:, None] * I.float() + r) + bias           # the epilogue's fp32 expression
+        assert torch.equal(y[idx], ref)
+
+
+def test_gradient_gemms_full_size_linearity_and_sums(ops):
+    torch.manual_seed(3)
+    n_out, k_in = 4 * C, C                                                 # fc1: dY is 25344 x 1536
+    dy1 = torch.randn(M, n_out, device="cuda") * 1e-3
+    dy2 = torch.randn(M, n_out, device="cuda") * 1e-3
+    qw = (2 * torch.randint(-2, 2, (n_out, k_in), device="cuda") + 1).to(torch.int8)
+    wT = ops.codes_transpose_bf16(qw)
+    ks = torch.rand(n_out, device="cuda") * 0.1
+    f = lambda d: ops.qgemm_bf16s_nt(d, wT, ks, 0.25)                       # noqa: E731
+    a, b, ab = f(dy1), f(dy2), f(dy1 + dy2)
+    assert rel_err(ab, a + b) < 2e-6                                       # linear in dY
+    rows = torch.randint(0, M, (128,), device="cuda")
+    ref = 0.25 * ((dy1[rows].double() * ks.double()) @ qw.double())
+    assert rel_err(a[rows], ref) < 1e-6
+    # dW: split-K over 25344 tokens; column sums of dY come out as the bias gradient
+    codes = torch.randint(-2, 2, (M, k_in), dtype=torch.int8, device="cuda")
+    s = torch.rand(N, device="cuda") + 0.1
+    baft = torch.randn(k_in, device="cuda") * 0.05
+    dW, db = ops.qgemm_bf16s_tn(dy1, codes, s, N, 0.01, None, baft, compute_db=True)
+    assert rel_err(db, dy1.double().sum(0)) < 1e-6
+    ae = O.lsq_effective_scale(s.cpu(), 0.01).cuda()[torch.arange(M, device="cuda") % N].double()
+    cols = torch.randint(0, n_out, (96,), device="cuda")
+    ref = (dy1[:, cols].double() * ae[:, None]).t() @ codes.double() + db.double()[cols][:, None] * baft.double()[None]
+    assert rel_err(dW[cols], ref) < 1e-6
+
+
+def test_softmax_lsq_full_size_rows_sum_to_one_and_match_oracle(ops):
+    torch.manual_seed(4)
+    Np = 208
+    rows = B * H * N
+    sc = torch.zeros(B, H, N, Np, device="cuda")
+    sc[..., :N] = torch.randn(B, H, N, N, device="cuda") * 3
+    s = torch.rand(N, device="cuda") * 0.05 + 0.02
+    prob, y, codes, rsum = ops.softmax_lsq_fwd(sc, s, rows, N, Np, N, 0.125, 3, rows, want_codes=True, need_values=True)
+    assert float((prob[..., :N].double().sum(-1) - 1).abs().max()) < 1e-6
+    assert float(prob[..., N:].abs().max()) == 0.0 and int(codes.max()) <= 3
+    assert torch.equal(rsum.view(B, H, N), codes[..., :N].float().sum(-1))
+    p_ref = torch.softmax(sc[5, 2, :, :N].double() * 0.125, -1)
+    assert rel_err(prob[5, 2, :, :N], p_ref) < 1e-6
