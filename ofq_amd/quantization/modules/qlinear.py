@@ -20,6 +20,7 @@ from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
 USE_CODE_GEMM = True
 # fc1's GEMM epilogue emits fc2's input codes (A/B switch for bench runs: OFQ_NO_EPILOGUE_FUSE=1)
 FUSE_NEXT_CODES = os.environ.get("OFQ_NO_EPILOGUE_FUSE") is None
+FUSE_NEXT_CODES_MLP = os.environ.get("OFQ_NO_EPILOGUE_FUSE_MLP") is None
 # The input quantiser's backward can run in the epilogue of the layer's dX GEMM (ofq_qgemm_bf16s_nt_lsq: dX never
 # goes to HBM).  Correct and tested, but OFF by default: measured on MI355X it loses -- the 2-waves-per-SIMD GEMM kernel
 # executes the division-heavy LSQ arithmetic at a fraction of the rate of the 5-waves-per-SIMD elementwise kernel
@@ -150,7 +151,7 @@ class QMLP(Mlp):
         return self.fc1.fused_input_quant(in_shape)
 
     def forward(self, x, pre_quant=None):
-        if FUSE_NEXT_CODES and self._fuse_gelu and self.fc1.code_path():
+        if FUSE_NEXT_CODES and FUSE_NEXT_CODES_MLP and self._fuse_gelu and self.fc1.code_path():
             # fc1's GEMM epilogue also applies GELU + fc2's offset and LSQ, so fc2 never re-reads the fp32 activation
             spec = self.fc2.input_fuse_spec(tuple(x.shape[:-1]) + (self.fc1.out_features,))
             h = self.fc1(x, fuse_next=spec, pre_quant=pre_quant)
