@@ -238,6 +238,10 @@ int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double bet
  *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */
 int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, int bits, float boundary_range,
                         float* frozen, int32_t* range_ws, ofq_stream_t stream);
+/*  The same mask for every CGA tensor of the model in three launches per 40 tensors: `tensors` is a HOST array of
+ *  {const float* W; float* frozen; int32_t* range_ws; int64_t rows; int64_t cols} (device pointers inside). */
+int64_t ofq_cga_tensor_entry_bytes(void);
+int ofq_cga_freeze_mask_multi(const void* tensors, int64_t n_tensors, int bits, float boundary_range, ofq_stream_t stream);
 /*  grad *= (1-frozen); saved = W*frozen   (before optimizer.step) */
 int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, float* saved, int64_t n,
                            ofq_stream_t stream);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "ofq_adamw_tensor_entry_bytes": (i64, []),
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
+    "ofq_cga_tensor_entry_bytes": (i64, []),
+    "ofq_cga_freeze_mask_multi": (i32, [vp, i64, i32, f32, vp]),
     "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
     "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),
 }

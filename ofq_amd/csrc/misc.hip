@@ -104,6 +104,93 @@ extern "C" int ofq_cga_freeze_mask(const float* W, int64_t rows, int64_t cols, i
   return 0;
 }
 
+// ---- all CGA tensors of the model in three launches (48 tensors for DeiT QKR: was 3 launches per tensor)
+struct CgaTensor { const float* W; float* frozen; int32_t* range; int64_t rows, cols; };
+#define CGA_PACK 40
+struct CgaPack {
+  CgaTensor t[CGA_PACK];
+  int32_t first_block[CGA_PACK + 1];      // prefix sums of ceil(rows / 4)
+  int32_t n;
+};
+
+__device__ __forceinline__ int cga_find(const CgaPack& pk, int block) {
+  int ti = 0;
+  while (ti + 1 < pk.n && block >= pk.first_block[ti + 1]) ++ti;
+  return ti;
+}
+
+__global__ void cga_range_init_multi_kernel(CgaPack pk) {
+  const int i = threadIdx.x;
+  if (i < pk.n) { pk.t[i].range[0] = 0x7fffffff; pk.t[i].range[1] = -0x7fffffff; }
+}
+
+__global__ __launch_bounds__(256) void cga_range_multi_kernel(CgaPack pk, float n) {
+  const int ti = cga_find(pk, blockIdx.x);
+  const CgaTensor t = pk.t[ti];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)(blockIdx.x - pk.first_block[ti]) * 4 + (threadIdx.x >> 6);
+  if (row >= t.rows) return;
+  const float* w = t.W + row * t.cols;
+  const float s = cga_row_scale(w, t.cols, lane);
+  int lo = 0x7fffffff, hi = -0x7fffffff;
+  for (int64_t i = lane; i < t.cols; i += 64) {
+    int L = (int)rintf(cga_b4(w[i], s, n));
+    lo = min(lo, L); hi = max(hi, L);
+  }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+  if (lane == 0) { atomicMin(&t.range[0], lo); atomicMax(&t.range[1], hi); }
+}
+
+__global__ __launch_bounds__(256) void cga_mask_multi_kernel(CgaPack pk, float n, float th_hi, float th_lo) {
+  const int ti = cga_find(pk, blockIdx.x);
+  const CgaTensor t = pk.t[ti];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)(blockIdx.x - pk.first_block[ti]) * 4 + (threadIdx.x >> 6);
+  if (row >= t.rows) return;
+  const float* w = t.W + row * t.cols;
+  const float s = cga_row_scale(w, t.cols, lane);
+  const int imin = t.range[0], imax = t.range[1];
+  for (int64_t i = lane; i < t.cols; i += 64) {
+    const float b4 = cga_b4(w[i], s, n);
+    float notfrozen = 0.f;
+    for (int k = imin; k < imax; ++k) {                                 // np.arange(min, max)  cga.py:465
+      const float d = __fsub_rn(b4, (float)k);
+      notfrozen += (d <= th_hi && d >= th_lo) ? 1.f : 0.f;              // cga.py:466-467
+    }
+    t.frozen[row * t.cols + i] = 1.0f - notfrozen;                      // cga.py:469
+  }
+}
+
+extern "C" int64_t ofq_cga_tensor_entry_bytes(void) { return (int64_t)sizeof(CgaTensor); }
+
+// tensors: HOST array of {const float* W; float* frozen; int32_t* range (2 ints of scratch); int64 rows; int64 cols}
+extern "C" int ofq_cga_freeze_mask_multi(const void* tensors, int64_t n_tensors, int bits, float boundary_range,
+                                         ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
+  const CgaTensor* ts = (const CgaTensor*)tensors;
+  hipStream_t st = (hipStream_t)stream;
+  const float n = (float)(1 << (bits - 1));
+  const float th_hi = (float)(0.5 + (double)boundary_range), th_lo = (float)(0.5 - (double)boundary_range);
+  for (int64_t base = 0; base < n_tensors; base += CGA_PACK) {
+    CgaPack pk = {};
+    pk.n = (int32_t)((n_tensors - base < CGA_PACK) ? (n_tensors - base) : CGA_PACK);
+    int64_t blocks = 0;
+    for (int i = 0; i < pk.n; ++i) {
+      pk.t[i] = ts[base + i];
+      if (!pk.t[i].W || !pk.t[i].frozen || !pk.t[i].range || pk.t[i].rows <= 0 || pk.t[i].cols <= 0) return OFQ_EINVAL;
+      pk.first_block[i] = (int32_t)blocks;
+      blocks += ceil_div(pk.t[i].rows, 4);
+      if (blocks >= (1ll << 31)) return OFQ_EINVAL;
+    }
+    pk.first_block[pk.n] = (int32_t)blocks;
+    hipLaunchKernelGGL(cga_range_init_multi_kernel, dim3(1), dim3(64), 0, st, pk);
+    hipLaunchKernelGGL(cga_range_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pk, n);
+    hipLaunchKernelGGL(cga_mask_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pk, n, th_hi, th_lo);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 __global__ void cga_mask_grad_save_kernel(float* __restrict__ grad, const float* __restrict__ W,
                                           const float* __restrict__ frozen, float* __restrict__ saved, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

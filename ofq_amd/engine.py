@@ -150,8 +150,13 @@ class CGAHooks:
         """optimizer: a FusedAdamW takes the masks itself (gradient mask + weight restore inside its one pass); any other
         optimizer gets the reference's three-kernel sequence around its step."""
         self._folded = optimizer is not None and hasattr(optimizer, "set_frozen")
-        for k, m in self.mods:
-            frz = ops.cga_freeze_mask(m.weight.data, self.bits, self.br)           # cga.py:960
+        ws = [m.weight.data for _, m in self.mods]
+        multi = bool(ws) and all(w.is_cuda and w.dim() == 2 and w.is_contiguous() for w in ws)
+        if multi:      # every mask in three launches (persistent mask / scratch buffers)
+            self._masks, self._ranges = ops.cga_freeze_mask_multi(ws, self.bits, self.br, getattr(self, "_masks", None),
+                                                                  getattr(self, "_ranges", None))
+        for i, (k, m) in enumerate(self.mods):
+            frz = self._masks[i] if multi else ops.cga_freeze_mask(m.weight.data, self.bits, self.br)   # cga.py:960
             if self._folded:
                 optimizer.set_frozen(m.weight, frz)
                 self.state[k] = (frz, None)

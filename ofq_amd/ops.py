@@ -545,6 +545,25 @@ def cga_freeze_mask(W, bits, boundary_range):
     return frozen
 
 
+def cga_freeze_mask_multi(weights, bits, boundary_range, frozen=None, ranges=None):
+    """freeze masks of many weight tensors in three launches per 40 tensors; returns (list of masks, range scratch)."""
+    import numpy as np
+    dev = weights[0].device
+    if frozen is None:
+        frozen = [torch.empty_like(w) for w in weights]
+    if ranges is None:
+        ranges = torch.empty((len(weights), 2), dtype=torch.int32, device=dev)
+    assert lib().ofq_cga_tensor_entry_bytes() == 40
+    tab = np.empty((len(weights), 5), dtype=np.int64)
+    for i, (w, f) in enumerate(zip(weights, frozen)):
+        if not w.is_cuda or w.dim() != 2 or not w.is_contiguous():
+            raise RuntimeError("ofq_amd: CGA weights must be contiguous 2-D tensors on a HIP device")
+        tab[i] = (w.data_ptr(), f.data_ptr(), ranges[i].data_ptr(), w.shape[0], w.shape[1])
+    _chk(lib().ofq_cga_freeze_mask_multi(tab.ctypes.data, len(weights), bits, float(boundary_range), _stream()),
+         "ofq_cga_freeze_mask_multi")
+    return frozen, ranges
+
+
 def cga_mask_grad_save(grad, W, frozen):
     saved = torch.empty_like(W)
     _chk(lib().ofq_cga_mask_grad_save(grad.data_ptr(), W.data_ptr(), frozen.data_ptr(), saved.data_ptr(), W.numel(),

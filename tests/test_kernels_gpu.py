@@ -328,6 +328,32 @@ def test_cga_golden_bit_exact(ops):
         assert torch.equal(Wp.detach().cpu()[fm], T(g["W"])[fm])      # frozen weights are restored exactly
 
 
+def test_cga_multi_tensor_masks_and_fused_adamw_equal_the_golden_sequence(ops):
+    """All masks in one multi-tensor call (ofq_cga_freeze_mask_multi) equal the per-tensor kernel bit for bit, and the
+    AdamW kernel with the mask folded in reproduces the golden mask-grad / AdamW / restore result (cga.py:953-1013)."""
+    from ofq_amd.optim import FusedAdamW
+    d = load_golden("g8_cga")
+    cases = [group(d, "c%d" % c) for c in range(int(d["ncases"]))]
+    by_cfg = {}
+    for g in cases:
+        by_cfg.setdefault((int(g["meta"][2]), float(g["br"])), []).append(g)
+    for (bits, br), gs in by_cfg.items():
+        Ws = [G(g["W"]) for g in gs] + [torch.randn(37, 50, device="cuda") * 0.02, torch.randn(1536, 384, device="cuda") * 0.02]
+        masks, _ = ops.cga_freeze_mask_multi(Ws, bits, br)
+        for w, m in zip(Ws, masks):
+            assert torch.equal(m, ops.cga_freeze_mask(w, bits, br))
+        for g, m in zip(gs, masks):
+            assert torch.equal(m.cpu(), T(g["frz"]))
+            Wp = torch.nn.Parameter(G(g["W"]).clone())
+            opt = FusedAdamW([Wp], lr=1e-3, weight_decay=0.05)
+            Wp.grad = G(g["g"]).clone()
+            opt.set_frozen(Wp, m)
+            opt.step()
+            assert rel_err(Wp.detach().cpu(), g["W_after"]) < 1e-6
+            fm = T(g["frz"]) == 1
+            assert torch.equal(Wp.detach().cpu()[fm], T(g["W"])[fm])
+
+
 def test_cpu_tensors_are_rejected_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.statsq_fwd(torch.zeros(4, 8), 2)
