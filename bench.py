@@ -183,8 +183,9 @@ def main():
         if args.verbose:
             torch.cuda.synchronize()
             say("warmup step %d done" % i)
-    timer = None if args.no_roofline_events else {}
-    ops.TIMERS = timer
+    # throughput pass: EXACTLY --steps steps, no instrumentation (a pair of HIP events around every matrix-core launch --
+    # ~600 per step -- costs 2-4 ms per step on this stack and would be charged to `value`)
+    ops.TIMERS = None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,7 +196,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.TIMERS = None
+    # roofline pass: the same --steps steps again, live, with HIP events around every matrix-core kernel launch (on the
+    # stream the kernels are launched on); rank 0 reports the dominant class
+    timer = None if args.no_roofline_events else {}
+    if timer is not None:
+        ops.TIMERS = timer
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ops.TIMERS = None
+        if world > 1:
+            dist.barrier()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,8 +232,9 @@ def main():
                 pass
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over the "
-                            "timed steps; for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "
+                    "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over a second, "
+                            "instrumented pass of the same --steps steps (the throughput pass carries no events: they cost "
+                            "2-4 ms/step); for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "
                             "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/r01_traffic.json)",
                     "launches_per_step": sm["launches"] / args.steps, "avg_launch_ms": round(sm["avg_ms"], 4),
                     "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
