@@ -7,9 +7,11 @@
 //   bwd :  xh = (xs - mu) * rstd, g = dy * gamma,
 //          dx = rstd * (g - mean(g) - xh * mean(g * xh))  [+ dres],   dgamma = sum_rows dy * xh,   dbeta = sum_rows dy
 //
-// One row is owned by TX lanes (32 or 64) holding J float4 each, so the two row reductions are DPP/shuffle only; a
-// workgroup walks rows with a one-row software prefetch; the column sums for dgamma/dbeta go through LDS once per
-// workgroup and a fixed-order second stage (strided_sum_kernel), like the LSQ offsets.
+// One row is owned by TX lanes (32 or 64) holding J float4 each, so the row reductions are DPP/shuffle only; the forward
+// walks rows with a one-row software prefetch (the backward does not: its extra operand sets would cost a wave per
+// SIMD); the column sums for dgamma/dbeta go through LDS once per workgroup and a fixed-order second stage
+// (strided_sum_kernel_t), like the LSQ offsets.  With the template flag Q the per-token LSQ that consumes the LayerNorm
+// output is applied in the same pass (forward: codes only; backward: LSQ backward in front of the LayerNorm backward).
 #include "common.h"
 
 struct LnArgs {

@@ -11,8 +11,13 @@
 //                     dy fp32 is scaled along k by the weight scale and split into three bf16 pieces
 //                     (dy*ks = hi + mid + lo exactly: 3 x 8 significand bits), qwT are the weight codes as bf16;
 //                     three v_mfma_f32_32x32x16_bf16 per k-step give the fp32-exact product at 3/16 of the fp32-MFMA cost.
-// Both kernels: 256 threads = 2x2 waves, 128x128 tile, operands K-contiguous ("NT"), branch-free staging with
-// clamped addresses, LDS rows padded by 16 B so that ds_read_b128 fragments are conflict-free.
+// The 4-wave kernels: 256 threads = 2x2 waves, 128x128 tile, operands K-contiguous ("NT"), branch-free staging with
+// clamped addresses, LDS rows padded by 16 B so that ds_read_b128 fragments are conflict-free.  The linear layers'
+// gradient GEMMs use the 8-wave "wide" kernels further down (128 x 384 tiles, double-buffered LDS, LDS-only barriers,
+// two-step register prefetch): the fp32 -> 3 x bf16 split of a dY panel is paid once per 384 output columns.
+// Workgroup order is XCD-aware over the whole (tile, batch) grid (xcd_remap_grid).  Epilogue rule learnt the hard way:
+// no load behind a per-element condition (one memory round trip each) -- per-row terms go through LDS, old values
+// for C += ... are fetched unconditionally on clamped addresses.
 #include "common.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
