@@ -78,12 +78,16 @@ def _worker(rank, world, port, q):
     for b in dp.buckets:
         for p in b.params:
             assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
-    # second step works after the reset, and optimizer steps keep replicas identical
+    # second step works after the reset, and optimizer steps keep replicas identical; `extra` takes no part in these
+    # steps (no gradient): its bucket is launched by finish_gradient_sync with a zero contribution
     opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=1e-2)
     for _ in range(2):
         dp.zero_grad()
+        assert all(p.grad is None for p in net.parameters())
         ((dp(xs) - ys) ** 2).mean().backward()
+        assert net.extra.grad is None
         dp.finish_gradient_sync()
+        assert net.extra.grad is not None and float(net.extra.grad.abs().max()) == 0.0
         opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     lo, hi = flat.clone(), flat.clone()
