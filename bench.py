@@ -34,8 +34,8 @@ PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)          # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=128)
     ap.add_argument("--model", default="deit_small_distilled_patch16_224")
     ap.add_argument("--wbits", type=int, default=2)
