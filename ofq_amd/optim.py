@@ -14,6 +14,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._frozen = {}            # id(param) -> {0,1} fp32 mask of the parameter's shape (CGA), or absent
+        self._shared_step = {}       # group index -> the cpu `step` tensor shared by the group's parameters
 
     def set_frozen(self, param, mask):
         """CGA: elements with mask != 0 take no update this step (gradient masked, weight restored)."""
@@ -56,11 +57,17 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            # all tensors of a group take the same number of steps (as in torch: one `step` per tensor, advanced together)
-            t = int(self.state[plist[0]]["step"].item() if torch.is_tensor(self.state[plist[0]]["step"])
-                    else self.state[plist[0]]["step"]) + 1
-            for p in plist:
-                self.state[p]["step"] = torch.tensor(float(t))
+            # all tensors of a group take the same number of steps (as in torch: one `step` per tensor, advanced together);
+            # they share ONE cpu tensor object, advanced once, instead of 150 fresh tensors per step
+            first = self.state[plist[0]]["step"]
+            t = int(first.item() if torch.is_tensor(first) else first) + 1
+            shared = self._shared_step.get(gi)
+            if shared is None or any(self.state[p]["step"] is not shared for p in plist):
+                shared = self._shared_step[gi] = torch.tensor(float(t))
+                for p in plist:
+                    self.state[p]["step"] = shared
+            else:
+                shared.fill_(float(t))
             b1, b2 = group["betas"]
             tens = self._table(plist)
             ops._chk(lib.ofq_adamw_multi(tens.ctypes.data, len(plist), float(group["lr"]), float(b1), float(b2),
