@@ -173,8 +173,8 @@ int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, co
 int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, float* O, const float* sp, float gscale_p,
                     const float* sv, float gscale_v, const float* bav, const float* rp, int64_t B, int64_t H, int64_t N,
                     int64_t d, int64_t Np, ofq_stream_t stream);
-int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* av_eff, const float* w, int64_t B,
-                       int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream);
+int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* sv, float gscale_v, const float* w,
+                       int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream);
 int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
                        int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream);
 int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,

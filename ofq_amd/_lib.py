@@ -50,7 +50,7 @@ SIGNATURES = {
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_pv_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, i64, i64, i64, i64, i64, vp]),
-    "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp]),

@@ -349,6 +349,9 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
     const int k0 = kt * QBS_BK;
     const bool kina = (k0 + kqa) < K, kinb = (k0 + kqb) < K;       // K % 8 == 0 (host check)
     rks = ksp ? *reinterpret_cast<const float4*>(ksp + (kina ? k0 + kqa : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
+    if (B_I8 && p.gscale2 > 0.f)      // the k-scale is a raw LSQ step: take its effective value here (no host-side prep kernels)
+      rks = make_float4(ofq_lsq_eff_scale(rks.x, p.gscale2), ofq_lsq_eff_scale(rks.y, p.gscale2),
+                        ofq_lsq_eff_scale(rks.z, p.gscale2), ofq_lsq_eff_scale(rks.w, p.gscale2));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = *reinterpret_cast<const float4*>(A + offA[i] + (kina ? k0 : -kqa));
@@ -1888,12 +1891,12 @@ extern "C" int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, floa
   return 0;
 }
 // dP[b,h,n,m] = sum_c (dO[b,n,h*d+c]*av[h*d+c]) * qv[b,m,h*d+c] + w[b,n,h]
-extern "C" int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* av_eff, const float* w, int64_t B,
-                                  int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream) {
-  if (!dO || !vcodes || !dP || !av_eff || B <= 0 || H <= 0 || N <= 0 || (d & 7) || ldP < N) return OFQ_EINVAL;
+extern "C" int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* sv, float gscale_v,
+                                  const float* w, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream) {
+  if (!dO || !vcodes || !dP || !sv || B <= 0 || H <= 0 || N <= 0 || (d & 7) || ldP < N) return OFQ_EINVAL;
   QGemmArgs a = {};
   const int64_t C = H * d;
-  a.A = dO; a.B = vcodes; a.C = dP; a.s = av_eff; a.u = w; a.b_is_i8 = 1;
+  a.A = dO; a.B = vcodes; a.C = dP; a.s = sv; a.gscale2 = gscale_v; a.u = w; a.b_is_i8 = 1;
   a.lda = C; a.ldb = C; a.ldc = ldP;
   a.sA0 = N * C; a.sA1 = d; a.sB0 = N * C; a.sB1 = d; a.sC0 = H * N * ldP; a.sC1 = N * ldP; a.sK1 = d;
   a.M = (int)N; a.N = (int)N; a.K = (int)d; a.nb1 = (int)H; a.alpha = 1.f;

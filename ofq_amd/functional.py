@@ -425,8 +425,7 @@ class PVCodesFn(torch.autograd.Function):
         C = H * d
         dO = dO.contiguous()
         w = ops.rowdot_f32_seg(dO.view(B * N, C), aux["bav"], H, d)
-        av_eff = ops.lsq_eff_scale(aux["sv"], aux["gv"])
-        dP = ops.qattn_dp(dO, aux["vcodes"], av_eff, w, B, H, N, d, Np)
+        dP = ops.qattn_dp(dO, aux["vcodes"], aux["sv"], aux["gv"], w, B, H, N, d, Np)
         dV = ops.qattn_dv(dO, aux["pcodes"], aux["sp"], aux["gp"], B, H, N, d, Np)
         return dP, dV, None
 

@@ -429,11 +429,13 @@ def qattn_pv(pcodes, vcodesT, sp, gp, sv, gv, bav, rp, B, H, N, d, Np):
     return O
 
 
-def qattn_dp(dO, vcodes, av_eff, w, B, H, N, d, ldP):
+def qattn_dp(dO, vcodes, sv, gv, w, B, H, N, d, ldP):
+    """dP[b,h,n,m] = sum_j dO[b,n,hd+j] * (av_eff[hd+j] * qv[b,m,hd+j]) + w[b,n,h]; av_eff = effective value of the step sv
+    (taken inside the kernel when gv > 0; gv = 0: sv is used as is)"""
     dP = torch.empty((B, H, N, ldP), dtype=torch.float32, device=dO.device)
     with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
-        _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), av_eff.data_ptr(), _p(w), B, H, N, d,
-                                      ldP, _stream()), "ofq_qattn_dp_bf16s")
+        _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), sv.data_ptr(), float(gv), _p(w), B, H, N,
+                                      d, ldP, _stream()), "ofq_qattn_dp_bf16s")
     return dP
 
 

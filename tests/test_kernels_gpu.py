@@ -474,7 +474,8 @@ def test_qattn_code_kernels_vs_fp64(ops):
     # ---- dP, dV
     dO = T(det_normalish((B, N, C), 108, 1.0))
     w = ops.rowdot_f32_seg(cu(dO).view(B * N, C), cu(bav), H, d)
-    dP = ops.qattn_dp(cu(dO), cu(vcodes), cu(av.float()), w, B, H, N, d, Np)
+    dP = ops.qattn_dp(cu(dO), cu(vcodes), cu(av.float()), 0.0, w, B, H, N, d, Np)          # effective step given
+    assert torch.equal(dP[..., :N], ops.qattn_dp(cu(dO), cu(vcodes), cu(sv), gv, w, B, H, N, d, Np)[..., :N])   # ... or in-kernel
     dP_ref = torch.einsum("bnhj,bmhj->bhnm", dO.double().view(B, N, H, d), vh.view(B, N, H, d))
     assert rel_err(dP.cpu()[..., :N], dP_ref.float()) < 2e-6
     dV = ops.qattn_dv(cu(dO), cu(pcodes).view(torch.int8), cu(sp), gp, B, H, N, d, Np)

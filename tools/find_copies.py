@@ -26,12 +26,18 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
-want = sys.argv[1:] or ["aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::contiguous", "aten::clone"]
+want = sys.argv[1:] or ["aten::copy_", "aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::add", "aten::add_",
+                        "aten::contiguous", "aten::clone", "aten::sum", "aten::mul", "aten::div", "aten::mean", "aten::neg"]
 cnt = collections.Counter()
 for ev in prof.events():
     if ev.name in want:
-        st = [f for f in (ev.stack or []) if "ofq_amd" in f or "bench" in f or "torch/optim" in f or "autograd" in f][:3]
+        st = [f for f in (ev.stack or []) if "ofq_amd" in f or "bench" in f or "torch/optim" in f][:2]
         shp = str(ev.input_shapes)[:60]
         cnt[(ev.name, shp, " <- ".join(s.split("/")[-1] for s in st))] += 1
-for (k, v) in cnt.most_common(45):
+for (k, v) in cnt.most_common(60):
+    print(v, k)
+
+print("---- all aten ops by count")
+allc = collections.Counter(ev.name for ev in prof.events() if ev.name.startswith("aten::"))
+for (k, v) in allc.most_common(40):
     print(v, k)

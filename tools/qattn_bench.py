@@ -27,7 +27,7 @@ bench("pv i8", lambda: ops.qattn_pv(pcodes, vT, sp, .01, sv, .01, bav, rp, B, H,
 dO = torch.randn(B, N, C, device=dev)
 w = ops.rowdot_f32_seg(dO.view(B * N, C), bav, H, d)
 bench("rowdot w", lambda: ops.rowdot_f32_seg(dO.view(B * N, C), bav, H, d), 1)
-bench("dP bf16s", lambda: ops.qattn_dp(dO, vcodes, sv, w, B, H, N, d, Np), fl * d)
+bench("dP bf16s", lambda: ops.qattn_dp(dO, vcodes, sv, 0.01, w, B, H, N, d, Np), fl * d)
 bench("dV bf16s", lambda: ops.qattn_dv(dO, pcodes, sp, .01, B, H, N, d, Np), fl * d)
 dS = torch.zeros(B, H, N, Np, device=dev); dS[..., :N] = torch.randn(B, H, N, N, device=dev)
 bench("dqkx bf16s", lambda: ops.qattn_dqkx(dS, xcodes, sx, .01, bax, B, H, N, C, Np), fl * C)
