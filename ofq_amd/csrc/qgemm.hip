@@ -299,6 +299,23 @@ __device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+// three-way bf16 split of two neighbouring fp32 (one packed dword per plane).  Written on explicit 2-vectors so that the
+// pairs are the naturally aligned (x,y) / (z,w) halves of the loaded float4: left to the SLP vectoriser the pairing was
+// (x,w) / (y,z), whose register shuffles (v_mov of freshly loaded registers) forced early s_waitcnt vmcnt on the prefetch
+template <int NS>
+__device__ __forceinline__ void split_pair_bf16(f32x2v x, unsigned (&out)[NS]) {
+  f32x2v rem = x;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const u32x2v hb = __builtin_bit_cast(u32x2v, rem) & 0xffff0000u;
+    out[q] = (hb.x >> 16) | hb.y;
+    rem = rem - __builtin_bit_cast(f32x2v, hb);
+  }
+}
+
 __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
   // two small signed integers -> packed bf16 pair (exact for |v| <= 256)
   return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
@@ -780,10 +797,10 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   }
   // two register prefetch slots: the loads of k-step t are issued two steps before their LDS store (the ~2 us HBM
   // latency is longer than one k-step)
-  float4 ra[2][2];
+  f32x4v ra[2][2];
   float rs[2][2];
   bool rok[2][2], rbok[2][NJ];
-  uint2 rb[2][NJ];
+  u32x2v rb[2][NJ];
   float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool do_csum = direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0);
   // all element offsets fit 32 bits (host check); loads are unconditional on clamped rows, masking happens at the
@@ -797,15 +814,21 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   unsigned long long tlast = clock64();
   const unsigned long long tstart = tlast;
 #endif
-  auto gload = [&](int kt, auto SLOT) {
+  // gload / lstore run unconditionally on every k-step (tiles past t_end repeat tile t_end-1 with `live` false, so
+  // their rows are masked out of the column sums and their stage is never read): with `if (kt + 3 < t_end)` guards the
+  // wait-count pass merges the "loads not issued" path into the steady state and waits for *every* outstanding load
+  // in lstore, i.e. the two-step prefetch degenerates to one
+  auto gload = [&](int kt_, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
+    const bool live = kt_ < t_end;
+    const int kt = min(kt_, t_end - 1);
     const int k0 = kt * QTN_BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int k = k0 + a_k + 16 * i;
       const int kc = min(k, p.Ktok - 1);
-      rok[sl][i] = a_ok && k < p.Ktok;
-      ra[sl][i] = *reinterpret_cast<const float4*>(Ap + (unsigned)(kc * ldA));
+      rok[sl][i] = a_ok && k < p.Ktok && live;
+      ra[sl][i] = *reinterpret_cast<const f32x4v*>(Ap + (unsigned)(kc * ldA));
       rs[sl][i] = p.s[kmod[i]];
       kmod[i] += QTN_BK;                                   // gload runs on consecutive k-steps: k mod S incrementally
       kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;               // S >= QTN_BK (host check)
@@ -814,11 +837,17 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     for (int i = 0; i < NJ; ++i) {
       const int k = k0 + b_row[i];
       rbok[sl][i] = b_ok[i] && k < p.Ktok;
-      rb[sl][i] = *reinterpret_cast<const uint2*>(Bp[i] + (unsigned)(min(k, p.Ktok - 1) * ldB));
+      rb[sl][i] = *reinterpret_cast<const u32x2v*>(Bp[i] + (unsigned)(min(k, p.Ktok - 1) * ldB));
     }
   };
   auto lstore = [&](unsigned char* sb, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
+    // pin the slot's registers here: the k-loop body is one basic block, and without an ordered use the selects / masks
+    // on the loaded values are placed right behind the loads' issue (one k-step early), where they wait for them
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) asm volatile("" : "+v"(rb[sl][i]));
 #ifdef TNW_TIMING
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     TNW_T(4);
@@ -833,25 +862,18 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
       v.z = __uint_as_float(__float_as_uint(ra[sl][i].z) & msk);
       v.w = __uint_as_float(__float_as_uint(ra[sl][i].w) & msk);
       csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
-      float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-      float pc[NS][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float rem = x[e];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const float h = trunc_bf16(rem);
-          pc[q][e] = h;
-          rem = __fsub_rn(rem, h);
-        }
-      }
+      const f32x2v v01 = {v.x, v.y}, v23 = {v.z, v.w};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(v01 * sc, lo);
+      split_pair_bf16<NS>(v23 * sc, hi);
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
-        w.x = pack_hi16(pc[q][0], pc[q][1]);
-        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        w.x = lo[q];
+        w.y = hi[q];
         *reinterpret_cast<uint2*>(&sb[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
       }
+      __builtin_amdgcn_sched_barrier(0);     // one row chunk at a time: interleaving them only costs registers
     }
 #ifdef TNW_TIMING
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -860,13 +882,14 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
       const unsigned bm = rbok[sl][i] ? 0xffffffffu : 0u;
-      const int w0 = (int)(rb[sl][i].x & bm), w1 = (int)(rb[sl][i].y & bm);
+      const int w0 = (int)(rb[sl][i][0] & bm), w1 = (int)(rb[sl][i][1] & bm);
       uint4 w;
       w.x = i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
       w.y = i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
       w.z = i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
       w.w = i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
       *reinterpret_cast<uint4*>(&sb[NS * PLANE + b_row[i] * LDB + b_col[i] * 2]) = w;
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -881,31 +904,46 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   const int p16 = lane & 15;
   const int fr_a = (8 * lh + (p16 >> 2)) * LDA + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
   const int fr_b = (8 * lh + (p16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
-  // all fragments of a k-step (both 16-deep MFMA steps) are requested before the first MFMA, so the LDS latency is paid
-  // once per k-step instead of once per plane; the scheduling barrier keeps the compiler from sinking the reads back
+  // Fragment schedule of one k-step (two 16-deep MFMA steps): every fragment of the first step is requested before the
+  // first MFMA; the fragments of the second step are requested inside the first step's MFMA sequence, each dY plane
+  // into the registers of the plane that has just been used up (48 fragment VGPRs instead of 72 -- the kernel sits at
+  // the 256-VGPR limit of two waves per SIMD).  The scheduling barriers pin that order.
+  static_assert(QTN_BK == 32, "two MFMA steps per k-step");
   auto compute = [&](const unsigned char* sb) {
-    bf16x8 av[QTN_BK / 16][NS][2], bv[QTN_BK / 16][NJ];
+    bf16x8 av[NS][2], bv[2][NJ];
+    const unsigned char* sa = &sb[fr_a + wm * 64 * 2];
+    const unsigned char* sbb = &sb[NS * PLANE + fr_b + wn * 32 * NJ * 2];
 #pragma unroll
-    for (int ks = 0; ks < QTN_BK / 16; ++ks) {
+    for (int j = 0; j < NJ; ++j) bv[0][j] = tr_frag_ld<LDB>(sbb + j * 64);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bv[ks][j] = tr_frag_ld<LDB>(&sb[NS * PLANE + ks * 16 * LDB + fr_b + (wn * 32 * NJ + j * 32) * 2]);
+    for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          av[ks][q][i] = tr_frag_ld<LDA>(&sb[q * PLANE + ks * 16 * LDA + fr_a + (wm * 64 + i * 32) * 2]);
-    }
+      for (int i = 0; i < 2; ++i) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + i * 64);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < QTN_BK / 16; ++ks)
+    for (int q = 0; q < NS; ++q) {
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[0][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == 0) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) bv[1][j] = tr_frag_ld<LDB>(sbb + 16 * LDB + j * 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[1][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);       // the staging that follows waits on global loads: keep it behind the MFMAs
   };
 
 
@@ -916,26 +954,26 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     compute(cur);
     TNW_T(0);
-    if (kt + 1 < t_end) {
-      lstore(nxt, SLOT);
-      TNW_T(1);
-      if (kt + 3 < t_end) gload(kt + 3, SLOT);
-      TNW_T(2);
-    }
+    lstore(nxt, SLOT);
+    TNW_T(1);
+    gload(kt + 3, SLOT);
+    TNW_T(2);
     lds_barrier();
     TNW_T(3);
   };
 
   if (t_begin < t_end) {
     gload(t_begin, Slot0());
-    if (t_begin + 1 < t_end) gload(t_begin + 1, Slot1());
+    gload(t_begin + 1, Slot1());
     lstore(smem, Slot0());
-    if (t_begin + 2 < t_end) gload(t_begin + 2, Slot0());
+    gload(t_begin + 2, Slot0());
     lds_barrier();
-    for (int kt = t_begin; kt < t_end; kt += 2) {
+    int kt = t_begin;
+    for (; kt + 1 < t_end; kt += 2) {
       step(kt, smem, smem + STAGE, Slot1());                               // tile kt+1 lives in slot 1
-      if (kt + 1 < t_end) step(kt + 1, smem + STAGE, smem, Slot0());       // tile kt+2 in slot 0
+      step(kt + 1, smem + STAGE, smem, Slot0());                           // tile kt+2 in slot 0
     }
+    if (kt < t_end) step(kt, smem, smem + STAGE, Slot1());
   }
 #ifdef TNW_TIMING
   if (blockIdx.x == 0 && lane == 0) {
@@ -1425,7 +1463,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     pb[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + (tid & 3) * 8;
   }
   const int kqa = (tid & 7) * 4, kqb = (tid & 3) * 8;
-  float4 ra[2][2], rks[2];
+  f32x4v ra[2][2], rks[2];
   i32x4 rb[NB];                                         // weights are L2-resident: one step of prefetch is enough
   bool rka[2], rkb;
   auto gload = [&](int kt, auto SLOT) {
@@ -1433,9 +1471,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     const int k0 = kt * QBS_BK;
     rka[sl] = (k0 + kqa) < K;                           // K % 8 == 0 (host check): chunks are all-in or all-out
     const int ka = rka[sl] ? k0 : 0;
-    rks[sl] = p.s ? *reinterpret_cast<const float4*>(p.s + ka + kqa) : make_float4(1.f, 1.f, 1.f, 1.f);
+    // no scale vector: the load still happens (from the dY panel, any valid address) and the value is replaced at the
+    // LDS store; a load under `if (p.s)` ends in a register copy that has to wait for it, i.e. s_waitcnt vmcnt(0) here
+    rks[sl] = *reinterpret_cast<const f32x4v*>(p.s ? p.s + ka + kqa : pa[0]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[sl][i] = *reinterpret_cast<const float4*>(pa[i] + ka);
+    for (int i = 0; i < 2; ++i) ra[sl][i] = *reinterpret_cast<const f32x4v*>(pa[i] + ka);
   };
   auto gload_b = [&](int kt) {
     const int k0 = kt * QBS_BK;
@@ -1446,38 +1486,39 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   };
   auto lstore = [&](unsigned char* sb, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
-    float4 ks = rks[sl];
-    if (!rka[sl]) ks = make_float4(0.f, 0.f, 0.f, 0.f);      // beyond K: zero pieces (register select, the loads are done)
+    // pin the slot's registers here: the k-loop body is one basic block, and without an ordered use the selects on the
+    // loaded values are placed right behind the loads' issue (one k-step early), where they wait for them
+    asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
+    f32x4v ks = rks[sl];
+    if (!p.s) ks = f32x4v{1.f, 1.f, 1.f, 1.f};
+    if (!rka[sl]) ks = f32x4v{0.f, 0.f, 0.f, 0.f};           // beyond K: zero pieces (register select, the loads are done)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (tid + 512 * i) >> 3;
       const float z = okA[i] ? 1.f : 0.f;
-      float x[4] = {ra[sl][i].x * (ks.x * z), ra[sl][i].y * (ks.y * z), ra[sl][i].z * (ks.z * z), ra[sl][i].w * (ks.w * z)};
-      float pc[NS][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float rem = x[e];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const float h = trunc_bf16(rem);
-          pc[q][e] = h;
-          rem = __fsub_rn(rem, h);
-        }
-      }
+      const f32x2v k01 = {ks[0] * z, ks[1] * z}, k23 = {ks[2] * z, ks[3] * z};
+      const f32x2v a01 = {ra[sl][i][0], ra[sl][i][1]}, a23 = {ra[sl][i][2], ra[sl][i][3]};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(a01 * k01, lo);
+      split_pair_bf16<NS>(a23 * k23, hi);
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
-        w.x = pack_hi16(pc[q][0], pc[q][1]);
-        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        w.x = lo[q];
+        w.y = hi[q];
         *reinterpret_cast<uint2*>(&sb[q * PLANE + row * QBS_LD + kqa * 2]) = w;
       }
+      __builtin_amdgcn_sched_barrier(0);     // one row chunk at a time: interleaving them only costs registers
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[i]));
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = (tid + 512 * i) >> 2;
       const int m = (okB[i] && rkb) ? -1 : 0;
       *reinterpret_cast<i32x4*>(&sb[NS * PLANE + row * QBS_LD + kqb * 2]) = rb[i] & m;
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   f32x16q acc[2][NJ];
@@ -1512,28 +1553,39 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);       // the staging below consumes global loads: keep its waits behind the MFMAs
   };
 
   using Slot0 = std::integral_constant<int, 0>;
   using Slot1 = std::integral_constant<int, 1>;
+  // The k-loop body is branch-free: past the last tile the loads repeat tile nkt-1 and the staging writes a stage that
+  // nobody reads.  With `if (kt + 3 < nkt)` guards around the loads the compiler's wait-count pass merges the "not
+  // issued" path with the steady state and ends up waiting for every outstanding load at the top of each k-step
+  // (s_waitcnt vmcnt(0) right after the barrier), which cancels the two-step prefetch of the dY panel.
+  const int klast = nkt - 1;
+  // Issue order = consumption order (vmcnt counts in order): weights of tile kt+2, then the dY panel of tile kt+3, both
+  // after the staging of tile kt+1; the staging of the next step then waits with 3 / 6 younger loads still in flight.
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
-    if (kt + 1 < nkt) gload_b(kt + 1);
     compute(cur);
-    if (kt + 1 < nkt) {
-      lstore(nxt, SLOT);
-      if (kt + 3 < nkt) gload(kt + 3, SLOT);
-    }
+    lstore(nxt, SLOT);
+    gload_b(min(kt + 2, klast));
+    gload(min(kt + 3, klast), SLOT);
     lds_barrier();
   };
   gload(0, Slot0());
   gload_b(0);
-  if (1 < nkt) gload(1, Slot1());
+  gload(min(1, klast), Slot1());
   lstore(smem, Slot0());
-  if (2 < nkt) gload(2, Slot0());
+  gload_b(min(1, klast));
+  gload(min(2, klast), Slot0());
   lds_barrier();
-  for (int kt = 0; kt < nkt; kt += 2) {
-    step(kt, smem, smem + STAGE, Slot1());
-    if (kt + 1 < nkt) step(kt + 1, smem + STAGE, smem, Slot0());
+  {
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      step(kt, smem, smem + STAGE, Slot1());
+      step(kt + 1, smem + STAGE, smem, Slot0());
+    }
+    if (kt < nkt) step(kt, smem, smem + STAGE, Slot1());
   }
 
   if constexpr (!LSQ) {
