@@ -35,6 +35,25 @@ __device__ __forceinline__ float ofq_lsq_quant(float xin, float a, float lo, flo
   return __fadd_rn(__fsub_rn(q, u), u);
 }
 
+// The level q = rint(clamp(x / a, lo, hi)) of ofq_lsq_quant without the IEEE division sequence in the common case.
+// `ra` is the correctly rounded 1 / a, so x * ra is within 1.5 ulp of the correctly rounded x / a, and the two round to
+// the same level unless the clamped product lies within `tol` = 8 ulp(max(|lo|, |hi|) + 1) of a half-integer.  Callers
+// OR the `risky` flags of a group of elements and redo the group with ofq_lsq_level_exact when any lane of the wave
+// raised one (rare: ~1e-5 per element at 2-4 bits), so the levels stay bit-identical at ~7 instead of ~16 VALU each.
+__device__ __forceinline__ float ofq_lsq_level_tol(float lo, float hi) {
+  const float m = fmaxf(fabsf(lo), fabsf(hi)) + 1.f;
+  return 8.f * (m * 1.1920929e-7f);                   // 8 * ulp-ish (m * 2^-23 >= ulp(m))
+}
+__device__ __forceinline__ float ofq_lsq_level_rcp(float x, float ra, float lo, float hi, float half_m_tol, bool& risky) {
+  const float u = __builtin_amdgcn_fmed3f(__fmul_rn(x, ra), lo, hi);        // clamp in one instruction (lo <= hi)
+  const float q = rintf(u);
+  risky |= !(fabsf(__fsub_rn(u, q)) < half_m_tol);                          // NaN -> risky
+  return q;
+}
+__device__ __forceinline__ float ofq_lsq_level_exact(float x, float a, float lo, float hi) {
+  return rintf(fminf(fmaxf(ofq_div(x, a), lo), hi));
+}
+
 __device__ __forceinline__ float ofq_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -86,11 +86,27 @@ __device__ __forceinline__ void qgemm_tile_id(const QGemmArgs& p, int& tm, int& 
 #define QI8_BK 64                 // bytes of k per LDS stage (two 32x32x32 MFMA steps)
 #define QI8_LD (QI8_BK + 16)      // padded LDS row (bytes)
 
+// workgroup barrier that orders LDS traffic only: global prefetch loads stay in flight across it (__syncthreads would
+// drain vmcnt and expose the HBM latency once per k-step)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+#ifdef I8X_TIMING
+__device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one mid-grid workgroup (tools/probe/i8_probe.hip)
+#define I8_T(slot) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_i8_dbg[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define I8_T(slot) do {} while (0)
+#endif
+
 // EPI 0: linear layer   1: QKR attention scores   2: P*V
 template <int EPI>
-__global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_i8_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
+  I8_T(0);
   int tm, tn, gby;
   qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -117,26 +133,62 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
     offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + kq[i];
     offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + kq[i];
   }
-  i32x4 ra[2], rb[2];
-  auto gload = [&](int kt) {
+  // Epilogue parameters (per-row steps / offsets, per-column scales) are requested before the k-loop: a workgroup lives
+  // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
+  // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
+  // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
+  float pre_ra, pre_rb = 0.f, pre_c[2][5];
+  {
+    const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
+    pre_ra = p.s[m % p.S];
+    if (EPI == 0) {
+      const float* qsp = (p.qout && !p.qcolmode) ? p.qs + ((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS : p.s;
+      pre_rb = *qsp;
+    }
+    if (EPI == 1) pre_rb = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+    if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+    if (EPI == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nc = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
+        pre_c[j][0] = p.cs[nc];
+        pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
+        pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
+        pre_c[j][3] = ((p.qout && p.qb4) ? p.qb4 : p.cs)[nc];
+        pre_c[j][4] = ((p.qout && p.qcolmode) ? p.qs : p.cs)[nc];
+      }
+    }
+  }
+
+  // Two register slots: the loads of tile kt+3 are issued behind the staging of tile kt+1 and are first touched (masked)
+  // two k-steps later, so a k-step never waits for the HBM / L2 latency of its own loads (k-steps are only 8 MFMAs
+  // long here).  The loop body is branch-free (tiles past the end repeat the last one into a stage nobody reads): guards
+  // around the loads make the compiler's wait-count pass wait for every outstanding load at each k-step.
+  i32x4 ra[2][2], rb[2][2];
+  const int klast = nkt - 1;
+  auto gload = [&](int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
     const int k0 = kt * QI8_BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool kin = (k0 + kq[i]) < K;                 // K % 16 == 0 (host check): a chunk is all in or all out
-      const i32x4 va = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq[i]));
-      const i32x4 vb = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq[i]));
-      const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
-      ra[i] = va & ma;
-      rb[i] = vb & mb;
+      ra[sl][i] = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq[i]));
+      rb[sl][i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq[i]));
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](unsigned char* sb, int kt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rb[sl][i]));
+    const int k0 = kt * QI8_BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + 256 * i;
       const int row = f >> 2;
-      *reinterpret_cast<i32x4*>(&smem[buf][row * QI8_LD + kq[i]]) = ra[i];
-      *reinterpret_cast<i32x4*>(&smem[buf][(BM + row) * QI8_LD + kq[i]]) = rb[i];
+      const bool kin = (k0 + kq[i]) < K;
+      const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
+      *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i] & ma;
+      *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i] & mb;
     }
   };
 
@@ -148,15 +200,9 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = (kt + 1) < nkt;
-    if (more) gload(kt + 1);
-    const unsigned char* a = &smem[buf][(wm * 64 + l31) * QI8_LD + lh * 16];
-    const unsigned char* b = &smem[buf][(BM + wn * 64 + l31) * QI8_LD + lh * 16];
+  auto compute = [&](const unsigned char* sb) {
+    const unsigned char* a = &sb[(wm * 64 + l31) * QI8_LD + lh * 16];
+    const unsigned char* b = &sb[(BM + wn * 64 + l31) * QI8_LD + lh * 16];
 #pragma unroll
     for (int ks = 0; ks < QI8_BK / 32; ++ks) {
       i32x4 av[2], bv[2];
@@ -170,11 +216,33 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    compute(cur);
+    lstore(nxt, min(kt + 1, klast), SLOT);
+    gload(min(kt + 3, klast), SLOT);
+    lds_barrier();
+  };
+  gload(0, Slot0());
+  gload(min(1, klast), Slot1());
+  lstore(smem[0], 0, Slot0());
+  gload(min(2, klast), Slot0());
+  lds_barrier();
+  I8_T(1);
+#ifndef I8X_NO_KLOOP
+  {
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      step(kt, smem[0], smem[1], Slot1());
+      step(kt + 1, smem[1], smem[0], Slot0());
+    }
+    if (kt < nkt) step(kt, smem[0], smem[1], Slot1());
   }
-
+#endif
+  I8_T(2);
   float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
   int ncol[2];
 #pragma unroll
@@ -185,27 +253,100 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
   float* row_a = reinterpret_cast<float*>(&smem[0][0]);
   float* row_b = row_a + BM;
   if (tid < BM) {
-    const int m = min(m0 + tid, p.M - 1);
-    row_a[tid] = ofq_lsq_eff_scale(p.s[m % p.S], p.gscale);
-    if (EPI == 0 && p.qout && !p.qcolmode)
-      row_b[tid] = ofq_lsq_eff_scale(p.qs[((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS], p.qgscale);
-    if (EPI == 1) row_b[tid] = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
-    if (EPI == 2) row_b[tid] = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+    row_a[tid] = ofq_lsq_eff_scale(pre_ra, p.gscale);
+    if (EPI == 0 && p.qout && !p.qcolmode) {
+      const float rbv = ofq_lsq_eff_scale(pre_rb, p.qgscale);
+      row_b[tid] = rbv;
+      row_a[2 * BM + tid] = __fdiv_rn(1.f, rbv);                 // row_c: reciprocal steps for the fast level path
+    }
+    if (EPI == 1 || EPI == 2) row_b[tid] = pre_rb;
   }
   __syncthreads();
+  I8_T(3);
   if (EPI == 0) {
     // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
     float csn[2], rn[2], bz[2], qb[2], qsc[2];
     signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [128][128] codes, behind row_a / row_b
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int nc = min(ncol[j], p.N - 1);
-      csn[j] = p.cs[nc] * p.alpha;
-      rn[j] = p.r ? p.r[nc] : 0.f;
-      bz[j] = p.bias ? p.bias[nc] : 0.f;
-      qb[j] = (p.qout && p.qb4) ? p.qb4[nc] : 0.f;
-      qsc[j] = (p.qout && p.qcolmode) ? ofq_lsq_eff_scale(p.qs[nc], p.qgscale) : 1.f;
+      csn[j] = pre_c[j][0] * p.alpha;
+      rn[j] = p.r ? pre_c[j][1] : 0.f;
+      bz[j] = p.bias ? pre_c[j][2] : 0.f;
+      qb[j] = (p.qout && p.qb4) ? pre_c[j][3] : 0.f;
+      qsc[j] = (p.qout && p.qcolmode) ? ofq_lsq_eff_scale(pre_c[j][4], p.qgscale) : 1.f;
     }
+    // Interior tiles (every tile of the DeiT-S shapes) take a straight-line epilogue specialised on the by-product mode:
+    // no per-element bounds / mode branches, row pointers from scalar arithmetic (the lane adds one 32-bit offset),
+    // LDS addresses as immediates, and the level through ofq_lsq_level_rcp.  This epilogue is VALU-bound (the qkx
+    // GEMM spent ~70 of its 119 us in it), so instructions per element are what counts.
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && 4 * (4 * p.ldc + p.N) < (int64_t)0x7fffffff;
+    if (interior) {
+      const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+      const float* row_c = row_a + 2 * BM;
+      float qrc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) qrc[j] = (p.qout && p.qcolmode) ? __fdiv_rn(1.f, qsc[j]) : 1.f;
+      const unsigned lane_off4 = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
+      float* Cb_t = Cb + (int64_t)(m0 + wm_s * 64) * p.ldc;
+      signed char* ct = ctile + (wm_s * 64 + 4 * lh) * BN + wn_s * 64 + l31;
+      const float* ra_t = row_a + wm_s * 64 + 4 * lh;
+      const float qlo = p.qlo, qhi = p.qhi;
+      const float half_m_tol = 0.5f - ofq_lsq_level_tol(qlo, qhi);
+      auto tile = [&](auto QMODE_, auto QGELU_) {
+        constexpr int QMODE = decltype(QMODE_)::value;          // 0 none, 1 per-row step, 2 per-column step
+        constexpr bool QGELU = decltype(QGELU_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
+            float xq[4][2], qv[4][2], rbv[4];
+            bool risky = false;
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+              const int e = eg * 4 + ee;
+              const int r = i * 32 + ee + 8 * eg;
+              const float ae = ra_t[r];
+              rbv[ee] = QMODE == 1 ? ra_t[BM + r] : 1.f;
+              const float rrb = QMODE == 1 ? ra_t[2 * BM + r] : 1.f;
+              float* rowp = Cb_t + (int64_t)r * p.ldc;           // uniform: lives in an SGPR pair
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+                // scalar row base + 32-bit lane offset + immediate: no per-element address arithmetic on the VALU
+#ifndef I8X_NO_F32_STORE
+                if (j == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+                else asm volatile("global_store_dword %0, %1, %2 offset:128" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+#else
+                if (yv == 123.456f) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+#endif
+                if (QMODE != 0) {
+                  xq[ee][j] = __fadd_rn(QGELU ? ofq_gelu(yv) : yv, qb[j]);
+                  qv[ee][j] = ofq_lsq_level_rcp(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, half_m_tol, risky);
+                }
+              }
+            }
+            if (QMODE != 0) {
+              if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j)
+                    qv[ee][j] = ofq_lsq_level_exact(xq[ee][j], QMODE == 2 ? qsc[j] : rbv[ee], qlo, qhi);
+              }
+#pragma unroll
+              for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)(int)qv[ee][j];
+            }
+          }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if (!p.qout) tile(I0(), std::false_type());
+      else if (p.qcolmode) { if (p.qgelu) tile(I2(), std::true_type()); else tile(I2(), std::false_type()); }
+      else { if (p.qgelu) tile(I1(), std::true_type()); else tile(I1(), std::false_type()); }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -226,6 +367,8 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
             }
           }
       }
+    }
+    I8_T(4);
     if (p.qout) {       // the code tile goes out in 64-byte row pieces (two threads per row) instead of single bytes
       __syncthreads();
       const int row = tid >> 1, c0 = (tid & 1) * 64;
@@ -239,6 +382,7 @@ __global__ __launch_bounds__(256) void qgemm_i8_nt_kernel(QGemmArgs p) {
         }
       }
     }
+    I8_T(5);
   } else if (EPI == 1) {
     // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
     float aq[2], tqa[2];
@@ -727,19 +871,12 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   }
 }
 
+
 // Wide variant for the linear layers (split-K mode only): 8 waves own a 128 x (128*NJ) tile, so one split of a dY
 // panel feeds NJ times more MFMA work.  tools/probe/overlap_probe.hip shows that on gfx950 the VALU stream of one wave
 // does NOT overlap the MFMA stream of its SIMD partner (233 us together vs 103 + 135 us alone), so every split/convert
 // instruction is paid in full: the lever is fewer VALU instructions per MFMA, which the wide tile gives.  LDS is
 // double buffered with ONE barrier per k-step (LDS-only barrier: global prefetches stay in flight across it).
-// workgroup barrier that orders LDS traffic only: global prefetch loads stay in flight across it (__syncthreads would
-// drain vmcnt and expose the HBM latency once per k-step)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 template <int LD>
 __device__ __forceinline__ bf16x8 tr_frag_ld(const unsigned char* base) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));

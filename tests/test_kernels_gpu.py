@@ -624,3 +624,57 @@ def test_fused_adamw_matches_torch_adamw_and_cga_sequence(ops):
     other = torch.optim.AdamW(groups([t.clone().cuda().requires_grad_(True) for t in cpu]), lr=1e-3)
     other.load_state_dict(opt.state_dict())
     opt.load_state_dict(other.state_dict())
+
+
+def _adversarial_level_pairs(lo, hi, count, seed):
+    """(step a, input x) pairs, x within 3 ulp of a tie (k + 0.5) * a, for which rint(clip(fl(x * fl(1/a)))) differs from
+    the reference's rint(clip(fl(x / a))) -- the cases a reciprocal-multiply shortcut gets wrong -- padded with plain ties."""
+    rng = np.random.RandomState(seed)
+    n = 400000
+    a = (0.05 + rng.rand(n)).astype(np.float32)
+    k = rng.randint(lo - 1, hi + 2, size=n).astype(np.float32) + np.float32(0.5)
+    x = (k * a).astype(np.float32)
+    u = rng.randint(-3, 4, size=n)
+    for d in range(1, 4):
+        x[u >= d] = np.nextafter(x[u >= d], np.float32(np.inf))
+        x[u <= -d] = np.nextafter(x[u <= -d], np.float32(-np.inf))
+    ra = (np.float32(1) / a).astype(np.float32)
+    fast = np.rint(np.clip((x * ra).astype(np.float32), lo, hi))
+    exact = np.rint(np.clip((x / a).astype(np.float32), lo, hi))
+    bad = np.nonzero(fast != exact)[0]
+    assert bad.size >= count // 2, "the search should find plenty of disagreeing pairs"
+    idx = np.concatenate([bad[:count], np.arange(count)])[:count]
+    return a[idx], x[idx], exact[idx]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("colmode", [0, 1])
+@pytest.mark.parametrize("bits,signed", [(2, True), (2, False), (4, True), (8, False)])
+def test_i8_epilogue_levels_on_rounding_boundaries(ops, bits, signed, colmode):
+    """The fused next-layer codes of the int8 GEMM (interior-tile epilogue: reciprocal multiply, exact division only for
+    waves that flag a product next to a half-integer) must equal rint(clip(fl(x / a))) exactly where that matters: every
+    row (row mode) / column (column mode) of this tile carries a (step, input) pair on which x * (1/a) and x / a round to
+    different levels (qlinear.py:66-68, lsq.py:593-601)."""
+    M = N = 128
+    K = 16
+    lo, hi = (-(2 ** (bits - 1)), 2 ** (bits - 1) - 1) if signed else (0, 2 ** bits - 1)
+    a, x, want1 = _adversarial_level_pairs(lo, hi, 128, 40 + bits + 10 * colmode)
+    xc = torch.zeros((M, K), dtype=torch.int8, device="cuda")
+    wc = torch.zeros((N, K), dtype=torch.int8, device="cuda")
+    ones = torch.ones(128, device="cuda")
+    fuse = dict(s=T(a).cuda(), S=128, gscale=0.0, b4=None, lo=lo, hi=hi, gelu=0, colmode=colmode)
+    if colmode:      # y[m][n] = r[n] = x[n] (zero codes, unit scales)
+        y = ops.qgemm_i8_nt(xc, wc, None, ones, 1.0, T(x).cuda(), ones, M, 0.0, fuse=fuse)
+        want_y = np.broadcast_to(x[None, :], (M, N))
+        want = np.broadcast_to(want1[None, :], (M, N))
+    else:            # y[m][n] = a_eff[m] * (+-1) = x[m]: the row's input step carries |x|, the code product its sign
+        xc[:, 0] = torch.from_numpy(np.where(x < 0, -1, 1).astype(np.int8)).cuda()
+        wc[:, 0] = 1
+        y = ops.qgemm_i8_nt(xc, wc, None, ones, 1.0, None, T(np.abs(x)).cuda(), M, 0.0, fuse=fuse)
+        want_y = np.broadcast_to(x[:, None], (M, N))
+        want = np.broadcast_to(want1[:, None], (M, N))
+    assert np.array_equal(y.cpu().numpy(), want_y)
+    got = fuse["codes_out"].cpu().numpy().astype(np.float32)
+    if not signed and bits == 8:
+        got = np.where(got < 0, got + 256, got)                       # uint8 levels travel in an int8 tensor
+    assert np.array_equal(got, want)
