@@ -466,7 +466,7 @@ __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
 }
 
 template <int NSPLIT, bool B_I8>
-__global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSPLIT * PLANE + BN * QBS_LD];
@@ -504,59 +504,56 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   }
   const int kqa = (tid & 7) * 4;       // same for all 4 chunks (256 % 8 == 0)
   const int kqb = (tid & 3) * 8;
-  float4 ra[4], rks;
+  // gload only issues the loads; scaling, masking, the int8 -> bf16 conversion and the split happen at the LDS store of
+  // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
+  f32x4v ra[4], rks;
   i32x4 rb[2];
+  bool rkina = false, rkinb = false;
   auto gload = [&](int kt) {
     const int k0 = kt * QBS_BK;
     const bool kina = (k0 + kqa) < K, kinb = (k0 + kqb) < K;       // K % 8 == 0 (host check)
-    rks = ksp ? *reinterpret_cast<const float4*>(ksp + (kina ? k0 + kqa : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
-    if (B_I8 && p.gscale2 > 0.f)      // the k-scale is a raw LSQ step: take its effective value here (no host-side prep kernels)
-      rks = make_float4(ofq_lsq_eff_scale(rks.x, p.gscale2), ofq_lsq_eff_scale(rks.y, p.gscale2),
-                        ofq_lsq_eff_scale(rks.z, p.gscale2), ofq_lsq_eff_scale(rks.w, p.gscale2));
+    rks = *reinterpret_cast<const f32x4v*>(ksp ? ksp + (kina ? k0 + kqa : 0) : A + offA[0]);      // no ksp: any valid address
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = *reinterpret_cast<const float4*>(A + offA[i] + (kina ? k0 : -kqa));
-      if (!(okA[i] && kina)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[i] = v;
-    }
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4v*>(A + offA[i] + (kina ? k0 : -kqa));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (!B_I8) {
-        const i32x4 v = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
-        rb[i] = v & ((okB[i] && kinb) ? -1 : 0);
-      } else {   // 8 int8 codes -> 8 bf16
-        const uint2 v = *reinterpret_cast<const uint2*>(B8 + offB[i] + (kinb ? k0 : -kqb));
-        const int m = (okB[i] && kinb) ? -1 : 0;
-        const int w0 = (int)v.x & m, w1 = (int)v.y & m;
-        rb[i].x = (int)i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
-        rb[i].y = (int)i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
-        rb[i].z = (int)i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
-        rb[i].w = (int)i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
+        rb[i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
+      } else {
+        const u32x2v v = *reinterpret_cast<const u32x2v*>(B8 + offB[i] + (kinb ? k0 : -kqb));
+        rb[i].x = (int)v[0];
+        rb[i].y = (int)v[1];
       }
     }
+    rkina = kina;
+    rkinb = kinb;
   };
   auto lstore = [&]() {
+    asm volatile("" : "+v"(rks));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[i]));
+    float ks[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = ksp ? rks[e] : 1.f;
+      if (B_I8 && p.gscale2 > 0.f) t = ofq_lsq_eff_scale(t, p.gscale2);      // raw LSQ step -> effective value
+      ks[e] = rkina ? t : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + 256 * i;
       const int row = f >> 3;
-      float x[4] = {ra[i].x * rks.x, ra[i].y * rks.y, ra[i].z * rks.z, ra[i].w * rks.w};
-      float pc[NSPLIT][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float rem = x[e];
-#pragma unroll
-        for (int sidx = 0; sidx < NSPLIT; ++sidx) {
-          const float h = trunc_bf16(rem);
-          pc[sidx][e] = h;
-          rem = __fsub_rn(rem, h);          // exact: h holds the leading 8 significand bits of rem
-        }
-      }
+      const float z = okA[i] ? 1.f : 0.f;
+      const f32x2v k01 = {ks[0] * z, ks[1] * z}, k23 = {ks[2] * z, ks[3] * z};
+      const f32x2v a01 = {ra[i][0], ra[i][1]}, a23 = {ra[i][2], ra[i][3]};
+      unsigned lo[NSPLIT], hi[NSPLIT];
+      split_pair_bf16<NSPLIT>(a01 * k01, lo);
+      split_pair_bf16<NSPLIT>(a23 * k23, hi);
 #pragma unroll
       for (int sidx = 0; sidx < NSPLIT; ++sidx) {
         uint2 w;
-        w.x = pack_hi16(pc[sidx][0], pc[sidx][1]);
-        w.y = pack_hi16(pc[sidx][2], pc[sidx][3]);
+        w.x = lo[sidx];
+        w.y = hi[sidx];
         *reinterpret_cast<uint2*>(&smem[sidx * PLANE + row * QBS_LD + kqa * 2]) = w;
       }
     }
@@ -564,7 +561,22 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int f = tid + 256 * i;
       const int row = f >> 2;
-      *reinterpret_cast<i32x4*>(&smem[NSPLIT * PLANE + row * QBS_LD + kqb * 2]) = rb[i];
+      const int m = (okB[i] && rkinb) ? -1 : 0;
+      i32x4 w;
+      if (!B_I8) {
+        asm volatile("" : "+v"(rb[i]));
+        w = rb[i] & m;
+      } else {   // 8 int8 codes -> 8 bf16
+        int w0 = rb[i].x, w1 = rb[i].y;
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        w0 &= m;
+        w1 &= m;
+        w.x = (int)i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
+        w.y = (int)i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
+        w.z = (int)i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
+        w.w = (int)i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
+      }
+      *reinterpret_cast<i32x4*>(&smem[NSPLIT * PLANE + row * QBS_LD + kqb * 2]) = w;
     }
   };
 
@@ -580,7 +592,8 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   for (int kt = 0; kt < nkt; ++kt) {
     lstore();
     __syncthreads();
-    if (kt + 1 < nkt) gload(kt + 1);
+    gload(min(kt + 1, nkt - 1));        // unconditional (the last one is never stored) and pinned ahead of the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     const unsigned char* a = &smem[(wm * 64 + l31) * QBS_LD + lh * 16];
     const unsigned char* b = &smem[NSPLIT * PLANE + (wn * 64 + l31) * QBS_LD + lh * 16];
 #pragma unroll
@@ -687,7 +700,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   constexpr int BM = 128, BN = 128, NS = 3;
   constexpr int PLANE = QTN_BK * QTN_LD;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(NS + 1) * PLANE];
@@ -716,55 +729,69 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
   const bool b_ok = (n0 + b_c) < p.N;                      // N % 16 == 0
   const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1 + (a_ok ? m0 + a_t : 0);
   const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1 + (b_ok ? n0 + b_c : 0);
-  float4 ra[4];
+  // gload only issues the loads; masks, the effective step, the column sums and the split happen at the LDS store of
+  // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
+  f32x4v ra[4];
   float rs[4];
   i32x4 rb;
+  bool rok[4], rbok = false;
   float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of the raw dY (bias gradient), tn == 0 tiles only
   const bool do_csum = direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0);
-  auto gload = [&](int kt) {
-    const int k0 = kt * QTN_BK;
+  // token index modulo S, kept incrementally (gload runs on consecutive k-steps): the integer modulo is ~22 VALU
+  // instructions, four of them per k-step were a third of this kernel's staging work
+  const bool kmod_inc = p.S >= QTN_BK;
+  int kmod[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kmod[i] = (t_begin * QTN_BK + a_k + 8 * i) % p.S;
+  auto gload = [&](int kt_) {
+    const bool live = kt_ < t_end;                  // past the end: repeat the last tile, masked out of the column sums
+    const int k0 = min(kt_, t_end - 1) * QTN_BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + a_k + 8 * i;
       const int kc = min(k, p.Ktok - 1);
-      float4 v = *reinterpret_cast<const float4*>(Ap + (int64_t)kc * p.lda);
-      if (!(a_ok && k < p.Ktok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[i] = v;
-      csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
-      rs[i] = ofq_lsq_eff_scale(p.s[kc % p.S], p.gscale);
+      ra[i] = *reinterpret_cast<const f32x4v*>(Ap + (int64_t)kc * p.lda);
+      rs[i] = p.s[kmod_inc ? kmod[i] : kc % p.S];
+      kmod[i] += QTN_BK;
+      kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;
+      rok[i] = a_ok && k < p.Ktok && live;
     }
     const int k = k0 + b_k;
-    const i32x4 v = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb);
-    rb = v & ((b_ok && k < p.Ktok) ? -1 : 0);
+    rb = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb);
+    rbok = b_ok && k < p.Ktok;
   };
   auto lstore = [&]() {
 #pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[i]), "+v"(rs[i]));
+    asm volatile("" : "+v"(rb));
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float x[4] = {ra[i].x * rs[i], ra[i].y * rs[i], ra[i].z * rs[i], ra[i].w * rs[i]};
-      float pc[NS][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float rem = x[e];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const float h = trunc_bf16(rem);
-          pc[q][e] = h;
-          rem = __fsub_rn(rem, h);
-        }
-      }
+      const unsigned msk = rok[i] ? 0xffffffffu : 0u;
+      float4 v;
+      v.x = __uint_as_float(__float_as_uint(ra[i][0]) & msk);
+      v.y = __uint_as_float(__float_as_uint(ra[i][1]) & msk);
+      v.z = __uint_as_float(__float_as_uint(ra[i][2]) & msk);
+      v.w = __uint_as_float(__float_as_uint(ra[i][3]) & msk);
+      csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
+      const float sc = ofq_lsq_eff_scale(rs[i], p.gscale);
+      const f32x2v v01 = {v.x, v.y}, v23 = {v.z, v.w};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(v01 * sc, lo);
+      split_pair_bf16<NS>(v23 * sc, hi);
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
-        w.x = pack_hi16(pc[q][0], pc[q][1]);
-        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        w.x = lo[q];
+        w.y = hi[q];
         *reinterpret_cast<uint2*>(&smem[q * PLANE + (a_k + 8 * i) * QTN_LD + a_t * 2]) = w;
       }
     }
     // 16 int8 codes -> 16 bf16
+    const i32x4 rbm = rb & (rbok ? -1 : 0);
     unsigned w[8];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const int word = rb[d];
+      const int word = rbm[d];
       w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
       w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
     }
@@ -790,7 +817,8 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_tn_kernel(QTnArgs p) {
     for (int kt = t_begin; kt < t_end; ++kt) {
       lstore();
       __syncthreads();
-      if (kt + 1 < t_end) gload(kt + 1);
+      gload(kt + 1);                       // unconditional (clamped, masked past the end), pinned ahead of the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < QTN_BK / 16; ++ks) {
         bf16x8 bv[2];
@@ -1266,7 +1294,7 @@ struct QNnArgs {
   float gscale;
 };
 
-__global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_nn_kernel(QNnArgs p) {
   constexpr int BM = 128, NS = 3;
   constexpr int PLANE_A = BM * QBS_LD;              // [row][k] bf16, 80 B rows
   constexpr int PLANE_B = QTN_BK * QTN_LD;          // [k][c]  bf16, 320 B rows
@@ -1296,58 +1324,61 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
   const int kqa = (tid & 7) * 4;
   const int b_k = tid >> 3, b_c = (tid & 7) * 16;
   const bool b_ok = (n0 + b_c) < p.N;
-  float4 ra[4], rks;
+  // gload only issues the loads (raw values + the masks as flags); scaling, masking and the split happen at the LDS
+  // store of the next iteration, behind the MFMAs of this one.  Touching a loaded value inside gload (mask select,
+  // effective-step arithmetic) puts the wait for it in front of the MFMAs, i.e. no overlap inside the workgroup.
+  f32x4v ra[4];
+  float rsv[4];
   i32x4 rb;
+  bool rkin = false, rbk = false;
   auto gload = [&](int t) {
     const int kb = t / nkt, kt = t - kb * nkt;
     const int k0 = kt * QBS_BK;
     const bool kina = (k0 + kqa) < K;
     const int kbase = kina ? k0 + kqa : 0;
     const float* sp = p.s + kb;
-    rks.x = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 0, K - 1) * p.ks_stride], p.gscale);
-    rks.y = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 1, K - 1) * p.ks_stride], p.gscale);
-    rks.z = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 2, K - 1) * p.ks_stride], p.gscale);
-    rks.w = ofq_lsq_eff_scale(sp[(int64_t)min(kbase + 3, K - 1) * p.ks_stride], p.gscale);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rsv[e] = sp[(int64_t)min(kbase + e, K - 1) * p.ks_stride];
     const float* At = Ab + kb * p.sAk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = *reinterpret_cast<const float4*>(At + offA[i] + (kina ? k0 : -kqa));
-      if (!(okA[i] && kina)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[i] = v;
-    }
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4v*>(At + offA[i] + (kina ? k0 : -kqa));
+    rkin = kina;
     const int k = k0 + b_k;
-    const i32x4 v = *reinterpret_cast<const i32x4*>(Bb + kb * p.sBk + (int64_t)min(k, K - 1) * p.ldb + (b_ok ? n0 + b_c : 0));
-    rb = v & ((b_ok && k < K) ? -1 : 0);
+    rb = *reinterpret_cast<const i32x4*>(Bb + kb * p.sBk + (int64_t)min(k, K - 1) * p.ldb + (b_ok ? n0 + b_c : 0));
+    rbk = b_ok && k < K;
   };
   auto lstore = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(rsv[e]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[i]));
+    asm volatile("" : "+v"(rb));
+    float ks[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ks[e] = rkin ? ofq_lsq_eff_scale(rsv[e], p.gscale) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + 256 * i;
       const int row = f >> 3;
-      float x[4] = {ra[i].x * rks.x, ra[i].y * rks.y, ra[i].z * rks.z, ra[i].w * rks.w};
-      float pc[NS][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float rem = x[e];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const float h = trunc_bf16(rem);
-          pc[q][e] = h;
-          rem = __fsub_rn(rem, h);
-        }
-      }
+      const float z = okA[i] ? 1.f : 0.f;
+      const f32x2v k01 = {ks[0] * z, ks[1] * z}, k23 = {ks[2] * z, ks[3] * z};
+      const f32x2v a01 = {ra[i][0], ra[i][1]}, a23 = {ra[i][2], ra[i][3]};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(a01 * k01, lo);
+      split_pair_bf16<NS>(a23 * k23, hi);
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
-        w.x = pack_hi16(pc[q][0], pc[q][1]);
-        w.y = pack_hi16(pc[q][2], pc[q][3]);
+        w.x = lo[q];
+        w.y = hi[q];
         *reinterpret_cast<uint2*>(&smem[q * PLANE_A + row * QBS_LD + kqa * 2]) = w;
       }
     }
+    const i32x4 rbm = rb & (rbk ? -1 : 0);
     unsigned w[8];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const int word = rb[d];
+      const int word = rbm[d];
       w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
       w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
     }
@@ -1370,7 +1401,8 @@ __global__ __launch_bounds__(256) void qgemm_bf16s_nn_kernel(QNnArgs p) {
   for (int t = 0; t < T; ++t) {
     lstore();
     __syncthreads();
-    if (t + 1 < T) gload(t + 1);
+    gload(min(t + 1, T - 1));          // unconditional (the last one is never stored): no guard, no merged wait state
+    __builtin_amdgcn_sched_barrier(0);  // ... and ahead of the MFMAs (the scheduler otherwise sinks the loads below them)
     const unsigned char* a = &smem[(wm * 64 + l31) * QBS_LD + lh * 16];
 #pragma unroll
     for (int ks = 0; ks < QBS_BK / 16; ++ks) {
