@@ -249,9 +249,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s W%dA%d%s%s QAT step (student fwd + KD loss + bwd + AdamW), %d img/GPU, "
-                                      "198 tokens, fp32, %s"
+                                      "%s, fp32, %s"
                                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
                                          " + CGA hooks" if args.cga else "", B,
+                                         "7x7 windows" if args.model.startswith("swin") else "198 tokens",
                                          "fp32 teacher forward in the step" if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss.detach())},
                "roofline": roof}
