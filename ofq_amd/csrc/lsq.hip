@@ -120,30 +120,44 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
   if (active_row_group) {
     // software-pipelined row walk: the next row's loads are issued before the current row is processed, so a wave
     // always has 2 rows (J float4 per tensor each) in flight and the stores never sit between a load and its use
+    // The loads of a row (x, g and the row's step) are issued together, unconditionally -- lanes past the width and
+    // the row past the end read a clamped, valid address -- and consumed together one iteration later.  Guards around
+    // them (`if (cok[j])`, `if (r + rstride < R)`) and the step loaded by itself inside the iteration made the
+    // compiler wait for every outstanding load right after issuing the next row's (s_waitcnt vmcnt(0)).
     const int64_t rstride = (int64_t)gridDim.x * TY;
     int64_t r = (int64_t)blockIdx.x * TY + ty;
     float4 xn[J], gn[J];
-    auto issue = [&](int64_t rr) {
+    float sn = 1.f;
+    int64_t ccol[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) ccol[j] = cok[j] ? (c4base + tx + (int64_t)j * TX) * 4 : 0;
+    const int smod_step = (int)(rstride % a.S);
+    int smod = (int)(r % a.S);                         // r mod S, kept incrementally
+    auto issue = [&](int64_t rr, int sm) {
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        if (cok[j]) {
-          const int64_t col = (c4base + tx + (int64_t)j * TX) * 4;
-          xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + col);
-          if (BWD) gn[j] = *reinterpret_cast<const float4*>(a.g + rr * a.ldy + col);
-        }
+        xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + ccol[j]);
+        if (BWD) gn[j] = *reinterpret_cast<const float4*>(a.g + rr * a.ldy + ccol[j]);
       }
+      if (!COLMODE) sn = a.s[sm];
     };
-    if (r < a.R) issue(r);
+    if (r < a.R) issue(r, smod);
     for (; r < a.R; r += rstride) {
       float arow = 1.f;
-      if (!COLMODE) arow = ofq_lsq_eff_scale(a.s[r % a.S], a.gscale);
+      if (!COLMODE) arow = ofq_lsq_eff_scale(sn, a.gscale);
       float4 xv[J], gv[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         xv[j] = xn[j];
         if (BWD) gv[j] = gn[j];
       }
-      if (r + rstride < a.R) issue(r + rstride);
+      {
+        int sm2 = smod + smod_step;
+        sm2 -= (sm2 >= a.S) ? a.S : 0;
+        smod = sm2;
+        const int64_t rn = r + rstride;
+        issue(rn < a.R ? rn : r, smod);
+      }
       float rowds = 0.f;
 #pragma unroll
       for (int j = 0; j < J; ++j) {

@@ -5,6 +5,8 @@ about twenty Function nodes, each one or two kernel launches, with hand-derived 
 Shapes: B batch, N tokens, C channels, H heads, d = C/H, Np = N rounded up to a multiple of 4 (row stride
 of the attention matrices, so that their rows stay 16-byte aligned for float4 loads).
 """
+import os
+
 import torch
 
 from . import ops
@@ -37,6 +39,10 @@ class LinearFn(torch.autograd.Function):
         dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dy2d) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return (dx.view(ctx.in_shape) if dx is not None else None), dW, db
+
+
+# attention scores backward: also add the (mathematically zero) row-sum term of dx_hat, as the reference's autograd does
+KEEP_ZERO_ROWSUM_TERM = os.environ.get("OFQ_KEEP_ZERO_ROWSUM_TERM", "0") == "1"
 
 
 def _shared_grad(acc, shape, device):
@@ -366,10 +372,13 @@ class QKRScoresCodesFn(torch.autograd.Function):
         dxq, accumulate, ret = _shared_grad(aux.get("xgrad_acc"), (B, N, C), dS.device)
         ops.qattn_dxq(dS, aux["qcodes"], aux["sq"], aux["gq"], B, H, N, C, Np, out=dxq, accumulate=accumulate)
         rs = aux["link"].pop("ds_rowsum", None)
-        if rs is None:
-            rs = dS[..., :N].sum(-1).reshape(-1)
-        # + sum_h rowsum_m(dS)[b,h,n] * baq[h,c]   (zero in exact arithmetic)
-        dxq.view(B * N, C).addmm_(rs.view(B, H, N).permute(0, 2, 1).reshape(B * N, H), aux["baq"].view(H, C))
+        if KEEP_ZERO_ROWSUM_TERM:
+            # + sum_h rowsum_m(dS)[b,h,n] * baq[h,c]: the offset move_qkx_aft enters x_hat . (q + baq)^T, so dx_hat gets
+            # rowsum(dS) * baq.  dS is a softmax backward, whose rows sum to zero: the term is fp32 rounding residue
+            # (~1e-7 of dx_hat, 1e-3 is the parity tolerance) and cost a K=6 GEMM over the 39 MB buffer per block.
+            if rs is None:
+                rs = dS[..., :N].sum(-1).reshape(-1)
+            dxq.view(B * N, C).addmm_(rs.view(B, H, N).permute(0, 2, 1).reshape(B * N, H), aux["baq"].view(H, C))
         return ret, dqkx, None
 
 
