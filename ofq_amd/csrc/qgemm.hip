@@ -336,7 +336,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
               for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
+#ifndef I8X_NO_CODE_LDS
                 for (int j = 0; j < 2; ++j) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)(int)qv[ee][j];
+#else
+                for (int j = 0; j < 2; ++j) if (qv[ee][j] == 77.f) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)1;
+#endif
             }
           }
       };
@@ -458,6 +462,30 @@ __device__ __forceinline__ void split_pair_bf16(f32x2v x, unsigned (&out)[NS]) {
     out[q] = (hb.x >> 16) | hb.y;
     rem = rem - __builtin_bit_cast(f32x2v, hb);
   }
+}
+
+// ---- staging work interleaved into the MFMA stream -------------------------------------------------------------------
+// tools/probe/filler_probe.hip: single-issue VALU instructions that follow an MFMA in the SAME wave's program order hide
+// in its shadow -- with two waves per SIMD the first two per MFMA are free and each further one costs ~2.2 cycles
+// instead of 4 -- while one v_pk_mul_f32 there costs ~10 cycles.  So the k-loops below place a few scalar staging
+// instructions behind every MFMA (pinned with sched_barrier) instead of running the staging as a block after the MFMAs,
+// and the split is written with these one-instruction wrappers so that the SLP vectoriser cannot re-pack it.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ float valu_mul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float valu_sub(float a, float b) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float valu_add(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float valu_hi16(float a) { float d; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(a)); return d; }
+// (lo_elem >> 16) | (hi_elem & 0xffff0000): the bf16 pair of two fp32 (truncating), one v_perm_b32
+__device__ __forceinline__ unsigned valu_pack_hi16(float lo_elem, float hi_elem) {
+  unsigned d;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi_elem), "v"(lo_elem), "s"(0x07060302u));
+  return d;
 }
 
 __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
@@ -1734,6 +1762,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   const int klast = nkt - 1;
   // Issue order = consumption order (vmcnt counts in order): weights of tile kt+2, then the dY panel of tile kt+3, both
   // after the staging of tile kt+1; the staging of the next step then waits with 3 / 6 younger loads still in flight.
+#ifdef NTW_SERIAL_STAGING
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     compute(cur);
     lstore(nxt, SLOT);
@@ -1741,6 +1770,94 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     gload(min(kt + 3, klast), SLOT);
     lds_barrier();
   };
+#else
+  // One k-step with the staging of tile kt+1 and the loads of tiles kt+2 / kt+3 cut into NP small pieces that are
+  // spread behind the 12*NJ MFMAs of tile kt (see the note at static_for above).  Piece list, per 128-row chunk i of the
+  // dY panel (17 pieces): for each half (x,y) / (z,w) of the float4 -- per element: [x = a*ks, p0 = hi16(x)],
+  // [r1 = x - p0, p1 = hi16(r1)], [r2 = r1 - p1] (r2 has <= 8 significant bits: it is its own bf16 plane), then one
+  // piece packing the three planes of the pair -- and three LDS stores; then the weight chunks (store each, no masks:
+  // rows past N only feed columns that are never written, k past K is zeroed through ks), then the six loads in
+  // consumption order.
+  constexpr int NM = 12 * NJ, NPA = 17, NP = 2 * NPA + NB + NB + 3;
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
+    const unsigned char* b = &cur[NS * PLANE + (wn * 32 * NJ + l31) * QBS_LD + lh * 16];
+    bf16x8 av[QBS_BK / 16][NS][2], bv[QBS_BK / 16][NJ];
+#pragma unroll
+    for (int ks = 0; ks < QBS_BK / 16; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[ks][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD + ks * 32);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          av[ks][q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + ks * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float ksv[4], x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+    unsigned lo[NS], hi[NS];
+    const int kb2 = min(kt + 2, klast) * QBS_BK, ka3 = min(kt + 3, klast) * QBS_BK;
+    auto piece = [&](auto P_) {
+      constexpr int P = decltype(P_)::value;
+      if constexpr (P < 2 * NPA) {
+        constexpr int i = P / NPA, r = P % NPA;
+        if constexpr (r == 0 && i == 0) {          // first touch of the slot: the wait for its loads lands here
+          asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ksv[e] = rka[sl] ? (p.s ? rks[sl][e] : 1.f) : 0.f;
+        }
+        if constexpr (r < 14) {
+          constexpr int pr = r / 7, rr = r % 7;
+          if constexpr (rr < 6) {
+            constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+            if constexpr (st == 0) { x_ = valu_mul(ra[sl][i][e], ksv[e]); p0v[el] = valu_hi16(x_); }
+            if constexpr (st == 1) { r1_ = valu_sub(x_, p0v[el]); p1v[el] = valu_hi16(r1_); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+          } else {
+            unsigned* dst = pr == 0 ? lo : hi;
+            dst[0] = valu_pack_hi16(p0v[0], p0v[1]);
+            dst[1] = valu_pack_hi16(p1v[0], p1v[1]);
+            dst[2] = valu_pack_hi16(r2v[0], r2v[1]);
+          }
+        } else {
+          constexpr int q = r - 14;
+          const int row = (tid + 512 * i) >> 3;
+          uint2 w;
+          w.x = lo[q];
+          w.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = w;
+        }
+      } else if constexpr (P < 2 * NPA + NB) {
+        constexpr int i = P - 2 * NPA;
+        const int row = (tid + 512 * i) >> 2;
+        asm volatile("" : "+v"(rb[i]));
+        *reinterpret_cast<i32x4*>(&nxt[NS * PLANE + row * QBS_LD + kqb * 2]) = rb[i];
+      } else if constexpr (P < 2 * NPA + 2 * NB) {
+        constexpr int i = P - 2 * NPA - NB;
+        rb[i] = *reinterpret_cast<const i32x4*>(pb[i] + ((kb2 + kqb) < K ? kb2 : 0));
+      } else {
+        constexpr int w = P - 2 * NPA - 2 * NB;
+        if constexpr (w == 0) {
+          rka[sl] = (ka3 + kqa) < K;
+          rks[sl] = *reinterpret_cast<const f32x4v*>(p.s ? p.s + (rka[sl] ? ka3 : 0) + kqa : pa[0]);
+        } else {
+          ra[sl][w - 1] = *reinterpret_cast<const f32x4v*>(pa[w - 1] + (rka[sl] ? ka3 : 0));
+        }
+      }
+    };
+    static_assert(NS == 3, "three planes");
+    static_for<NM>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+  };
+#endif
   gload(0, Slot0());
   gload_b(0);
   gload(min(1, klast), Slot1());
