@@ -481,7 +481,51 @@ __device__ __forceinline__ float valu_mul(float a, float b) { float d; asm("v_mu
 __device__ __forceinline__ float valu_sub(float a, float b) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float valu_add(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float valu_hi16(float a) { float d; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(d) : "v"(a)); return d; }
+__device__ __forceinline__ float valu_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float valu_fma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// byte BYTE of w, sign-extended, as fp32 (one SDWA convert)
+template <int BYTE>
+__device__ __forceinline__ float valu_cvt_i8(unsigned w) {
+  float d;
+  if constexpr (BYTE == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(d) : "v"(w));
+  if constexpr (BYTE == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(d) : "v"(w));
+  if constexpr (BYTE == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(d) : "v"(w));
+  if constexpr (BYTE == 3) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(d) : "v"(w));
+  return d;
+}
+// four int8 codes of one dword -> two packed bf16 pairs (exact), one asm statement (4 SDWA converts + 2 v_perm_b32)
+__device__ __forceinline__ void valu_cvt4_i8_bf16(unsigned w, unsigned& d01, unsigned& d23) {
+  float t0, t1, t2, t3;
+  asm("v_cvt_f32_i32_sdwa %2, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0\n\t"
+      "v_cvt_f32_i32_sdwa %3, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+      "v_cvt_f32_i32_sdwa %4, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n\t"
+      "v_cvt_f32_i32_sdwa %5, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3\n\t"
+      "v_perm_b32 %0, %3, %2, %7\n\t"
+      "v_perm_b32 %1, %5, %4, %7"
+      : "=&v"(d01), "=&v"(d23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(w), "s"(0x07060302u));
+}
+// ofq_lsq_eff_scale, instruction for instruction: a = max(s, 1e-5); t = a * g; (a - t) + t
+__device__ __forceinline__ float valu_eff_scale(float s, float g) {
+  float a, t, d;
+  asm("v_max_f32 %0, 0x3727c5ac, %3\n\tv_mul_f32 %1, %0, %4\n\tv_sub_f32 %2, %0, %1\n\tv_add_f32 %2, %2, %1"
+      : "=&v"(a), "=&v"(t), "=&v"(d) : "v"(s), "v"(g));
+  return d;
+}
+// two-instruction steps of the split as ONE asm statement: between separate asm statements the hazard recogniser pads
+// with s_nop (it cannot see what they are), which costs an issue slot each
+__device__ __forceinline__ void valu_mul_hi16(float a, float b, float& x, float& p0) {        // x = a*b; p0 = hi16(x)
+  asm("v_mul_f32 %0, %2, %3\n\tv_and_b32 %1, 0xffff0000, %0" : "=&v"(x), "=v"(p0) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void valu_sub_hi16(float a, float b, float& r, float& p) {          // r = a-b; p = hi16(r)
+  asm("v_sub_f32 %0, %2, %3\n\tv_and_b32 %1, 0xffff0000, %0" : "=&v"(r), "=v"(p) : "v"(a), "v"(b));
+}
 // (lo_elem >> 16) | (hi_elem & 0xffff0000): the bf16 pair of two fp32 (truncating), one v_perm_b32
+__device__ __forceinline__ void valu_pack3_hi16(const float (&a)[2], const float (&b)[2], const float (&c)[2], unsigned* d) {
+  asm("v_perm_b32 %0, %4, %3, %9\n\tv_perm_b32 %1, %6, %5, %9\n\tv_perm_b32 %2, %8, %7, %9"
+      : "=&v"(d[0]), "=&v"(d[1]), "=v"(d[2])
+      : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]), "v"(c[0]), "v"(c[1]), "s"(0x07060302u));
+}
 __device__ __forceinline__ unsigned valu_pack_hi16(float lo_elem, float hi_elem) {
   unsigned d;
   asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi_elem), "v"(lo_elem), "s"(0x07060302u));
@@ -1144,6 +1188,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   using Slot1 = std::integral_constant<int, 1>;
   // one k-step: MFMA on `cur` (tile kt) and staging of tile kt+1 (register slot (kt+1)&1 -> `nxt`), then the loads of
   // tile kt+3 into the freed slot
+#ifdef TNW_SERIAL_STAGING
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     compute(cur);
     TNW_T(0);
@@ -1154,6 +1199,108 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     lds_barrier();
     TNW_T(3);
   };
+#else
+  // One k-step with the staging of tile kt+1 and the loads of tile kt+3 cut into small pieces behind the 12*NJ MFMAs of
+  // tile kt (see the note at static_for).  Per dY row chunk i (18 pieces): [effective step of the row, masked], then per
+  // element [x = v*sc, column sum, p0 = hi16(x)] [r1 = x - p0, p1 = hi16(r1)] [r2 = r1 - p1] with a pack piece after
+  // each pair, then three LDS stores; per code chunk: two convert+pack pieces (no masks: tokens past Ktok are zeroed
+  // through sc, columns past N are never written) and a store; then the seven loads in consumption order.  The
+  // fragments of the second 16-deep MFMA step are read behind the MFMAs that used up their registers.
+  constexpr int NM = 12 * NJ, NPA = 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned offA[2] = {0u, 0u}, offB[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) offB[j] = 0u;
+  const unsigned stepA = 4u * (unsigned)(QTN_BK * ldA), stepB = (unsigned)(QTN_BK * ldB);
+  const unsigned maxA = 4u * (unsigned)((p.Ktok - 1) * ldA), maxB = (unsigned)((p.Ktok - 1) * ldB);
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    bf16x8 av[NS][2], bv[2][NJ];
+    const unsigned char* sa = &cur[fr_a + wm * 64 * 2];
+    const unsigned char* sbb = &cur[NS * PLANE + fr_b + wn * 32 * NJ * 2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[0][j] = tr_frag_ld<LDB>(sbb + j * 64);
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + i * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    float sc = 0.f, okf = 0.f, x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+    unsigned lo[NS], hi[NS], bw[4];
+    // loads of tile kt+3 (clamped to the last tile of this split, masked out when past it)
+    const bool live3 = kt + 3 < t_end;
+    const int rows_left3 = p.Ktok - min(kt + 3, t_end - 1) * QTN_BK;       // token rows of that tile that exist
+    const unsigned advA = live3 ? stepA : 0u, advB = live3 ? stepB : 0u;
+    auto piece = [&](auto P_) {
+      constexpr int P = decltype(P_)::value;
+      if constexpr (P < 2 * NPA) {
+        constexpr int i = P / NPA, r = P % NPA;
+        if constexpr (r == 0) {
+          asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));       // first touch: the wait for the slot's loads lands here
+          const float e = valu_eff_scale(rs[sl][i], p.gscale);
+          sc = rok[sl][i] ? e : 0.f;
+          okf = rok[sl][i] ? 1.f : 0.f;
+        } else if constexpr (r < 15) {
+          constexpr int pr = (r - 1) / 7, rr = (r - 1) % 7;
+          if constexpr (rr < 6) {
+            constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+            if constexpr (st == 0) {
+              valu_mul_hi16(ra[sl][i][e], sc, x_, p0v[el]);
+              cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
+            }
+            if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+          } else {
+            valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
+          }
+        } else {
+          constexpr int q = r - 15;
+          uint2 w;
+          w.x = lo[q];
+          w.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+        }
+      } else if constexpr (P < 2 * NPA + NPB * NJ) {
+        constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
+        if constexpr (r == 0) {
+          asm volatile("" : "+v"(rb[sl][j]));
+          valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+        } else if constexpr (r == 1) {
+          valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+        } else {
+          *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+        }
+      } else if constexpr (P < 2 * NPA + NPB * NJ + 2) {
+        // byte offsets advance by one tile per k-step (no advance past the split's last tile) and are clamped to the
+        // last token row: one add + one min per pointer instead of a 64-bit multiply-add chain per load
+        constexpr int i = P - 2 * NPA - NPB * NJ;
+        rok[sl][i] = a_ok && (a_k + 16 * i) < rows_left3 && live3;
+        offA[i] += advA;
+        ra[sl][i] = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(Ap) + min(offA[i], maxA));
+        rs[sl][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.s) + 4u * (unsigned)kmod[i]);
+        kmod[i] += QTN_BK;
+        kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;
+      } else {
+        constexpr int j = P - 2 * NPA - NPB * NJ - 2;
+        offB[j] += advB;
+        rb[sl][j] = *reinterpret_cast<const u32x2v*>(reinterpret_cast<const char*>(Bp[j]) + min(offB[j], maxB));
+      }
+    };
+    static_for<NM>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (ks == 0) {                        // second-step fragments into the registers that have just been used up
+        if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
+        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+      }
+      constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+  };
+#endif
 
   if (t_begin < t_end) {
     gload(t_begin, Slot0());
@@ -1161,6 +1308,16 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     lstore(smem, Slot0());
     gload(t_begin + 2, Slot0());
     lds_barrier();
+#ifndef TNW_SERIAL_STAGING
+    cs[0] = csacc.x; cs[1] = csacc.y; cs[2] = csacc.z; cs[3] = csacc.w;      // the k-loop continues the same running sums
+    {   // the prologue has loaded tiles t_begin .. t_begin+2 (clamped): the k-loop's first load is tile t_begin+3
+      const int tl = min(t_begin + 2, t_end - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) offA[i] = 4u * (unsigned)((tl * QTN_BK + a_k + 16 * i) * ldA);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) offB[j] = (unsigned)((tl * QTN_BK + b_row[j]) * ldB);
+    }
+#endif
     int kt = t_begin;
     for (; kt + 1 < t_end; kt += 2) {
       step(kt, smem, smem + STAGE, Slot1());                               // tile kt+1 lives in slot 1
@@ -1168,6 +1325,9 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     }
     if (kt < t_end) step(kt, smem, smem + STAGE, Slot1());
   }
+#ifndef TNW_SERIAL_STAGING
+  if (t_begin < t_end) csacc = make_float4(cs[0], cs[1], cs[2], cs[3]);
+#endif
 #ifdef TNW_TIMING
   if (blockIdx.x == 0 && lane == 0) {
     for (int q = 0; q < 6; ++q) g_tnw_dbg[wid][q] = tacc[q];
@@ -1811,14 +1971,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
           constexpr int pr = r / 7, rr = r % 7;
           if constexpr (rr < 6) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
-            if constexpr (st == 0) { x_ = valu_mul(ra[sl][i][e], ksv[e]); p0v[el] = valu_hi16(x_); }
-            if constexpr (st == 1) { r1_ = valu_sub(x_, p0v[el]); p1v[el] = valu_hi16(r1_); }
+            if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
+            if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
             if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
-            unsigned* dst = pr == 0 ? lo : hi;
-            dst[0] = valu_pack_hi16(p0v[0], p0v[1]);
-            dst[1] = valu_pack_hi16(p1v[0], p1v[1]);
-            dst[2] = valu_pack_hi16(r2v[0], r2v[1]);
+            valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
         } else {
           constexpr int q = r - 14;
