@@ -2448,6 +2448,206 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
   return 0;
 }
 // dxq[b,n,c] (+)= sum_h sum_m (dS[b,h,n,m]*aq[m,h]) * qq[b,m,h,c]
+// Wide dxq kernel (C % 384 == 0): 8 waves own a 128 x 384 tile of dx_hat[b], i.e. all channels of 128 tokens, so the
+// dS panel is split into its bf16 planes once instead of three times; the A side is the wide dX kernel's ([row][k]
+// planes, ds_read_b128 fragments), the B side the wide dW kernel's (int8 codes -> [k][c] bf16, transpose reads).  The
+// k index runs over (head, key token); double-buffered LDS, two register slots, staging interleaved into the MFMA
+// stream (see static_for).  k past the token count is zeroed through the per-k step (v_mul_legacy_f32: 0 * x = 0 even
+// for the uninitialised pad columns of dS) and through zero codes.
+__global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
+  constexpr int BM = 128, NJ = 3, BN = 128 * NJ, NS = 3;
+  constexpr int PLANE = BM * QBS_LD;                // [row][k] bf16, 80 B rows
+  constexpr int LDB = BN * 2 + 64;                  // [k][c] bf16
+  constexpr int STAGE = NS * PLANE + QBS_BK * LDB;
+  constexpr int CPR = BN / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  int tm, b0;
+  xcd_remap_grid(tm, b0);
+  const int m0 = tm * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* Ab = p.A + b0 * p.sA0;
+  const int8_t* Bb = p.B + b0 * p.sB0;
+  const int K = p.K;
+  const int nkt = (K + QBS_BK - 1) / QBS_BK;
+  const int T = nkt * p.nkb;
+
+  const int kqa = (tid & 7) * 4;
+  unsigned rowoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) rowoff[i] = (unsigned)(min(m0 + ((tid + 512 * i) >> 3), p.M - 1) * (int)p.lda);
+  int b_row[NJ], b_col[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = tid + 512 * j;
+    b_row[j] = f / CPR;
+    b_col[j] = (f % CPR) * 8;
+  }
+  f32x4v ra[2][2];
+  float rsv[2][4];
+  u32x2v rb[2][NJ];
+  int rkn[2];                                        // valid k of the slot's 4-chunk (0..4)
+  bool rbk[2][NJ];
+  // the load stream walks (head, k-tile) one tile per call; past the last tile it repeats it (never consumed)
+  int lkb = 0, lkt = 0, lt = 0;
+  auto gload = [&](auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const int k0 = lkt * QBS_BK;
+    const int nv = min(max(K - (k0 + kqa), 0), 4);
+    rkn[sl] = nv;
+    const int ka = nv > 0 ? k0 + kqa : 0;            // an all-out chunk reads the row start (valid memory), then is zeroed
+    const float* At = Ab + lkb * p.sAk + ka;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[sl][i] = *reinterpret_cast<const f32x4v*>(At + rowoff[i]);
+    const float* sp = p.s + lkb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rsv[sl][e] = sp[(int64_t)min(ka + e, K - 1) * p.ks_stride];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = k0 + b_row[j];
+      rbk[sl][j] = k < K;
+      rb[sl][j] = *reinterpret_cast<const u32x2v*>(Bb + lkb * p.sBk + (int64_t)min(k, K - 1) * p.ldb + b_col[j]);
+    }
+    const int adv = (lt + 1 < T) ? 1 : 0;             // scalar selects, no branch inside the MFMA stream
+    lt += adv;
+    lkt += adv;
+    const int wrap = (lkt == nkt) ? 1 : 0;
+    lkt = wrap ? 0 : lkt;
+    lkb += wrap;
+  };
+  // pieces of the staging of one slot (shared by the prologue, which runs them back to back, and the k-step)
+  float ksv[4], x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+  unsigned lo[NS], hi[NS], bw[4];
+  constexpr int NPA = 17, NPB = 3, NPS = 2 * NPA + NPB * NJ;      // staging pieces; the k-step appends one load piece
+  auto stage_piece = [&](unsigned char* nxt, auto SLOT, auto P_) {
+    constexpr int sl = decltype(SLOT)::value;
+    constexpr int P = decltype(P_)::value;
+    if constexpr (P < 2 * NPA) {
+      constexpr int i = P / NPA, r = P % NPA;
+      if constexpr (r == 0 && i == 0) {
+        asm volatile("" : "+v"(ra[sl][0]), "+v"(ra[sl][1]), "+v"(rsv[sl][0]), "+v"(rsv[sl][1]), "+v"(rsv[sl][2]), "+v"(rsv[sl][3]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = valu_eff_scale(rsv[sl][e], p.gscale);
+          ksv[e] = e < rkn[sl] ? t : 0.f;
+        }
+      }
+      if constexpr (r < 14) {
+        constexpr int pr = r / 7, rr = r % 7;
+        if constexpr (rr < 6) {
+          constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+          if constexpr (st == 0)
+            asm("v_mul_legacy_f32 %0, %2, %3\n\tv_and_b32 %1, 0xffff0000, %0" : "=&v"(x_), "=v"(p0v[el]) : "v"(ra[sl][i][e]), "v"(ksv[e]));
+          if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
+          if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+        } else {
+          valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
+        }
+      } else {
+        constexpr int q = r - 14;
+        const int row = (tid + 512 * i) >> 3;
+        uint2 w;
+        w.x = lo[q];
+        w.y = hi[q];
+        *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = w;
+      }
+    } else {
+      constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
+      if constexpr (r == 0) {
+        asm volatile("" : "+v"(rb[sl][j]));
+        valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][0] : 0u, bw[0], bw[1]);
+      } else if constexpr (r == 1) {
+        valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][1] : 0u, bw[2], bw[3]);
+      } else {
+        *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+      }
+    }
+  };
+
+  f32x16q acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int p16 = lane & 15;
+  const int fr_b = (8 * lh + (p16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  constexpr int NM = 12 * NJ, NP = NPS + 1;
+  auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
+    const unsigned char* sbb = &cur[NS * PLANE + fr_b + wn * 32 * NJ * 2];
+    bf16x8 av[NS][2], bv[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[0][j] = tr_frag_ld<LDB>(sbb + j * 64);
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NM>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (ks == 0) {
+        if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
+        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+      }
+      constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) {
+        constexpr int P = P0 + decltype(D_)::value;
+        if constexpr (P < NPS) stage_piece(nxt, SLOT, std::integral_constant<int, P>{});
+        else gload(SLOT);                            // the slot is free again: loads of the tile three steps ahead
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+  };
+  gload(Slot0());
+  gload(Slot1());
+  static_for<NPS>([&](auto P_) { stage_piece(smem, Slot0(), P_); });
+  gload(Slot0());
+  lds_barrier();
+  {
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      step(smem, smem + STAGE, Slot1());
+      step(smem + STAGE, smem, Slot0());
+    }
+    if (t < T) step(smem, smem + STAGE, Slot1());
+  }
+
+  float* Cb = p.C + b0 * p.sC0;
+  int ncol[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ncol[j] = wn * 32 * NJ + j * 32 + l31;          // N == 384: every column exists
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int eb = 0; eb < 4; ++eb) {
+      float old[4][NJ];
+      if (p.accumulate) {      // old values fetched unconditionally on clamped rows, a quad of rows at a time
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+          const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh, p.M - 1);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) old[ee][j] = Cb[(int64_t)mc * p.ldc + ncol[j]];
+        }
+      }
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (m < p.M) Cb[(int64_t)m * p.ldc + ncol[j]] = p.accumulate ? acc[i][j][eb * 4 + ee] + old[ee][j] : acc[i][j][eb * 4 + ee];
+      }
+    }
+}
+
 extern "C" int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float* dxq, const float* sq, float gscale_q,
                                    int accumulate, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
   if (!dS || !qcodes || !dxq || !sq || B <= 0 || H <= 0 || N <= 0 || (C & 15) || (ldS & 7) || ldS < N) return OFQ_EINVAL;
@@ -2456,8 +2656,12 @@ extern "C" int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float*
   a.sA0 = H * N * ldS; a.sB0 = N * H * C; a.sC0 = N * C; a.sAk = N * ldS; a.sBk = C;
   a.M = (int)N; a.N = (int)C; a.K = (int)N; a.nkb = (int)H; a.ks_stride = (int)H; a.accumulate = accumulate; a.gscale = gscale_q;
   a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(C, 128);
-  hipLaunchKernelGGL(qgemm_bf16s_nn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  static const bool nn_narrow = getenv("OFQ_NN_NARROW") != nullptr;           // A/B switch (tools/)
+  if (C == 384 && !nn_narrow && N * ldS < (1ll << 31))
+    hipLaunchKernelGGL(qgemm_bf16s_nn_wide_kernel, dim3((unsigned)a.tiles_m, (unsigned)B), dim3(512), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(qgemm_bf16s_nn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
