@@ -94,6 +94,88 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Epilogue of one interior 128x128 tile of the linear-layer GEMM: y = cs[n] * (a_eff[m] * I + r[n]) + bias[n] stored as
+// fp32, plus (optionally) the next quantiser's int8 levels into the LDS code tile.  Straight-line code specialised on the
+// by-product mode: no per-element bounds / mode branches, row pointers from scalar arithmetic (the lane adds one 32-bit
+// offset), LDS addresses as immediates, the level through ofq_lsq_level_rcp.  This epilogue is VALU-bound, so
+// instructions per element are what counts.  row_a: [3][128] floats in LDS (effective input step, the by-product's
+// per-row step and its reciprocal), ctile: [128][128] bytes in LDS.
+__device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const i32x16 (&acc)[2][2], float* Cb, const float* row_a,
+                                                      signed char* ctile, const float (&csn)[2], const float (&rn)[2],
+                                                      const float (&bz)[2], const float (&qb)[2], const float (&qsc)[2], int m0,
+                                                      int n0, int wm, int wn, int l31, int lh) {
+  constexpr int BM = 128, BN = 128;
+    const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+    const float* row_c = row_a + 2 * BM;
+    float qrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) qrc[j] = (p.qout && p.qcolmode) ? __fdiv_rn(1.f, qsc[j]) : 1.f;
+    const unsigned lane_off4 = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
+    float* Cb_t = Cb + (int64_t)(m0 + wm_s * 64) * p.ldc;
+    signed char* ct = ctile + (wm_s * 64 + 4 * lh) * BN + wn_s * 64 + l31;
+    const float* ra_t = row_a + wm_s * 64 + 4 * lh;
+    const float qlo = p.qlo, qhi = p.qhi;
+    const float half_m_tol = 0.5f - ofq_lsq_level_tol(qlo, qhi);
+    auto tile = [&](auto QMODE_, auto QGELU_) {
+      constexpr int QMODE = decltype(QMODE_)::value;          // 0 none, 1 per-row step, 2 per-column step
+      constexpr bool QGELU = decltype(QGELU_)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
+          float xq[4][2], qv[4][2], rbv[4];
+          bool risky = false;
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee) {
+            const int e = eg * 4 + ee;
+            const int r = i * 32 + ee + 8 * eg;
+            const float ae = ra_t[r];
+            rbv[ee] = QMODE == 1 ? ra_t[BM + r] : 1.f;
+            const float rrb = QMODE == 1 ? ra_t[2 * BM + r] : 1.f;
+            float* rowp = Cb_t + (int64_t)r * p.ldc;           // uniform: lives in an SGPR pair
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+              // scalar row base + 32-bit lane offset + immediate: no per-element address arithmetic on the VALU
+#ifndef I8X_NO_F32_STORE
+              if (j == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+              else asm volatile("global_store_dword %0, %1, %2 offset:128" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+#else
+              if (yv == 123.456f) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+#endif
+              if (QMODE != 0) {
+                xq[ee][j] = __fadd_rn(QGELU ? ofq_gelu(yv) : yv, qb[j]);
+                qv[ee][j] = ofq_lsq_level_rcp(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, half_m_tol, risky);
+              }
+            }
+          }
+          if (QMODE != 0) {
+            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+#pragma unroll
+              for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  qv[ee][j] = ofq_lsq_level_exact(xq[ee][j], QMODE == 2 ? qsc[j] : rbv[ee], qlo, qhi);
+            }
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+#ifndef I8X_NO_CODE_LDS
+              for (int j = 0; j < 2; ++j) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)(int)qv[ee][j];
+#else
+              for (int j = 0; j < 2; ++j) if (qv[ee][j] == 77.f) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)1;
+#endif
+          }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (!p.qout) tile(I0(), std::false_type());
+    else if (p.qcolmode) { if (p.qgelu) tile(I2(), std::true_type()); else tile(I2(), std::false_type()); }
+    else { if (p.qgelu) tile(I1(), std::true_type()); else tile(I1(), std::false_type()); }
+}
+
 #ifdef I8X_TIMING
 __device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one mid-grid workgroup (tools/probe/i8_probe.hip)
 #define I8_T(slot) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_i8_dbg[slot] = __builtin_readcyclecounter(); } while (0)
@@ -101,9 +183,12 @@ __device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one m
 #define I8_T(slot) do {} while (0)
 #endif
 
+#ifndef I8_WPE
+#define I8_WPE 3                   // waves per SIMD the int8 kernel is compiled for (tools/probe/i8_probe.hip overrides it)
+#endif
 // EPI 0: linear layer   1: QKR attention scores   2: P*V
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_i8_nt_kernel(QGemmArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
   I8_T(0);
@@ -166,6 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // around the loads make the compiler's wait-count pass wait for every outstanding load at each k-step.
   i32x4 ra[2][2], rb[2][2];
   const int klast = nkt - 1;
+  const bool nomask = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (K % QI8_BK) == 0;
   auto gload = [&](int kt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
     const int k0 = kt * QI8_BK;
@@ -181,14 +267,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rb[sl][i]));
     const int k0 = kt * QI8_BK;
+    if (nomask) {      // interior tile, no k tail (every tile of the DeiT-S shapes): 16 v_and + the mask selects per k-step gone
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f >> 2;
-      const bool kin = (k0 + kq[i]) < K;
-      const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
-      *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i] & ma;
-      *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i] & mb;
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid + 256 * i) >> 2;
+        *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i];
+        *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const int row = f >> 2;
+        const bool kin = (k0 + kq[i]) < K;
+        const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
+        *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i] & ma;
+        *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i] & mb;
+      }
     }
   };
 
@@ -281,75 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // GEMM spent ~70 of its 119 us in it), so instructions per element are what counts.
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && 4 * (4 * p.ldc + p.N) < (int64_t)0x7fffffff;
     if (interior) {
-      const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
-      const float* row_c = row_a + 2 * BM;
-      float qrc[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) qrc[j] = (p.qout && p.qcolmode) ? __fdiv_rn(1.f, qsc[j]) : 1.f;
-      const unsigned lane_off4 = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
-      float* Cb_t = Cb + (int64_t)(m0 + wm_s * 64) * p.ldc;
-      signed char* ct = ctile + (wm_s * 64 + 4 * lh) * BN + wn_s * 64 + l31;
-      const float* ra_t = row_a + wm_s * 64 + 4 * lh;
-      const float qlo = p.qlo, qhi = p.qhi;
-      const float half_m_tol = 0.5f - ofq_lsq_level_tol(qlo, qhi);
-      auto tile = [&](auto QMODE_, auto QGELU_) {
-        constexpr int QMODE = decltype(QMODE_)::value;          // 0 none, 1 per-row step, 2 per-column step
-        constexpr bool QGELU = decltype(QGELU_)::value;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
-            float xq[4][2], qv[4][2], rbv[4];
-            bool risky = false;
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) {
-              const int e = eg * 4 + ee;
-              const int r = i * 32 + ee + 8 * eg;
-              const float ae = ra_t[r];
-              rbv[ee] = QMODE == 1 ? ra_t[BM + r] : 1.f;
-              const float rrb = QMODE == 1 ? ra_t[2 * BM + r] : 1.f;
-              float* rowp = Cb_t + (int64_t)r * p.ldc;           // uniform: lives in an SGPR pair
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
-                // scalar row base + 32-bit lane offset + immediate: no per-element address arithmetic on the VALU
-#ifndef I8X_NO_F32_STORE
-                if (j == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
-                else asm volatile("global_store_dword %0, %1, %2 offset:128" ::"v"(lane_off4), "v"(yv), "s"(rowp));
-#else
-                if (yv == 123.456f) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
-#endif
-                if (QMODE != 0) {
-                  xq[ee][j] = __fadd_rn(QGELU ? ofq_gelu(yv) : yv, qb[j]);
-                  qv[ee][j] = ofq_lsq_level_rcp(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, half_m_tol, risky);
-                }
-              }
-            }
-            if (QMODE != 0) {
-              if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
-#pragma unroll
-                for (int ee = 0; ee < 4; ++ee)
-#pragma unroll
-                  for (int j = 0; j < 2; ++j)
-                    qv[ee][j] = ofq_lsq_level_exact(xq[ee][j], QMODE == 2 ? qsc[j] : rbv[ee], qlo, qhi);
-              }
-#pragma unroll
-              for (int ee = 0; ee < 4; ++ee)
-#pragma unroll
-#ifndef I8X_NO_CODE_LDS
-                for (int j = 0; j < 2; ++j) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)(int)qv[ee][j];
-#else
-                for (int j = 0; j < 2; ++j) if (qv[ee][j] == 77.f) ct[(i * 32 + ee + 8 * eg) * BN + j * 32] = (signed char)1;
-#endif
-            }
-          }
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>;
-      if (!p.qout) tile(I0(), std::false_type());
-      else if (p.qcolmode) { if (p.qgelu) tile(I2(), std::true_type()); else tile(I2(), std::false_type()); }
-      else { if (p.qgelu) tile(I1(), std::true_type()); else tile(I1(), std::false_type()); }
+      i8_epi0_interior_tile(p, acc, Cb, row_a, ctile, csn, rn, bz, qb, qsc, m0, n0, wm, wn, l31, lh);
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
