@@ -1420,6 +1420,73 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   }
 }
 
+// Split-K reduce, latency-parallel version (N % 4 == 0, N >= 256): the row-per-block kernel below walks the `split`
+// partials of an element four at a time, i.e. split/4 dependent memory round trips in a launch of only M blocks (384 rows =
+// 1.5 blocks per CU) -- 86 % of its wave time is parked.  Here a block owns 64 float4 chunks of the output and its four
+// waves each sum every fourth partial, four loads in flight (split/16 round trips), combined through LDS in a fixed order
+// (deterministic).  db[o] = sum_s csum[s][o] is computed by the block(s) touching row o (written by the one holding
+// the row's first chunk); dW[o][c] += db[o] * baft[c] as before.
+__global__ __launch_bounds__(256) void qgemm_tn_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                               const float* __restrict__ csum, float* __restrict__ db,
+                                                               const float* __restrict__ baft, int M, int N, int split) {
+  __shared__ float4 red[3][64];
+  __shared__ float dbs[2];
+  const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int N4 = N >> 2;
+  const int64_t MN = (int64_t)M * N;
+  const int g0 = blockIdx.x * 64;
+  const int total = M * N4;
+  const int o_first = g0 / N4, o_last = min(g0 + 63, total - 1) / N4;      // N4 >= 64: at most two rows per block
+  if (part < 2) {
+    const int o = part == 0 ? o_first : o_last;
+    float v = 0.f;
+    if (csum) {
+      for (int s = tx; s < split; s += 64) v += csum[(int64_t)s * M + o];
+      v = ofq_wave_sum(v);
+      const int gfirst = o * N4;                                             // the block holding chunk (o, 0) publishes db[o]
+      if (tx == 0 && gfirst >= g0 && gfirst < g0 + 64 && (part == 0 || o_last != o_first)) db[o] = v;
+    } else if (db) {
+      v = db[o];
+    }
+    if (tx == 0) dbs[part] = v;
+  }
+  const int g = min(g0 + tx, total - 1);
+  const int o = g / N4, c4 = g - o * N4;
+  const float* p = ws + (int64_t)o * N + 4 * c4;
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = part; s < split; s += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int su = s + 4 * u;
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)min(su, split - 1) * MN);     // unconditional load
+      const float m = su < split ? 1.f : 0.f;
+      a[u].x += v.x * m; a[u].y += v.y * m; a[u].z += v.z * m; a[u].w += v.w * m;
+    }
+  }
+  float4 t;
+  t.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+  t.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+  t.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+  t.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+  if (part > 0) red[part - 1][tx] = t;
+  __syncthreads();
+  if (part == 0 && g0 + tx < total) {
+    const float4 r1 = red[0][tx], r2 = red[1][tx], r3 = red[2][tx];
+    t.x = (t.x + r1.x) + (r2.x + r3.x);
+    t.y = (t.y + r1.y) + (r2.y + r3.y);
+    t.z = (t.z + r1.z) + (r2.z + r3.z);
+    t.w = (t.w + r1.w) + (r2.w + r3.w);
+    if (baft && (db || csum)) {
+      const float dbo = dbs[o == o_first ? 0 : 1];
+      const float4 bf = *reinterpret_cast<const float4*>(baft + 4 * c4);
+      t.x += dbo * bf.x; t.y += dbo * bf.y; t.z += dbo * bf.z; t.w += dbo * bf.w;
+    }
+    *reinterpret_cast<float4*>(C + (int64_t)o * N + 4 * c4) = t;
+  }
+}
+
 // one block per output row o:  db[o] = sum_s csum[s][o] (when the GEMM produced column sums), then
 // dW[o][c] = sum_s ws[s][o][c] + db[o] * baft[c]  -- fixed order, four partial sums in flight per thread
 __global__ __launch_bounds__(256) void qgemm_tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C,
@@ -1490,8 +1557,13 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
     hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   }
   OFQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, (const float*)ws, dW,
-                     compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
+  static const bool red_rows = getenv("OFQ_TN_REDUCE_ROWS") != nullptr;      // A/B switch (tools/)
+  if ((N & 3) == 0 && N >= 256 && !red_rows)
+    hipLaunchKernelGGL(qgemm_tn_reduce4_kernel, dim3((unsigned)ceil_div(M * (N / 4), 64)), dim3(256), 0, st, (const float*)ws, dW,
+                       compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
+  else
+    hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, (const float*)ws, dW,
+                       compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
