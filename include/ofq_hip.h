@@ -43,6 +43,13 @@ int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* 
  *  rout[row] = sum_k rvec[k] * code[row][k] (the offset term of ofq_qgemm_i8_nt: rvec = the layer's move_aft). */
 int ofq_statsq_codes_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* codes,
                          void* codesT_bf16, const float* rvec, float* rout, ofq_stream_t stream);
+/*  The same code path for MANY weight tensors in one or two launches (weights only change at the optimizer step, so a
+ *  training step can refresh every layer's operands up front instead of one small launch inside each forward):
+ *  host_entries = n records of ofq_statsq_tensor_entry_bytes() bytes, each { const float* W; float* scale; int8_t* codes;
+ *  uint16_t* codesT_bf16 ( may be NULL ); const float* rvec ( may be NULL ); float* rout; int64 rows, cols, bits; }.
+ *  Row for row identical to ofq_statsq_codes_fwd (no fake-quant values are written). */
+int64_t ofq_statsq_tensor_entry_bytes(void);
+int ofq_statsq_codes_multi(const void* host_entries, int64_t n, ofq_stream_t stream);
 
 /* ---- K3/K5  LSQ activation quantiser with its LearnableBias sandwich:
  *  LsqQuantizer.forward lsq.py:571-602 (+ :72-101, :336-373, :419-437, :489-505), LsqQuantizer4v.forward

@@ -28,6 +28,8 @@ SIGNATURES = {
     "ofq_abi_version": (i32, []),
     "ofq_statsq_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, i32, i32, vp]),
     "ofq_statsq_codes_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "ofq_statsq_tensor_entry_bytes": (i64, []),
+    "ofq_statsq_codes_multi": (i32, [vp, i64, vp]),
     "ofq_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,

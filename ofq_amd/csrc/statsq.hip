@@ -5,14 +5,10 @@
 // HBM-bound: 4 B read + 4 B written per weight (+1 B for the optional level).
 #include "common.h"
 
-__global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict__ W, int64_t rows, int64_t cols,
-                                                         float n, float* __restrict__ out,
-                                                         float* __restrict__ scale, int8_t* __restrict__ levels,
-                                                         int scale_given, int odd_codes,
-                                                         unsigned short* __restrict__ codesT, const float* __restrict__ rvec,
-                                                         float* __restrict__ rout) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void statsq_row(const float* __restrict__ W, int64_t rows, int64_t cols, float n,
+                                           float* __restrict__ out, float* __restrict__ scale, int8_t* __restrict__ levels,
+                                           int scale_given, int odd_codes, unsigned short* __restrict__ codesT,
+                                           const float* __restrict__ rvec, float* __restrict__ rout, int64_t row, int lane) {
   if (row >= rows) return;
   const float* w = W + row * cols;
   const bool vec = ((cols & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
@@ -82,6 +78,62 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
     racc = ofq_wave_sum(racc);
     if (lane == 0) rout[row] = racc;
   }
+}
+
+__global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict__ W, int64_t rows, int64_t cols,
+                                                         float n, float* __restrict__ out,
+                                                         float* __restrict__ scale, int8_t* __restrict__ levels,
+                                                         int scale_given, int odd_codes,
+                                                         unsigned short* __restrict__ codesT, const float* __restrict__ rvec,
+                                                         float* __restrict__ rout) {
+  statsq_row(W, rows, cols, n, out, scale, levels, scale_given, odd_codes, codesT, rvec, rout,
+             (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// Multi-tensor code path: the weights of a model only change at the optimizer step, so the scale / int8 codes / transposed
+// bf16 codes / offset row-dots of ALL quantised linear layers are produced by one or two launches at the start of a
+// training step (descriptors in the kernel arguments, like ofq_adamw_multi) instead of one 10-us, mostly latency-bound
+// launch per layer inside its forward.  Row for row the arithmetic is statsq_row's.
+#define STATSQ_MAX_TENSORS 40
+struct StatsqEntry {          // host layout of ofq_statsq_codes_multi's table (ofq_statsq_tensor_entry_bytes() bytes each)
+  const float* W; float* scale; int8_t* codes; unsigned short* codesT; const float* rvec; float* rout;
+  int64_t rows, cols, bits;
+};
+struct StatsqPack {
+  StatsqEntry e[STATSQ_MAX_TENSORS];
+  int first_block[STATSQ_MAX_TENSORS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void statsq_multi_kernel(StatsqPack pk) {
+  int t = 0;
+  while (t + 1 < pk.n && (int)blockIdx.x >= pk.first_block[t + 1]) ++t;          // uniform scan over <= 40 entries
+  const StatsqEntry& e = pk.e[t];
+  statsq_row(e.W, e.rows, e.cols, (float)(1 << (e.bits - 1)), nullptr, e.scale, e.codes, 0, 1, e.codesT, e.rvec, e.rout,
+             (int64_t)((int)blockIdx.x - pk.first_block[t]) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+extern "C" int64_t ofq_statsq_tensor_entry_bytes(void) { return (int64_t)sizeof(StatsqEntry); }
+
+extern "C" int ofq_statsq_codes_multi(const void* host_entries, int64_t n, ofq_stream_t stream) {
+  if (!host_entries || n <= 0) return OFQ_EINVAL;
+  const StatsqEntry* he = (const StatsqEntry*)host_entries;
+  for (int64_t base = 0; base < n; base += STATSQ_MAX_TENSORS) {
+    StatsqPack pk;
+    pk.n = (int)((n - base) < STATSQ_MAX_TENSORS ? (n - base) : STATSQ_MAX_TENSORS);
+    int blocks = 0;
+    for (int i = 0; i < pk.n; ++i) {
+      const StatsqEntry& e = he[base + i];
+      if (!e.W || !e.scale || !e.codes || e.rows <= 0 || e.cols <= 0 || e.bits < 1 || e.bits > 7 || (e.rvec && !e.rout))
+        return OFQ_EINVAL;
+      pk.e[i] = e;
+      pk.first_block[i] = blocks;
+      blocks += (int)((e.rows + 3) / 4);
+    }
+    pk.first_block[pk.n] = blocks;
+    hipLaunchKernelGGL(statsq_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 static int statsq_launch(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* levels,

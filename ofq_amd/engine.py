@@ -175,6 +175,42 @@ class CGAHooks:
         self.state.clear()
 
 
+WEIGHT_CODE_CACHE = os.environ.get("OFQ_NO_WEIGHT_CODE_CACHE", "0") != "1"
+
+
+def _statsq_modules(model):
+    lst = getattr(model, "_ofq_statsq_list", None)
+    if lst is None:
+        from .quantization.quantizer.statsq import StatsQuantizer
+        lst = [m for m in model.modules() if isinstance(m, StatsQuantizer)]
+        model._ofq_statsq_list = lst
+    return lst
+
+
+def refresh_weight_codes(model):
+    """StatsQ operands (scale, int8 codes, transposed bf16 codes, offset row-dots) of every quantised linear layer whose
+    weight is a leaf Parameter, in one or two launches (ofq_statsq_codes_multi) instead of one launch inside each forward.
+    Valid until invalidate_weight_codes(): train_step() brackets exactly the forward/backward of one step with the two,
+    so nothing can observe operands of stale weights (the optimizer, CGA restore and checkpoint loads all run outside)."""
+    from . import ops
+    todo = []
+    for q in _statsq_modules(model):
+        la = q._last_args
+        if la is not None and la[0].is_leaf and la[0].is_cuda and la[0].dim() == 2 and la[0].is_contiguous():
+            todo.append((q, la))
+    if not todo:
+        return 0
+    res = ops.statsq_codes_multi([(la[0].detach(), la[1], None if la[2] is None else la[2].detach(), la[3]) for _, la in todo])
+    for (q, la), r in zip(todo, res):
+        q._pre = (la[0], la[2], la[3], r)
+    return len(todo)
+
+
+def invalidate_weight_codes(model):
+    for q in _statsq_modules(model):
+        q._pre = None
+
+
 def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
     """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
     loss_fn = loss_fn or KDLossSoftandHard()
@@ -182,7 +218,13 @@ def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=N
         dp.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=True)
-    out, _ = (dp or model)(images)
+    if WEIGHT_CODE_CACHE:
+        refresh_weight_codes(model)
+    try:
+        out, _ = (dp or model)(images)
+    finally:
+        if WEIGHT_CODE_CACHE:
+            invalidate_weight_codes(model)      # the operands are captured by the autograd graph; the cache itself ends here
     loss = loss_fn(out, target, soft_target)
     loss.backward()
     if dp is not None:

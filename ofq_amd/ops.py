@@ -143,6 +143,32 @@ def statsq_codes_fwd(W, bits, rvec=None, need_values=True, want_T=True):
     return out, s, codes, codesT, r
 
 
+def statsq_codes_multi(items):
+    """items: list of (W, bits, rvec or None, want_T).  One or two launches for all of them; returns a list of
+    (scale, codes int8 [out][in], codesT bf16 [in][out] or None, r or None), values identical to statsq_codes_fwd."""
+    import ctypes as C
+    import struct
+    esz = int(lib().ofq_statsq_tensor_entry_bytes())
+    assert esz == 72
+    outs, blob, keep = [], bytearray(), []
+    for (W, bits, rvec, want_T) in items:
+        _dev(W, "weight")
+        Wc = W.contiguous()
+        rows, cols = Wc.shape
+        dev = Wc.device
+        s = torch.empty(rows, dtype=torch.float32, device=dev)
+        codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+        codesT = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev) if want_T else None
+        r = torch.empty(rows, dtype=torch.float32, device=dev) if rvec is not None else None
+        blob += struct.pack("<6Q3q", Wc.data_ptr(), s.data_ptr(), codes.data_ptr(), _p(codesT) or 0, _p(rvec) or 0, _p(r) or 0,
+                            rows, cols, int(bits))
+        keep.append(Wc)
+        outs.append((s, codes, codesT, r))
+    buf = (C.c_char * len(blob)).from_buffer(blob)
+    _chk(lib().ofq_statsq_codes_multi(C.addressof(buf), len(items), _stream()), "ofq_statsq_codes_multi")
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------ LSQ
 class LsqGeom:
     """How a tensor maps onto the kernel's [outer][S][inner] view (include/ofq_hip.h, ofq_lsq_fwd)."""

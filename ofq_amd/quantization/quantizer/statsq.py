@@ -14,6 +14,14 @@ class _StatsQFn(torch.autograd.Function):
         if want_codes and (rvec is not None or not need_values):
             # code path of a linear layer: scale, codes, transposed bf16 codes and the offset row-dot in ONE launch;
             # the fp32 fake-quant values are not written (nothing reads them), a zero-stride tensor carries the edge
+            if not need_values:
+                holder._last_args = (weight, bits, rvec, want_T)        # what refresh_weight_codes() recomputes in bulk
+                pre = holder._pre
+                if (pre is not None and pre[0].data_ptr() == weight.data_ptr() and pre[0].shape == weight.shape
+                        and (pre[1] is None) == (rvec is None) and (rvec is None or pre[1].data_ptr() == rvec.data_ptr())
+                        and (pre[2] or not want_T)):
+                    holder._s_dev, holder._codes, holder._codesT, holder._r = pre[3]
+                    return ops.placeholder(tuple(weight.shape), weight.device)
             out, s, codes, codesT, r = ops.statsq_codes_fwd(weight, bits, rvec=rvec, need_values=need_values,
                                                             want_T=want_T)
             holder._s_dev, holder._codes, holder._codesT, holder._r = s, codes, codesT, r
@@ -38,6 +46,8 @@ class StatsQuantizer(nn.Module):
         self._codes = None
         self._codesT = None
         self._r = None
+        self._last_args = None      # (weight, bits, rvec, want_T) of the last code-path forward
+        self._pre = None            # (weight, rvec, has_T, (s, codes, codesT, r)) filled by engine.refresh_weight_codes()
 
     def codes_T(self):
         """Weight codes transposed to [in][out] as bf16 (exact small integers) for dX = dY @ W_hat."""

@@ -678,3 +678,25 @@ def test_i8_epilogue_levels_on_rounding_boundaries(ops, bits, signed, colmode):
     if not signed and bits == 8:
         got = np.where(got < 0, got + 256, got)                       # uint8 levels travel in an int8 tensor
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_statsq_multi_tensor_equals_the_per_tensor_launch(ops):
+    """ofq_statsq_codes_multi (all layers' weight operands in one or two launches) against ofq_statsq_codes_fwd, bit for
+    bit: scale, odd int8 codes, transposed bf16 codes, offset row-dots; 45 tensors so that the table is split over two
+    launches; shapes of the DeiT-S / DeiT-T layers plus ragged ones, 2-4 bits, with and without rvec / transposed codes."""
+    rng = np.random.RandomState(5)
+    shapes = [(384, 384), (1536, 384), (384, 1536), (192, 192), (576, 192), (10, 20), (7, 33), (130, 64), (96, 288)]
+    items = []
+    for i in range(45):
+        r, c = shapes[i % len(shapes)]
+        W = T(rng.randn(r, c).astype(np.float32) * 0.05).cuda()
+        bits = 2 + i % 3
+        rvec = T(rng.randn(c).astype(np.float32) * 0.1).cuda() if i % 4 else None
+        items.append((W, bits, rvec, bool(i % 5)))
+    got = ops.statsq_codes_multi(items)
+    for (W, bits, rvec, want_T), (s, codes, codesT, r) in zip(items, got):
+        _, s1, c1, t1, r1 = ops.statsq_codes_fwd(W, bits, rvec=rvec, need_values=False, want_T=want_T)
+        assert torch.equal(s, s1) and torch.equal(codes, c1)
+        assert (codesT is None) == (t1 is None) and (codesT is None or torch.equal(codesT, t1))
+        assert (r is None) == (r1 is None) and (r is None or torch.equal(r, r1))

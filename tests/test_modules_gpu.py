@@ -459,3 +459,32 @@ def test_block_norm_quant_fusion_matches_separate_kernels(env):
     assert torch.equal(fused["c"], plain["c"]) and torch.equal(fused["d"], plain["d"])
     bad = {k: rel_err(fused[k], plain[k]) for k in fused if rel_err(fused[k], plain[k]) > 1e-5 and "move_" not in k}
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_train_step_with_bulk_weight_codes_equals_per_layer_statsq():
+    """engine.train_step refreshes every layer's StatsQ operands with one multi-tensor launch at the start of the step;
+    three steps must produce the same losses and parameters, bit for bit, as the per-layer launches inside the forwards."""
+    import copy
+    from ofq_amd import engine
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    torch.manual_seed(0)
+    base = engine.build_student("deit_tiny_distilled_patch16_224", 3, 3, qk_reparam=True).cuda()
+    imgs = torch.randn(4, 3, 224, 224, device="cuda")
+    tgt = torch.randint(0, 1000, (4,), device="cuda")
+    soft = torch.randn(4, 1000, device="cuda")
+    engine.setup_alpha(base, imgs)
+    results = []
+    for cache in (False, True):
+        model = copy.deepcopy(base).train()
+        opt = engine.make_optimizer(model)
+        engine.WEIGHT_CODE_CACHE = cache
+        losses = [float(engine.train_step(model, opt, imgs, tgt, soft, KDLossSoftandHard())) for _ in range(3)]
+        if cache:
+            assert any(q._last_args is not None for q in engine._statsq_modules(model))
+            assert all(q._pre is None for q in engine._statsq_modules(model))          # nothing outlives the step
+        results.append((losses, [p.detach().clone() for p in model.parameters()]))
+    engine.WEIGHT_CODE_CACHE = True
+    assert results[0][0] == results[1][0]
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
