@@ -197,11 +197,16 @@ class VisionTransformer(nn.Module):
         x = self._tokens(x)
         attn_matrixs, feats = [], []
         pending = None
-        for i, blk in enumerate(self.blocks):
-            x, a, pending, xin = blk.forward_fused(x, pending)      # same values as x, a = blk(x), adds fused into norms
-            attn_matrixs.append(a)
-            if i > 0:
-                feats.append(xin)
+        served = F_ofq.all_wqk([blk.attn for blk in self.blocks])
+        try:
+            for i, blk in enumerate(self.blocks):
+                x, a, pending, xin = blk.forward_fused(x, pending)  # same values as x, a = blk(x), adds fused into norms
+                attn_matrixs.append(a)
+                if i > 0:
+                    feats.append(xin)
+        finally:
+            for a_ in served:
+                a_._wqk_pre = None
         x = x + pending
         feats.append(x)
         # LayerNorm is per token and only the class / distillation tokens are read: norm those rows only

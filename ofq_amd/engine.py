@@ -12,6 +12,7 @@ from .deit import create_model
 from .quantization.modules.utils import replace_module_by_qmodule_deit, replace_module_by_qmodule_swin
 from .quantization.utils import KDLossSoftandHard
 from . import ops
+from . import functional as F_ofq
 
 ACT_LAYER_MAPPINGS = {'relu': nn.ReLU, 'gelu': nn.GELU, 'prelu': nn.PReLU, 'rprelu': 'rprelu', 'None': 'None'}
 
@@ -220,10 +221,12 @@ def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=N
         optimizer.zero_grad(set_to_none=True)
     if WEIGHT_CODE_CACHE:
         refresh_weight_codes(model)
+        F_ofq.STEP_CACHE_ACTIVE = True
     try:
         out, _ = (dp or model)(images)
     finally:
         if WEIGHT_CODE_CACHE:
+            F_ofq.STEP_CACHE_ACTIVE = False
             invalidate_weight_codes(model)      # the operands are captured by the autograd graph; the cache itself ends here
     loss = loss_fn(out, target, soft_target)
     loss.backward()

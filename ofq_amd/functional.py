@@ -176,6 +176,76 @@ class WqkFn(torch.autograd.Function):
         return dWq, dWk, None
 
 
+class AllWqkFn(torch.autograd.Function):
+    """WqkFn for all blocks of a model in one batched GEMM each way (batch = blocks x heads): W_qk only depends on
+    parameters, and the per-block products are tiny (0.11 GFLOP, ~25-33 us each, latency-bound: three launches per block).
+    Inputs: H, then q.weight, k.weight of every block; outputs: one (H*C, C) tensor per block (views of one buffer).
+    The backward runs once, when the last block's gradient has arrived, i.e. at the end of the model's backward."""
+
+    @staticmethod
+    def forward(ctx, H, *ws):
+        L = len(ws) // 2
+        Wq = torch.stack(ws[0::2])                                    # (L, H*d, C)
+        Wk = torch.stack(ws[1::2])
+        C = Wq.shape[2]
+        d = Wq.shape[1] // H
+        out = torch.empty((L, H * C, C), dtype=torch.float32, device=Wq.device)
+        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=L * H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0))
+        ctx.save_for_backward(Wq, Wk)
+        ctx.H = H
+        ctx.set_materialize_grads(False)
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        Wq, Wk = ctx.saved_tensors
+        H = ctx.H
+        L, _, C = Wq.shape
+        d = Wq.shape[1] // H
+        g = torch.stack([gi if gi is not None else torch.zeros((H * C, C), dtype=Wq.dtype, device=Wq.device) for gi in gs])
+        dWq = torch.empty_like(Wq)
+        dWk = torch.empty_like(Wk)
+        ops.gemm(Wk, g, dWq, d, C, C, C, C, C, transB=True, nb0=L * H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
+        ops.gemm(Wq, g, dWk, d, C, C, C, C, C, nb0=L * H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
+        grads = [None]
+        for l in range(L):
+            grads += [dWq[l], dWk[l]]
+        return tuple(grads)
+
+
+BULK_WQK = os.environ.get("OFQ_NO_BULK_WQK", "0") != "1"
+STEP_CACHE_ACTIVE = False          # set by engine.train_step around the forward (see engine.refresh_weight_codes)
+
+
+def all_wqk(attns):
+    """Pre-compute W_qk (and, inside a training step, its StatsQ operands) for every QKR attention module of `attns` that
+    shares one shape; each module picks its tensor up from `_wqk_pre` in its forward.  Returns the modules served."""
+    if not BULK_WQK or len(attns) < 2:
+        return []
+    a0 = attns[0]
+    ok = all(hasattr(a, "q") and hasattr(a, "k") and hasattr(a, "qk_quant") and a.q.weight.shape == a0.q.weight.shape
+             and a.num_heads == a0.num_heads and a.q.weight.is_cuda for a in attns)
+    if not ok:
+        return []
+    ws = []
+    for a in attns:
+        ws += [a.q.weight, a.k.weight]
+    outs = AllWqkFn.apply(a0.num_heads, *ws)
+    for a, w in zip(attns, outs):
+        a._wqk_pre = w
+    if STEP_CACHE_ACTIVE:
+        # the StatsQ operands of the 12 W_qk in one launch (their per-block launches are as latency-bound as the GEMMs)
+        todo = [(a, a.qk_quant._last_args) for a in attns if a.qk_quant._last_args is not None]
+        if len(todo) == len(attns):
+            res = ops.statsq_codes_multi([(a._wqk_pre.detach(), la[1], None if la[2] is None else la[2].detach(), la[3])
+                                          for a, la in todo])
+            for (a, la), r in zip(todo, res):
+                a.qk_quant._pre = (a._wqk_pre, la[2], la[3], r)
+    return attns
+
+
 class QKRScoresFn(torch.autograd.Function):
     """S[b,h,n,m] = sum_c xq[b,n,c] * qkx[b,m,h,c]   (attention.py:207-210), S stored (B,H,N,Np)."""
 

@@ -214,7 +214,9 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
         else:
             v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
-        Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
+        Wqk_fp = getattr(self, "_wqk_pre", None)          # all blocks' W_qk in one batched GEMM (functional.all_wqk)
+        if Wqk_fp is None:
+            Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
         if use_codes:
             qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None,
                                fuse=qspec, xgrad_acc=xacc)

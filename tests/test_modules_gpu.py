@@ -488,3 +488,28 @@ def test_train_step_with_bulk_weight_codes_equals_per_layer_statsq():
     assert results[0][0] == results[1][0]
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_bulk_wqk_equals_per_block_wqk():
+    """functional.all_wqk (W_qk of all blocks in one batched GEMM each way, backward once at the end) against the per-block
+    WqkFn: same logits and the same q / k weight gradients, bit for bit (same kernel, same per-head products)."""
+    import copy
+    from ofq_amd import engine, functional as F_ofq
+    torch.manual_seed(1)
+    base = engine.build_student("deit_tiny_distilled_patch16_224", 3, 3, qk_reparam=True).cuda().train()
+    imgs = torch.randn(2, 3, 224, 224, device="cuda")
+    engine.setup_alpha(base, imgs)
+    res = []
+    for bulk in (False, True):
+        model = copy.deepcopy(base)
+        F_ofq.BULK_WQK = bulk
+        (cls, dist), _ = model(imgs)
+        (cls.square().mean() + dist.square().mean()).backward()
+        res.append((cls.detach().clone(), [blk.attn.q.weight.grad.clone() for blk in model.blocks] +
+                    [blk.attn.k.weight.grad.clone() for blk in model.blocks]))
+        assert all(getattr(blk.attn, "_wqk_pre", None) is None for blk in model.blocks)       # nothing left behind
+    F_ofq.BULK_WQK = True
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
