@@ -479,7 +479,7 @@ def test_train_step_with_bulk_weight_codes_equals_per_layer_statsq():
         model = copy.deepcopy(base).train()
         opt = engine.make_optimizer(model)
         engine.WEIGHT_CODE_CACHE = cache
-        losses = [float(engine.train_step(model, opt, imgs, tgt, soft, KDLossSoftandHard())) for _ in range(3)]
+        losses = [float(engine.train_step(model, opt, imgs, tgt, soft, KDLossSoftandHard()).detach()) for _ in range(3)]
         if cache:
             assert any(q._last_args is not None for q in engine._statsq_modules(model))
             assert all(q._pre is None for q in engine._statsq_modules(model))          # nothing outlives the step
