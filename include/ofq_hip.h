@@ -220,7 +220,7 @@ int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
  *  b4[c]; step lsq_s[r % S], range [lo, hi]) -- the same codes ofq_lsq_fwd produces from the LayerNorm output, which
  *  is only written when y != NULL.  The backward takes the gradient of the quantised tensor, recomputes the
  *  LayerNorm output from (x, mean, rstd), applies ofq_lsq_bwd's arithmetic and the LayerNorm backward in one pass:
- *  dx [+ dres], dgamma, dbeta (= the gradient of b4 as well), ds[S], dbaft[cols]. */
+ *  dx [+ dres], dgamma, dbeta, db4 (optional: the same column sums as dbeta, for move_b4), ds[S], dbaft[cols]. */
 int ofq_layernorm_lsq_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xsum,
                           float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S, float gscale,
                           const float* b4, int lo, int hi, int64_t rows, int64_t cols, int64_t ldx, float eps,
@@ -228,8 +228,8 @@ int ofq_layernorm_lsq_fwd(const float* x, const float* res, const float* gamma, 
 size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t rows, int64_t cols);
 int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale, const float* b4,
-                          int lo, int hi, float* dx, float* dgamma, float* dbeta, float* ds, float* dbaft, int64_t rows,
-                          int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                          int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds, float* dbaft,
+                          int64_t rows, int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, ofq_stream_t stream);
 
 /* ---- AdamW over many tensors in one launch (train.py:662, :933: timm create_optimizer_v2 -> torch.optim.AdamW), with
  *  the CGA freeze folded in (cga.py:962-964, :994-997): where frozen[i] != 0 the gradient is masked before the moment

@@ -66,8 +66,8 @@ SIGNATURES = {
     "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp]),
     "ofq_layernorm_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, i64, i64, i64, f32, vp]),
     "ofq_layernorm_lsq_bwd_ws_bytes": (sz, [i64, i64]),
-    "ofq_layernorm_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, vp, i64, i64, i64,
-                                    i64, vp, sz, vp]),
+    "ofq_layernorm_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64,
+                                    i64, i64, vp, sz, vp]),
     "ofq_adamw_tensor_entry_bytes": (i64, []),
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),

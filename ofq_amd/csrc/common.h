@@ -89,7 +89,7 @@ __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { retur
 // Up to three independent jobs (ds, db4, dbaft) in one launch: blockIdx.y selects the job.
 // source offset of column c: (c / col_div) * col_mul + (c % col_div) * cnt   (col_div = 0: plain c * cnt)
 struct SumJob { const float* src; float* dst; int64_t ncols, nrows, row_stride; int cnt; float scale; int64_t col_div, col_mul; };
-struct SumJobs { SumJob j[3]; };
+struct SumJobs { SumJob j[5]; };
 
 // 1024 threads = CPB columns x (1024 / CPB) row lanes, four independent accumulators per lane: the partials are a few
 // hundred rows deep, so the kernel is a chain of dependent L2 round trips unless many loads are in flight.  CPB = 64

@@ -338,7 +338,7 @@ extern "C" size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t R, int64_t C) {
 
 extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
-                                     const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* ds,
+                                     const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds,
                                      float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
                                      ofq_stream_t stream) {
   if (!gq || !x || !mean || !rstd || !dx || !ws || !lsq_s || S <= 0 || R % S) return OFQ_EINVAL;
@@ -355,18 +355,18 @@ extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const floa
   hipStream_t st = (hipStream_t)stream;
   rc = ln_launch<true, true>(g, a, st);
   if (rc) return rc;
+  // every second-stage sum of this call in ONE launch (they are a few microseconds each and latency-bound): the column
+  // sums, the step gradient, and db4 -- the same column sum as dbeta, written a second time so that the two parameters
+  // get separate gradient tensors without a copy kernel
   SumJobs jobs = {};
-  if (dgamma) jobs.j[0] = {a.colpart, dgamma, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
-  if (dbeta) jobs.j[1] = {a.colpart + C, dbeta, C, g.gx, 3 * C, 1, 1.0f, 0, 0};           // = d move_b4 as well
-  if (dbaft) jobs.j[2] = {a.colpart + 2 * C, dbaft, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
-  if (dgamma || dbeta || dbaft) {
-    strided_sum_launch(jobs, C, 3, st);
-    OFQ_LAUNCH_CHECK();
-  }
-  if (ds) {
-    SumJobs j2 = {};
-    j2.j[0] = {a.rowpart, ds, S, R / S, S, 1, gscale, 0, 0};
-    strided_sum_launch(j2, S, 1, st);
+  int nj = 0;
+  if (dgamma) jobs.j[nj++] = {a.colpart, dgamma, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (dbeta) jobs.j[nj++] = {a.colpart + C, dbeta, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (db4) jobs.j[nj++] = {a.colpart + C, db4, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (dbaft) jobs.j[nj++] = {a.colpart + 2 * C, dbaft, C, g.gx, 3 * C, 1, 1.0f, 0, 0};
+  if (ds) jobs.j[nj++] = {a.rowpart, ds, S, R / S, S, 1, gscale, 0, 0};
+  if (nj) {
+    strided_sum_launch(jobs, C > S ? C : S, nj, st);
     OFQ_LAUNCH_CHECK();
   }
   return 0;

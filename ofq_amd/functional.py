@@ -612,10 +612,9 @@ class NormQuantFn(torch.autograd.Function):
             return dxs, dxs, None, None, None, None, None, None, None
         gq = dxq.reshape(-1, C).contiguous()
         dres = None if dxs is None else dxs.reshape(-1, C).contiguous()
-        dx, dg, db, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
+        dx, dg, db, db4, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
         dx = dx.view(shp)
-        return (dx, dx if ctx.has_res else None, dg, (db if bias is not None else None), None, ds,
-                (db.clone() if b4 is not None else None), dba, None)
+        return (dx, dx if ctx.has_res else None, dg, (db if bias is not None else None), None, ds, db4, dba, None)
 
 
 def norm_quant(norm, spec, x, res=None):

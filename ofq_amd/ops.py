@@ -545,20 +545,21 @@ def layernorm_lsq_fwd(x2d, gamma, beta, eps, s, b4, g, res2d=None):
 
 
 def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None):
-    """returns (dx [+ dres], dgamma, dbeta (= db4), ds, dbaft)"""
+    """returns (dx [+ dres], dgamma, dbeta, db4 (same values as dbeta, its own tensor; None without b4), ds, dbaft)"""
     rows, cols = x2d.shape
     dev = x2d.device
     dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
     dg = torch.empty(cols, dtype=torch.float32, device=dev) if gamma is not None else None
     db = torch.empty(cols, dtype=torch.float32, device=dev)
+    db4 = torch.empty(cols, dtype=torch.float32, device=dev) if b4 is not None else None
     dba = torch.empty(cols, dtype=torch.float32, device=dev)
     ds = torch.empty_like(s)
     ws = workspace(lib().ofq_layernorm_lsq_bwd_ws_bytes(rows, cols), dev)
     _chk(lib().ofq_layernorm_lsq_bwd(gq2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                      _p(dres2d), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, dx.data_ptr(), _p(dg),
-                                     db.data_ptr(), ds.data_ptr(), dba.data_ptr(), rows, cols, x2d.stride(0), gq2d.stride(0),
-                                     ws.data_ptr(), ws.numel(), _stream()), "ofq_layernorm_lsq_bwd")
-    return dx, dg, db, ds, dba
+                                     db.data_ptr(), _p(db4), ds.data_ptr(), dba.data_ptr(), rows, cols, x2d.stride(0),
+                                     gq2d.stride(0), ws.data_ptr(), ws.numel(), _stream()), "ofq_layernorm_lsq_bwd")
+    return dx, dg, db, db4, ds, dba
 
 
 # ------------------------------------------------------------------------------------------------ CGA
