@@ -700,3 +700,27 @@ def test_statsq_multi_tensor_equals_the_per_tensor_launch(ops):
         assert torch.equal(s, s1) and torch.equal(codes, c1)
         assert (codesT is None) == (t1 is None) and (codesT is None or torch.equal(codesT, t1))
         assert (r is None) == (r1 is None) and (r is None or torch.equal(r, r1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [198, 130, 64])
+def test_qattn_dxq_wide_kernel_vs_fp64(ops, N):
+    """dxq on the 128x384-tile kernel (C = 384: the DeiT-S case; k runs over (head, key token) with a k tail since
+    N % 32 != 0, rows past N in the second token tile, pad columns of dS left uninitialised on purpose) against fp64,
+    plain and accumulating (attention.py:210, backward of x_hat . qkx_hat^T)."""
+    B, H, C = 3, 6, 384
+    Np = (N + 7) // 8 * 8
+    rs = np.random.RandomState(11 + N)
+    gq = 0.013
+    qcodes = torch.from_numpy(rs.randint(-2, 2, (B, N, H, C)).astype(np.int8))
+    sq = T(0.05 + rs.rand(N * H).astype(np.float32))
+    dS = torch.full((B, H, N, Np), float("nan"))
+    dS[..., :N] = T(rs.randn(B, H, N, N).astype(np.float32) * 1e-2)
+    aq = O.lsq_effective_scale(sq, gq).view(N, H).double()
+    ref = torch.einsum("bhnm,bmhc->bnc", dS[..., :N].double(), aq[None, :, :, None] * qcodes.double())
+    cu = lambda t: t.cuda()
+    dxq = ops.qattn_dxq(cu(dS), cu(qcodes), cu(sq), gq, B, H, N, C, Np)
+    assert rel_err(dxq.cpu(), ref.float()) < 2e-6
+    base = T(rs.randn(B, N, C).astype(np.float32))
+    dxq2 = ops.qattn_dxq(cu(dS), cu(qcodes), cu(sq), gq, B, H, N, C, Np, out=base.clone().cuda(), accumulate=True)
+    assert rel_err(dxq2.cpu(), (ref + base.double()).float()) < 2e-6
