@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — images/sec of one OFQ QAT training step on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU -- started by torch.distributed.run,
+                                                            or, without a launcher, by this file itself as N children)
 
 Workload (config C3 of BASELINE.json / SURVEY.md §8d): DeiT-S (C384, H6, 12 blocks, 198 tokens) W2A2 with
 QK-reparameterisation, 128 images per GPU (global batch 128*N, weak scaling), fp32, synthetic ImageNet-shaped
 batches (randn images, random labels, random teacher logits), random-init weights.  One step = student
-forward + KDLossSoftandHard + backward (+ bucketed RCCL all-reduce for N > 1) + AdamW step.
+forward + KDLossSoftandHard + backward (+ bucketed RCCL all-reduce for N > 1) + AdamW step; the device side of the step
+is captured once in a hipGraph (engine.GraphedTrainStep) and replayed -- every kernel of every timed step runs.
 
 Prints ONE JSON line on rank 0, with two extra objects:
   roofline      — the dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs per launch / HIP-event time per launch,
@@ -50,6 +52,8 @@ def parse():
     ap.add_argument("--with-teacher", action="store_true",
                     help="second line of SURVEY 8(d): add the fp32 teacher forward (no_grad, same architecture, random init) "
                          "that produces the KD soft targets to every step (train.py:906-910)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -116,8 +120,38 @@ class _c_stdout_to_stderr:
         return False
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this file, one per GPU, as CHILD processes --
+    before this process has touched the GPU (a process that has initialised HIP must never exec or be replaced) -- with the
+    rendezvous variables torch.distributed.run would set, pass rank 0's JSON line through and exit with the worst code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()                 # counts devices without initialising the runtime
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OFQ_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    raise SystemExit(max(abs(c) for c in codes))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,7 +212,18 @@ def main():
                 s_t = t_out
         return engine.train_step(model, opt, images, target, s_t, loss_fn, dp=dp, cga=cga)
 
-    for i in range(args.warmup):
+    eager_step = step
+    use_graph = not args.no_graph and teacher is None
+    n_warm = args.warmup
+    if use_graph:
+        # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures
+        gstep = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=cga, warmup=2)
+        n_warm = max(args.warmup, gstep.warmup + 1)          # the capture must not fall into the timed region
+
+        def step():
+            return gstep(images, target, soft)
+
+    for i in range(n_warm):
         step()
         if args.verbose:
             torch.cuda.synchronize()
@@ -196,13 +241,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    loss_value = float(loss.detach())                 # (the static loss tensor of the graph: read before any further step)
     # roofline pass: the same --steps steps again, live, with HIP events around every matrix-core kernel launch (on the
     # stream the kernels are launched on); rank 0 reports the dominant class
     timer = None if args.no_roofline_events else {}
     if timer is not None:
         ops.TIMERS = timer
         for _ in range(args.steps):
-            step()
+            eager_step()                                    # HIP events cannot sit inside a replayed graph
         torch.cuda.synchronize()
         ops.TIMERS = None
         if world > 1:
@@ -254,7 +300,9 @@ def main():
                                          " + CGA hooks" if args.cga else "", B,
                                          "7x7 windows" if args.model.startswith("swin") else "198 tokens",
                                          "fp32 teacher forward in the step" if args.with_teacher else "teacher logits synthetic"),
-                          "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss.detach())},
+                          "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
+                          "launch": "hipGraph replay" if use_graph else "eager (one ctypes launch per kernel)",
+                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)

@@ -23,13 +23,15 @@
 extern "C" {
 #endif
 
-#define OFQ_ABI_VERSION 1
+#define OFQ_ABI_VERSION 2
 #define OFQ_EINVAL (-1)  /* bad argument (shape, alignment, null pointer) */
 #define OFQ_ENOWS  (-2)  /* workspace too small */
 
 typedef void* ofq_stream_t;
 
 int ofq_abi_version(void);
+/* "OFQ_SOURCE_HASH=<16 hex>": content hash of the kernel sources + this header the library was built from */
+const char* ofq_source_hash(void);
 
 /* ---- K1  StatsQ weight quantiser: StatsQuantizer.forward, src/quantization/quantizer/statsq.py:133-150
  *  s_r = 2*mean_c|W_rc| ; L = rne(clamp(W/s,-1,1-1e-6)*n - 0.5) ; Wq = s*(L+0.5)/n ; out = (Wq - W) + W
@@ -240,6 +242,14 @@ int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, co
 int64_t ofq_adamw_tensor_entry_bytes(void);
 int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps, float weight_decay,
                     double bias_correction1, double bias_correction2, ofq_stream_t stream);
+/*  hipGraph form of the same step: a captured launch must not carry the per-step lr / bias corrections in its arguments,
+ *  so the eight scalars {lr, 1-b1, b2, 1-b2, eps, wd, bc1, sqrt(bc2)} live in DEVICE memory.  ofq_adamw_hyper_pack forms
+ *  their HOST image exactly as ofq_adamw_multi does (bit-identical updates); ofq_store_f32 writes up to 32 floats to device
+ *  memory with the values travelling in the kernel arguments (legal beside a graph replay, nothing to keep alive). */
+int ofq_adamw_hyper_pack(float* host8, float lr, double beta1, double beta2, float eps, float weight_decay,
+                         double bias_correction1, double bias_correction2);
+int ofq_adamw_multi_dev(const void* tensors, int64_t n_tensors, const float* hyper_dev, ofq_stream_t stream);
+int ofq_store_f32(float* dst_dev, const float* host_vals, int n, ofq_stream_t stream);
 
 /* ---- K16  CGA: freeze_outside_boundary_weight_idx cga.py:450-469 and the step hooks cga.py:962-964,
  *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */

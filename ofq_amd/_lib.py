@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "ofq_abi_version": (i32, []),
+    "ofq_source_hash": (C.c_char_p, []),
     "ofq_statsq_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, i32, i32, vp]),
     "ofq_statsq_codes_fwd": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ofq_statsq_tensor_entry_bytes": (i64, []),
@@ -70,6 +71,9 @@ SIGNATURES = {
                                     i64, i64, vp, sz, vp]),
     "ofq_adamw_tensor_entry_bytes": (i64, []),
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
+    "ofq_adamw_hyper_pack": (i32, [vp, f32, f64, f64, f32, f32, f64, f64]),
+    "ofq_adamw_multi_dev": (i32, [vp, i64, vp, vp]),
+    "ofq_store_f32": (i32, [vp, vp, i32, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
     "ofq_cga_tensor_entry_bytes": (i64, []),
     "ofq_cga_freeze_mask_multi": (i32, [vp, i64, i32, f32, vp]),
@@ -78,20 +82,24 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2
 
 
 def load():
-    """Load the shared library (building it first if the sources are newer and hipcc is available)."""
+    """Load the shared library; it is (re)built first when it is missing or was built from other sources than the ones
+    next to it (content hash, ofq_amd/build.py), under a file lock so that ranks started together do not race."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        try:
-            from . import build as _b
-            _b.build()
-        except Exception as e:  # noqa: BLE001
-            raise RuntimeError("ofq_amd: %s is missing and could not be built (%s). "
-                               "Run `python -m ofq_amd.build`; there is no CPU fallback." % (LIB_PATH, e))
+    if "OFQ_HIP_LIB" not in os.environ:
+        from . import build as _b
+        if _b.needs_build():
+            try:
+                _b.build()
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError("ofq_amd: %s is missing or stale (built from %s, sources are %s) and could not be "
+                                   "rebuilt (%s). Run `python -m ofq_amd.build`; there is no CPU fallback."
+                                   % (LIB_PATH, _b.built_hash(), _b.source_hash(), e))
     # PyTorch-ROCm ships its own libamdhip64; it has to be in the process BEFORE this library is mapped, otherwise the
     # loader binds our kernels to /opt/rocm's copy and every launch fails with hipErrorNoDevice (two HIP runtimes, the
     # streams and allocations belong to torch's).  Importing torch first makes the soname resolve to the loaded one.
@@ -101,7 +109,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.ofq_abi_version() != 1:
+    if lib.ofq_abi_version() != ABI_VERSION:
         raise RuntimeError("ofq_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib

@@ -22,8 +22,14 @@ struct AdamWPack {
   int32_t n;
 };
 
-__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, float lr, float omb1, float b2, float omb2, float eps,
-                                                          float wd, float bc1, float sqrt_bc2) {
+// the eight step scalars: by value (ofq_adamw_multi) or read from device memory (ofq_adamw_multi_dev: a launch captured
+// in a hipGraph must not carry the per-step lr and bias corrections in its arguments)
+struct AdamWHyper { float lr, omb1, b2, omb2, eps, wd, bc1, sqrt_bc2; };
+
+template <bool DEV>
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, AdamWHyper hv, const AdamWHyper* __restrict__ hd) {
+  const AdamWHyper h = DEV ? *hd : hv;
+  const float lr = h.lr, omb1 = h.omb1, b2 = h.b2, omb2 = h.omb2, eps = h.eps, wd = h.wd, bc1 = h.bc1, sqrt_bc2 = h.sqrt_bc2;
   int ti = 0;
   while (ti + 1 < pk.n && (int)blockIdx.x >= pk.first_chunk[ti + 1]) ++ti;
   const AdamWTensor t = pk.t[ti];
@@ -72,12 +78,33 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, float lr
 
 extern "C" int64_t ofq_adamw_tensor_entry_bytes(void) { return (int64_t)sizeof(AdamWTensor); }
 
-// tensors: HOST array of n_tensors entries {p, g, m, v, frozen (or NULL), n} with device pointers inside
-extern "C" int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps,
-                               float weight_decay, double bias_correction1, double bias_correction2, ofq_stream_t stream) {
-  if (!tensors || n_tensors <= 0 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
+// host image of the eight scalars exactly as ofq_adamw_multi forms them (1 - beta in double, sqrt(bc2) in double)
+extern "C" int ofq_adamw_hyper_pack(float* host8, float lr, double beta1, double beta2, float eps, float weight_decay,
+                                    double bias_correction1, double bias_correction2) {
+  if (!host8 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
+  const AdamWHyper h = {lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay,
+                        (float)bias_correction1, (float)sqrt(bias_correction2)};
+  memcpy(host8, &h, sizeof(h));
+  return 0;
+}
+
+// dst[i] = vals[i], i < n <= 32: the values travel in the kernel arguments (no staging buffer to keep alive, legal next to
+// a graph replay on the same stream)
+struct StoreF32Args { float v[32]; };
+__global__ void store_f32_kernel(float* dst, StoreF32Args a, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = a.v[threadIdx.x];
+}
+extern "C" int ofq_store_f32(float* dst_dev, const float* host_vals, int n, ofq_stream_t stream) {
+  if (!dst_dev || !host_vals || n <= 0 || n > 32) return OFQ_EINVAL;
+  StoreF32Args a = {};
+  for (int i = 0; i < n; ++i) a.v[i] = host_vals[i];
+  hipLaunchKernelGGL(store_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_dev, a, n);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+static int adamw_launch(const void* tensors, int64_t n_tensors, const AdamWHyper& hv, const AdamWHyper* hd, hipStream_t stream) {
   const AdamWTensor* ts = (const AdamWTensor*)tensors;
-  const float sq2 = (float)sqrt(bias_correction2);
   for (int64_t base = 0; base < n_tensors; base += ADAMW_PACK) {
     AdamWPack pk = {};
     pk.n = (int32_t)((n_tensors - base < ADAMW_PACK) ? (n_tensors - base) : ADAMW_PACK);
@@ -91,10 +118,24 @@ extern "C" int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr,
     }
     pk.first_chunk[pk.n] = (int32_t)chunks;
     if (chunks == 0) continue;
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, pk, lr,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay,
-                       (float)bias_correction1, sq2);
+    if (hd) hipLaunchKernelGGL(adamw_multi_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd);
+    else hipLaunchKernelGGL(adamw_multi_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd);
     OFQ_LAUNCH_CHECK();
   }
   return 0;
+}
+
+// tensors: HOST array of n_tensors entries {p, g, m, v, frozen (or NULL), n} with device pointers inside
+extern "C" int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps,
+                               float weight_decay, double bias_correction1, double bias_correction2, ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
+  AdamWHyper h;
+  ofq_adamw_hyper_pack((float*)&h, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2);
+  return adamw_launch(tensors, n_tensors, h, nullptr, (hipStream_t)stream);
+}
+
+// the same step with the eight scalars read from DEVICE memory (hyper_dev: 8 floats in ofq_adamw_hyper_pack's order)
+extern "C" int ofq_adamw_multi_dev(const void* tensors, int64_t n_tensors, const float* hyper_dev, ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || !hyper_dev) return OFQ_EINVAL;
+  return adamw_launch(tensors, n_tensors, AdamWHyper{}, (const AdamWHyper*)hyper_dev, (hipStream_t)stream);
 }

@@ -1,6 +1,12 @@
 // Single translation unit of libofq_hip.so (gfx950 only).
 #include "common.h"
 extern "C" int ofq_abi_version(void) { return OFQ_ABI_VERSION; }
+#ifndef OFQ_SOURCE_HASH
+#define OFQ_SOURCE_HASH "unhashed-build--"
+#endif
+// content hash of csrc/* + include/ofq_hip.h at build time (ofq_amd/build.py); the loader compares it with the sources
+// it finds next to the library and refuses (or rebuilds) a stale .so
+extern "C" const char* ofq_source_hash(void) { return "OFQ_SOURCE_HASH=" OFQ_SOURCE_HASH; }
 #include "statsq.hip"
 #include "lsq.hip"
 #include "softmax_lsq.hip"

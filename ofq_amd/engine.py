@@ -212,9 +212,8 @@ def invalidate_weight_codes(model):
         q._pre = None
 
 
-def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
-    """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
-    loss_fn = loss_fn or KDLossSoftandHard()
+def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
+    """Everything of one step that touches the device (train.py:893-933); GraphedTrainStep captures exactly this."""
     if dp is not None:
         dp.zero_grad()
     else:
@@ -238,3 +237,95 @@ def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=N
     if cga is not None:
         cga.after_step(optimizer)
     return loss
+
+
+def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
+    """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
+    loss_fn = loss_fn or KDLossSoftandHard()
+    if dp is not None:
+        dp.sync_buffers()                       # DDP's per-forward buffer broadcast (train.py:727, broadcast_buffers=True)
+    return _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga)
+
+
+def _latch_quantizers(model):
+    from .quantization.quantizer.lsq import LsqQuantizer4img
+    return [(m, q) for m in model.modules() for q in [getattr(m, "input_quant_fn", None)] if isinstance(q, LsqQuantizer4img)]
+
+
+class GraphedTrainStep:
+    """train_step() with the device side of the step captured once in a hipGraph and replayed: one hipGraphLaunch instead of
+    ~850 ctypes launches and ~20 ms of Python per step (the C ABI is capture-safe by construction: no allocation, no sync,
+    no global state; torch's allocator serves the capture from a private pool, so every activation, gradient and workspace
+    address is the same in every replay).
+
+    What is NOT in the graph, because it changes from step to step on the host:
+      * lr and the AdamW bias corrections -- FusedAdamW keeps them in device memory and advance_for_replay() rewrites
+        them before each replay (same host arithmetic as the eager step: the update is bit-identical);
+      * the batch: copied into the static input buffers (a device-to-device copy; skipped when the caller passes the
+        static buffers themselves, as bench.py does);
+      * DDP's per-forward buffer broadcast and the stem quantiser's signedness latch (lsq.py:338-355), a host decision:
+        checked before the replay while the quantiser is still unsigned; if it flips, the step is re-captured.
+
+    The first `warmup` calls run eagerly (real training steps: lazily created state -- optimizer moments, workspaces,
+    CGA masks -- must exist before the capture); the next call captures and replays."""
+
+    def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2):
+        if not hasattr(optimizer, "advance_for_replay"):
+            raise RuntimeError("GraphedTrainStep needs ofq_amd.optim.FusedAdamW (per-step scalars in device memory)")
+        self.model, self.optimizer, self.dp, self.cga = model, optimizer, dp, cga
+        self.loss_fn = loss_fn or KDLossSoftandHard()
+        self.warmup = int(warmup)
+        self.calls = 0
+        self.graph = None
+        self.static = None
+        self.loss = None
+        self.captures = 0
+        self._static_grads = []
+        self._latches = _latch_quantizers(model)
+
+    def _unsigned_latches(self):
+        return [(m, q) for m, q in self._latches if not q.latched()]
+
+    def _capture(self, images, target, soft_target):
+        dev = images.device
+        self.static = (images, target, soft_target)          # the caller's tensors become the static inputs
+        self.optimizer.begin_capture(dev)
+        self.optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        # with a process group alive, RCCL's watchdog thread queries events while the capture runs: only this thread's
+        # calls (and the autograd thread's launches on the capturing stream) belong to the capture
+        mode = "thread_local" if self.dp is not None and self.dp.sync else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
+            self.loss = _step_body(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+        self.graph = g
+        self.captures += 1
+        # the gradient tensors the replays write (static addresses in the graph's pool)
+        self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+
+    def __call__(self, images, target, soft_target):
+        self.calls += 1
+        if self.graph is None and self.calls <= self.warmup:
+            return train_step(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+        if self.dp is not None:
+            self.dp.sync_buffers()
+        # the signedness latch of a still-unsigned image quantiser: decide on the host, as the eager forward would
+        flipped = False
+        for m, q in self._unsigned_latches():
+            before = q.latched()
+            q._latch(q.latch_input(images, getattr(m, "move_b4").bias))
+            flipped |= q.latched() != before
+        if self.graph is not None and (flipped or images.shape != self.static[0].shape):
+            self.graph = None                              # clamp bounds / shapes are baked into the captured launches
+        if self.graph is None:
+            self._capture(images, target, soft_target)
+        else:
+            for dst, src in zip(self.static, (images, target, soft_target)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        self.optimizer.advance_for_replay()
+        self.graph.replay()
+        if self._static_grads and self._static_grads[0][0].grad is not self._static_grads[0][1]:
+            for p, g in self._static_grads:            # an eager step in between re-pointed p.grad: show the replay's
+                p.grad = g
+        return self.loss

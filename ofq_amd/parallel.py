@@ -10,12 +10,25 @@ the global ones).  Design notes for MI355X:
     (not one accumulate kernel per parameter), reduced in place (RCCL AVG), and p.grad is re-pointed at the slices,
     so AdamW reads the averaged values with no unpack.
   * buckets are filled in reverse parameter order (heads and last blocks finish first in backward) and each is
-    launched from an autograd post-accumulate hook as soon as its last gradient lands.
+    launched from an autograd post-accumulate hook as soon as its last gradient lands.  The first synchronised backward
+    records the order in which the gradients really arrive and the buckets are rebuilt in that order (as torch's DDP
+    does): the q / k weights of all QKR blocks get their gradients from ONE node at the very end of backward
+    (functional.AllWqkFn), and in parameter order they would hold every bucket back until then.
+  * buffers: DDP re-broadcasts rank 0's buffers before every forward (train.py:727, broadcast_buffers=True).  The only
+    buffers on this path are the stem quantiser's data-latched `signed` flags (lsq.py:310, 338-355), which go 0 -> 1 once
+    and never back: sync_buffers() does the same broadcast before each forward until rank 0 holds them at 1, after
+    which the broadcast is the identity and is skipped (no per-step collective, no per-step host sync).
+  * a parameter that takes no part in a step: DDP (find_unused_parameters=False, the reference's setting) raises;
+    so does finish_gradient_sync().
 StatsQ statistics need no collective: s = 2*mean|W| is a pure function of replica-identical weights
 (SURVEY.md §2.3); `check_statsq_consistency` verifies exactly that with one tiny all-reduce.
 """
 import torch
 import torch.distributed as dist
+
+
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 class GradBucket:
@@ -36,6 +49,10 @@ class DataParallel(torch.nn.Module):
         # force_sync: run the hooks / collectives even in a one-rank group (exercises the RCCL path on a 1-GPU box)
         self.sync = self.world > 1 or (force_sync and dist.is_initialized())
         self._hooks = []
+        self._bucket_mb = bucket_mb
+        self._arrival = None               # parameter arrival order of the first synchronised backward (then: buckets rebuilt)
+        self._rebuilt = False
+        self._buffers_settled = False
         if broadcast and self.sync:
             self.broadcast_parameters()
         self._build_buckets(bucket_mb)
@@ -53,9 +70,47 @@ class DataParallel(torch.nn.Module):
                 n = t.numel()
                 t.copy_(flat[off:off + n].view_as(t))
                 off += n
+        self._forget_latches()
 
-    def _build_buckets(self, bucket_mb):
+    def _latch_quantizers(self):
+        return [m for m in self.module.modules() if hasattr(m, "sync_latch") and hasattr(m, "latched")]
+
+    def _forget_latches(self):
+        for q in self._latch_quantizers():
+            q.sync_latch()
+
+    @torch.no_grad()
+    def sync_buffers(self):
+        """DDP's per-forward buffer broadcast from rank 0, skipped once it has become the identity (see the module text)."""
+        if not self.sync or self._buffers_settled:
+            return
+        bufs = [b.data for b in self.module.buffers()]
+        if not bufs:
+            self._buffers_settled = True
+            return
+        for dtype in {t.dtype for t in bufs}:
+            group = [t for t in bufs if t.dtype == dtype]
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src=0, group=self.group)
+            off = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+        self._forget_latches()
+        latches = self._latch_quantizers()
+        latch_bufs = {id(q.signed) for q in latches}
+        # every rank now holds rank 0's values, so every rank takes the same decision
+        self._buffers_settled = all(id(b) in latch_bufs for b in self.module.buffers()) and all(q.latched() for q in latches)
+
+    def _build_buckets(self, bucket_mb, order=None):
         params = [p for p in self.module.parameters() if p.requires_grad]
+        if order is not None:
+            seen = {id(p) for p in order}
+            params = [p for p in params if id(p) not in seen] + list(reversed(order))     # reversed again below
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         cap = int(bucket_mb * 1024 * 1024 / 4)
         groups, cur, cur_n = [], [], 0
         for p in reversed(params):                      # backward produces gradients roughly in reverse order
@@ -91,6 +146,8 @@ class DataParallel(torch.nn.Module):
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+        if self.sync and not self._rebuilt and self._arrival is None:
+            self._arrival = []                        # record the first synchronised backward
 
     def _launch(self, b):
         """Pack the bucket's gradients into its flat buffer with one multi-tensor copy, start the asynchronous
@@ -98,9 +155,11 @@ class DataParallel(torch.nn.Module):
         every p.grad at its slice, which will hold the averaged value once the work completes."""
         have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
         if len(have) < len(b.params):
-            b.flat.zero_()                            # parameters that took no part in this step contribute zeros
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            # torch's DDP with find_unused_parameters=False (the reference, train.py:727) fails here as well
+            raise RuntimeError("ofq_amd DataParallel: %d parameter(s) of a gradient bucket took no part in this step "
+                               "(no gradient); every trainable parameter must be used in the forward"
+                               % (len(b.params) - len(have)))
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(b.views, b.params):
             p.grad = v
         if self._avg:
@@ -110,6 +169,8 @@ class DataParallel(torch.nn.Module):
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if self._arrival is not None:
+            self._arrival.append(p)
         b = self._bucket_of[p]
         b.pending -= 1
         if b.pending == 0:
@@ -131,6 +192,18 @@ class DataParallel(torch.nn.Module):
                     self._launch(b)
             for b in self.buckets:
                 b.work.wait()
+            if not self._rebuilt and self._arrival and not _capturing(self.buckets[0].flat):
+                # same autograd graph on every rank => same arrival order on every rank => same buckets
+                order, self._arrival, self._rebuilt = self._arrival, None, True
+                grads = {id(p): p.grad for b in self.buckets for p in b.params}
+                self._build_buckets(self._bucket_mb, order=order)
+                for b in self.buckets:                # this step's averaged gradients move to the new slices
+                    for v, p in zip(b.views, b.params):
+                        v.copy_(grads[id(p)])
+                        p.grad = v
+                for b in self.buckets:
+                    b.pending, b.work = len(b.params), None
+                return
         self._reset()
 
     def forward(self, *a, **k):

@@ -207,26 +207,49 @@ class LsqQuantizer4img(_LsqBase):
     def __init__(self, bit=8, all_positive=False, per_channel=True, learnable=True, **kwargs):
         super().__init__(bit, all_positive, per_channel, learnable)
         self.register_buffer("signed", torch.zeros(1))                   # lsq.py:310
+        self._signed_host = None     # host copy of `signed` (None: unknown, read the buffer once); see _latch
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._signed_host = None
+
+    def sync_latch(self):
+        """Forget the host copy of `signed` (call after writing the buffer from outside: broadcast, checkpoint load)."""
+        self._signed_host = None
+
+    def latched(self):
+        if self._signed_host is None:
+            self._signed_host = float(self.signed) != 0
+        return self._signed_host
 
     def _latch(self, xin):
-        # lsq.py:338-355 (one host sync per call in the reference as well; the stem runs once per step)
-        if float(self.signed) == 0 and bool((xin.min() < -1e-5).item()):
+        """lsq.py:338-355: `signed` goes 0 -> 1 the first time a negative value is seen and never back.  The reference
+        reads the buffer (a device sync) on every call; here the host keeps a copy, so a latched quantiser -- every
+        normalised ImageNet batch -- costs no sync, and the data is only inspected while the quantiser is unsigned."""
+        if not self.latched() and bool((xin.min() < -1e-5).item()):
             self.signed.data.fill_(1)
-        self.thd_neg, self.thd_pos = _bounds(self.bit, float(self.signed) == 0)
+            self._signed_host = True
 
     def _geom(self, shp, bias_len, prologue, ldx, ldy):
         B, Cc, Hh, Ww = shp
         return ops.LsqGeom(B, Cc, Hh * Ww, bias_len, 0, self.thd_neg, self.thd_pos, B * Hh * Ww, prologue)
 
     def _init_value(self, x):
-        return 2 * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=0) / (self.thd_pos ** 0.5)    # lsq.py:322
+        k = 4 if self.all_positive else 2                                # lsq.py:322-323
+        return k * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=0) / (self.thd_pos ** 0.5)
 
     def _add_bias_for_init(self, xin, b4):
         return xin + b4.view(xin.shape[-1], xin.shape[-2])               # qbias.py:21
 
+    def latch_input(self, x, b4):
+        return x.detach() if b4 is None else x.detach() + b4.detach().view(x.shape[-1], x.shape[-2])
+
     def quant(self, x, b4=None, baft=None, **kw):
-        xin = x.detach() if b4 is None else x.detach() + b4.detach().view(x.shape[-1], x.shape[-2])
-        self._latch(xin)
+        # inside a stream capture the host cannot look at the data: engine.GraphedTrainStep takes the decision before the
+        # capture / replay and re-captures when it flips (the clamp bounds are arguments of the captured launches)
+        if not self.latched() and not torch.cuda.is_current_stream_capturing():
+            self._latch(self.latch_input(x, b4))
+        self.thd_neg, self.thd_pos = _bounds(self.bit, not self.latched())
         return super().quant(x, b4, baft, **kw)
 
 
@@ -245,7 +268,8 @@ class LsqQuantizer4Conv2d(_LsqBase):
         return ops.LsqGeom(1, O, inner, 0, 0, self.thd_neg, self.thd_pos, inner)
 
     def _init_value(self, x):
-        return 2 * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=-1) / (self.thd_pos ** 0.5)   # lsq.py:405
+        k = 4 if self.all_positive else 2                                # lsq.py:405-406
+        return k * x.abs().mean(dim=-1).mean(dim=-1).mean(dim=-1) / (self.thd_pos ** 0.5)
 
 
 class LsqQuantizerWeight(_LsqBase):

@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), "include/ofq_hip.h declares %s but %s does not export it" % (name, so)
     handle = _lib.load()
-    assert handle.ofq_abi_version() == 1
+    assert handle.ofq_abi_version() == 2
 
 
 def test_python_binding_table_matches_header():

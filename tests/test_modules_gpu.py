@@ -21,6 +21,20 @@ def _rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _elementwise_bad_fraction(a, b, tol=TOL, floor=0.1):
+    """Share of the NON-TINY elements (|ref| > floor * max|ref|) whose own relative error exceeds tol.  rel_err / _rel_l2
+    are normalised by the tensor's scale; this is the element-wise reading of BASELINE.json's 'within 1e-3 fp32 relative'.
+    Isolated elements may legitimately differ (a value that sits on a clamp edge follows fp32 rounding noise, in the
+    reference as well), so callers bound the share, not the maximum."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu().reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).cpu().reshape(-1)
+    big = b.abs() > floor * b.abs().max()
+    if not bool(big.any()):
+        return 0.0
+    rel = ((a - b).abs() / b.abs())[big]
+    return float((rel > tol).double().mean())
+
+
 def _offset_grad_err(grad, g, name):
     """Gradients of the LearnableBias offsets around attention are compared on the common scale of the module's
     offset gradients, not each on its own: d/d(move_k_aft) and d/d(move_qkx_aft) are identically zero in exact
@@ -183,8 +197,11 @@ def test_tiny_deit_full_step_golden(env):
                 worst[pn] = e
                 n += 1
         assert n > 60
-        bad = {k: v for k, v in worst.items() if v > 5e-3}
+        bad = {k: v for k, v in worst.items() if v > TOL}          # BASELINE.json: 1e-3 (measured: 1e-7 .. 1e-5)
         assert not bad, bad
+        frac = {pn: _elementwise_bad_fraction(p.grad, g["grad:" + pn]) for pn, p in model.named_parameters()
+                if "grad:" + pn in g and "move_" not in pn}
+        assert max(frac.values()) <= 2e-3, {k: v for k, v in frac.items() if v > 2e-3}
         model.eval()
         with torch.no_grad():
             ev, _ = model(img)
@@ -300,7 +317,7 @@ def test_swin_tiny_full_step_golden(env):
             if "grad:" + pn in g:
                 assert p.grad is not None, pn
                 e = _offset_grad_err(p.grad, g, pn) if "move_" in pn else _rel_l2(p.grad, g["grad:" + pn])
-                if e > 5e-3 and float(np.abs(g["grad:" + pn]).max()) > 1e-6:
+                if e > TOL and float(np.abs(g["grad:" + pn]).max()) > 1e-6:
                     bad[pn] = e
                 n += 1
         assert n > 80 and not bad, bad
@@ -513,3 +530,41 @@ def test_bulk_wqk_equals_per_block_wqk():
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_zero_rowsum_term_of_dxhat_is_rounding_residue():
+    """The product drops `rowsum(dS) * move_qkx_aft` from dx_hat (functional.QKRScoresCodesFn.backward): dS is a softmax
+    backward, its rows sum to zero, so the term the reference's autograd adds (attention.py:207-210) is fp32 rounding
+    residue.  With functional.KEEP_ZERO_ROWSUM_TERM the term is computed as the reference does; every gradient of a full
+    QKR model must agree with the default path to 1e-6 of its scale (1e-3 is the parity tolerance)."""
+    import copy
+    from ofq_amd import engine, functional as F_ofq
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    torch.manual_seed(3)
+    base = engine.build_student("deit_tiny_distilled_patch16_224", 2, 2, qk_reparam=True, depth=3).cuda()
+    with torch.no_grad():
+        for blk in base.blocks:                                  # non-zero offsets, or the term is exactly zero
+            blk.attn.move_qkx_aft.bias.normal_(0.0, 0.05)
+            blk.attn.quant_x_4_qkv.move_aft.bias.normal_(0.0, 0.05)
+    imgs = torch.randn(4, 3, 224, 224, device="cuda")
+    tgt = torch.randint(0, 1000, (4,), device="cuda")
+    soft = torch.randn(4, 1000, device="cuda")
+    engine.setup_alpha(base, imgs)
+    grads = []
+    try:
+        for keep in (False, True):
+            F_ofq.KEEP_ZERO_ROWSUM_TERM = keep
+            model = copy.deepcopy(base).train()
+            out, _ = model(imgs)
+            KDLossSoftandHard()(out, tgt, soft).backward()
+            grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        F_ofq.KEEP_ZERO_ROWSUM_TERM = False
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 50
+    differs = False
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        differs |= not torch.equal(a, b)
+        assert rel_err(a, b) < 1e-6, (n, rel_err(a, b))
+    assert differs          # the switch really changes the computation (it adds the residue)

@@ -78,16 +78,28 @@ def _worker(rank, world, port, q):
     for b in dp.buckets:
         for p in b.params:
             assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
-    # second step works after the reset, and optimizer steps keep replicas identical; `extra` takes no part in these
-    # steps (no gradient): its bucket is launched by finish_gradient_sync with a zero contribution
+    # the first synchronised backward recorded the arrival order of the gradients and the buckets were rebuilt in it
+    # (c before b before a: the order backward produces them), identically on both ranks
+    assert dp._rebuilt
+    order = [id(p) for b in dp.buckets for p in b.params]
+    pos = {k: order.index(id(getattr(net, k).weight)) for k in "abc"}
+    assert pos["c"] < pos["b"] < pos["a"], pos
+    sizes = torch.tensor([float(len(b.params)) for b in dp.buckets] + [float(len(dp.buckets))])
+    s2 = sizes.clone()
+    dist.broadcast(s2, src=0)
+    assert torch.equal(sizes, s2)
+    # further steps work after the rebuild, and optimizer steps keep replicas identical
     opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=1e-2)
     for _ in range(2):
         dp.zero_grad()
         assert all(p.grad is None for p in net.parameters())
-        ((dp(xs) - ys) ** 2).mean().backward()
-        assert net.extra.grad is None
+        (((dp(xs) - ys) ** 2).mean() + 0.0 * net.extra.sum()).backward()
         dp.finish_gradient_sync()
-        assert net.extra.grad is not None and float(net.extra.grad.abs().max()) == 0.0
+        g2 = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
+        (g_lo, g_hi) = (g2.clone(), g2.clone())
+        dist.all_reduce(g_lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(g_hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(g_lo, g_hi)
         opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     lo, hi = flat.clone(), flat.clone()
@@ -101,6 +113,30 @@ def _worker(rank, world, port, q):
     h._s_dev = 2 * net.a.weight.detach().abs().mean(1)
     net.holder = h
     assert check_statsq_consistency(net) == 0.0
+    # DDP's per-forward buffer broadcast (train.py:727) for the data-latched `signed` flag (lsq.py:338-355)
+    from ofq_amd.quantization.quantizer.lsq import LsqQuantizer4img
+    net3 = Net()
+    del net3.signed
+    net3.input_quant_fn = LsqQuantizer4img(bit=8)
+    dp3 = DataParallel(net3, bucket_mb=1.0)
+    qz = net3.input_quant_fn
+    pos_x, neg_x = torch.rand(2, 3, 4, 4), -torch.rand(2, 3, 4, 4) - 1.0
+    dp3.sync_buffers()                                   # forward 1: rank 0 sees unsigned data, rank 1 signed data
+    qz._latch(neg_x if rank == 1 else pos_x)
+    assert qz.latched() == (rank == 1) and not dp3._buffers_settled
+    dp3.sync_buffers()                                   # forward 2: rank 0's buffer (0) overwrites rank 1's local latch
+    assert not qz.latched() and float(qz.signed) == 0.0
+    qz._latch(neg_x if rank == 0 else pos_x)             # now rank 0 sees negative data and latches
+    assert qz.latched() == (rank == 0)
+    dp3.sync_buffers()                                   # forward 3: every rank holds rank 0's 1; the broadcast has
+    assert qz.latched() and float(qz.signed) == 1.0      # become the identity and is skipped from now on
+    assert dp3._buffers_settled
+    dp3.sync_buffers()
+    # a parameter that takes no part in a step: DDP with find_unused_parameters=False raises, and so does this
+    dp.zero_grad()
+    ((dp(xs) - ys) ** 2).mean().backward()
+    with pytest.raises(RuntimeError, match="took no part"):
+        dp.finish_gradient_sync()
     q.put((rank, "ok"))
     dist.destroy_process_group()
 

@@ -39,7 +39,9 @@ def T(a, device="cpu"):
 
 
 def rel_err(a, b):
-    """max|a-b| / max|b|  (the 'fp32 relative tolerance' of BASELINE.json, normalised by the tensor scale)."""
+    """max|a-b| / max|b|: the 'fp32 relative tolerance' of BASELINE.json read on the scale of the tensor (max-abs error
+    over max-abs value), NOT element-wise -- an element that is tiny next to its neighbours is compared on their scale.
+    tests/test_modules_gpu.py::_elementwise_bad_fraction adds the element-wise reading on the non-tiny elements."""
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     den = b.abs().max().item()
