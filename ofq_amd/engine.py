@@ -197,7 +197,7 @@ def refresh_weight_codes(model):
     todo = []
     for q in _statsq_modules(model):
         la = q._last_args
-        if la is not None and la[0].is_leaf and la[0].is_cuda and la[0].dim() == 2 and la[0].is_contiguous():
+        if la is not None and la[0] is not None and la[0].is_cuda and la[0].dim() == 2 and la[0].is_contiguous():
             todo.append((q, la))
     if not todo:
         return 0
@@ -280,6 +280,10 @@ class GraphedTrainStep:
         self.static = None
         self.loss = None
         self.captures = 0
+        # the eager warm-up calls and the capture share ONE side stream: autograd nodes that outlive a step (AccumulateGrad
+        # nodes pinned by gradient hooks, for instance) remember the stream they were created on, and a capture must never
+        # touch the default stream
+        self.stream = torch.cuda.Stream()
         self._static_grads = []
         self._latches = _latch_quantizers(model)
 
@@ -293,10 +297,14 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        # with a process group alive, RCCL's watchdog thread queries events while the capture runs: only this thread's
-        # calls (and the autograd thread's launches on the capturing stream) belong to the capture
-        mode = "thread_local" if self.dp is not None and self.dp.sync else "global"
-        with torch.cuda.graph(g, capture_error_mode=mode):
+        mode = "global"
+        if self.dp is not None and self.dp.sync:
+            # with a process group alive, RCCL's watchdog thread polls the events of earlier collectives: let it retire
+            # them (it looks every 100 ms), and let only this thread's calls count as capture errors
+            import time
+            time.sleep(0.35)
+            mode = "thread_local"
+        with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
             self.loss = _step_body(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
         self.graph = g
         self.captures += 1
@@ -306,7 +314,12 @@ class GraphedTrainStep:
     def __call__(self, images, target, soft_target):
         self.calls += 1
         if self.graph is None and self.calls <= self.warmup:
-            return train_step(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                loss = train_step(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+            cur.wait_stream(self.stream)
+            return loss
         if self.dp is not None:
             self.dp.sync_buffers()
         # the signedness latch of a still-unsigned image quantiser: decide on the host, as the eager forward would

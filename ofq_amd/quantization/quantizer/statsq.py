@@ -15,7 +15,9 @@ class _StatsQFn(torch.autograd.Function):
             # code path of a linear layer: scale, codes, transposed bf16 codes and the offset row-dot in ONE launch;
             # the fp32 fake-quant values are not written (nothing reads them), a zero-stride tensor carries the edge
             if not need_values:
-                holder._last_args = (weight, bits, rvec, want_T)        # what refresh_weight_codes() recomputes in bulk
+                # what refresh_weight_codes() / all_wqk() recompute in bulk.  A non-leaf weight (W_qk) is NOT kept: the
+                # reference would pin its grad_fn -- and through it the AccumulateGrad nodes of q / k -- across steps
+                holder._last_args = (weight if weight.is_leaf else None, bits, rvec, want_T)
                 pre = holder._pre
                 if (pre is not None and pre[0].data_ptr() == weight.data_ptr() and pre[0].shape == weight.shape
                         and (pre[1] is None) == (rvec is None) and (rvec is None or pre[1].data_ptr() == rvec.data_ptr())
@@ -46,7 +48,7 @@ class StatsQuantizer(nn.Module):
         self._codes = None
         self._codesT = None
         self._r = None
-        self._last_args = None      # (weight, bits, rvec, want_T) of the last code-path forward
+        self._last_args = None      # (leaf weight or None, bits, rvec, want_T) of the last code-path forward
         self._pre = None            # (weight, rvec, has_T, (s, codes, codesT, r)) filled by engine.refresh_weight_codes()
 
     def codes_T(self):

@@ -39,10 +39,16 @@ def build_parser(cga=False):
     p.add_argument('--sched', default='cosine')
     p.add_argument('--seed', type=int, default=42)
     p.add_argument('--log-interval', type=int, default=50)
+    p.add_argument('--cooldown-epochs', type=int, default=0)
+    p.add_argument('--smoothing', type=float, default=0.1)
     p.add_argument('--output', default='')
     p.add_argument('--resume', default='')
+    p.add_argument('--no-resume-opt', action='store_true')
+    p.add_argument('--initial-checkpoint', default='', help='student weights loaded after the surgery, strict=False (train.py:515-516)')
     p.add_argument('--mixup', type=float, default=0.0)
     p.add_argument('--cutmix', type=float, default=0.0)
+    p.add_argument('--no-graph', action='store_true',
+                   help='launch every kernel from Python instead of replaying the captured hipGraph of the step')
     # quantisation flags (train.py:297-366)
     p.add_argument('--quantized', action='store_true')
     p.add_argument('--wq-enable', action='store_true')
@@ -67,7 +73,10 @@ def build_parser(cga=False):
     p.add_argument('--use-kd', action='store_true')
     p.add_argument('--teacher', default='deit_small_distilled_patch16_224')
     p.add_argument('--teacher_pretrained', action='store_true')
-    p.add_argument('--kd_hard_and_soft', type=int, default=1)
+    p.add_argument('--teacher-checkpoint', default='', help='teacher weights, strict (train.py:331, :440-441)')
+    p.add_argument('--teacher-random-init', action='store_true',
+                   help='explicitly accept a randomly initialised teacher (synthetic-data smoke runs only)')
+    p.add_argument('--kd_hard_and_soft', type=int, default=0, help='0: soft label only, 1: hard + soft label (train.py:360)')
     # process layout (train.py:1085-1096)
     p.add_argument('--world_size', default='1')
     p.add_argument('--visible_gpu', default='')
@@ -107,11 +116,47 @@ class SyntheticLoader:
             yield self.pool[i % len(self.pool)]
 
 
-def cosine_lr(step, total, base, min_lr, warmup_steps, warmup_lr):
-    if step < warmup_steps:
-        return warmup_lr + (base - warmup_lr) * step / max(1, warmup_steps)
-    t = (step - warmup_steps) / max(1, total - warmup_steps)
-    return min_lr + 0.5 * (base - min_lr) * (1 + math.cos(math.pi * min(t, 1.0)))
+def cosine_lr(epoch, epochs, base, min_lr, warmup_epochs, warmup_lr):
+    """timm 0.5.4 CosineLRScheduler as train.py:731-739, :840 drives it (t_in_epochs, warmup_prefix=False, one cycle):
+    the rate is set once per EPOCH; linear warm-up from warmup_lr for warmup_epochs, then the cosine on the UNSHIFTED
+    epoch index, and min_lr from `epochs` on (the cool-down epochs)."""
+    if epoch < warmup_epochs:
+        return warmup_lr + epoch * (base - warmup_lr) / warmup_epochs
+    if epoch >= epochs:
+        return min_lr
+    return min_lr + 0.5 * (base - min_lr) * (1 + math.cos(math.pi * epoch / epochs))
+
+
+def load_checkpoint(model, path, strict=True, map_location="cpu"):
+    """timm.models.helpers.load_checkpoint (train.py:441, :516): accepts a bare state dict or a training checkpoint
+    ('state_dict' / 'model'), strips DDP's 'module.' prefix."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    sd = ck
+    if isinstance(ck, dict):
+        for key in ("state_dict", "model"):
+            if key in ck and isinstance(ck[key], dict):
+                sd = ck[key]
+                break
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=strict)
+
+
+def check_supported(args):
+    """Flags the reference accepts that this path does not implement must not be dropped silently."""
+    bad = []
+    if args.opt.lower() != "adamw":
+        bad.append("--opt %s (only adamw: train_scripts/*, configs/*.yml)" % args.opt)
+    if args.sched != "cosine":
+        bad.append("--sched %s (only cosine)" % args.sched)
+    if args.mixup > 0 or args.cutmix > 0:
+        bad.append("--mixup/--cutmix > 0 (the timm augmentation pipeline is SURVEY.md 8(f) rank 4, not built)")
+    if args.use_kd and args.kd_hard_and_soft not in (0, 1):
+        bad.append("--kd_hard_and_soft %d (0: soft only, 1: hard + soft)" % args.kd_hard_and_soft)
+    if args.use_kd and not args.teacher_checkpoint and not args.teacher_random_init:
+        bad.append("--use-kd without --teacher-checkpoint: the teacher would distil noise (pretrained weights cannot be "
+                   "downloaded here); pass --teacher-random-init to accept that for a synthetic smoke run")
+    if bad:
+        raise SystemExit("ofq_amd train: unsupported or inconsistent options:\n  " + "\n  ".join(bad))
 
 
 def log(rank, msg):
@@ -122,7 +167,8 @@ def log(rank, msg):
 def main_worker(local_rank, args, cga, spawned):
     from . import engine, parallel
     from .deit import create_model
-    from .quantization.utils import KDLossSoftandHard
+    from .quantization.utils import KDLossSoftandHard, KLLossSoft
+    check_supported(args)
     if spawned:
         world = int(args.world_size)
         rank = local_rank
@@ -139,7 +185,7 @@ def main_worker(local_rank, args, cga, spawned):
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # train.py:474
     torch.manual_seed(args.seed)                                                             # train.py:501
-    model = create_model(args.model, num_classes=args.num_classes)
+    model = create_model(args.model, num_classes=args.num_classes, pretrained=args.pretrained)   # raises: no download
     if args.quantized:
         if args.qmodules is None:
             if args.model_type == 'swin':
@@ -148,49 +194,73 @@ def main_worker(local_rank, args, cga, spawned):
                 args.qmodules = engine.default_qmodules(len(model.blocks))
         model = engine.get_qat_model(model, args)                                           # train.py:523
     model.to(dev)
-    teacher = None
-    if args.use_kd:
-        teacher = create_model(args.teacher, num_classes=args.num_classes).to(dev)          # train.py:428
     loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, args.num_classes, dev, args.seed + rank)
     val_loader = SyntheticLoader(args.val_steps, args.batch_size, args.num_classes, dev, args.seed + 1000 + rank)
-    engine.setup_alpha(model, loader.pool[0][0])                                            # train.py:656-657
+    if args.quantized:
+        engine.setup_alpha(model, loader.pool[0][0])                                        # train.py:656-657
+    if args.initial_checkpoint:                                                              # train.py:515-516
+        # (the lazily created LSQ steps exist by now, so a quantised checkpoint's `s` vectors have somewhere to go)
+        load_checkpoint(model, args.initial_checkpoint, strict=False, map_location=dev)
+    teacher = None
+    if args.use_kd:                                                                          # train.py:428-442, :526-531
+        teacher = create_model(args.teacher, num_classes=args.num_classes, pretrained=args.teacher_pretrained).to(dev)
+        if args.teacher_checkpoint:
+            load_checkpoint(teacher, args.teacher_checkpoint, strict=True, map_location=dev)
+        else:
+            log(rank, "WARNING: --teacher-random-init: the teacher has random weights, the soft targets are noise")
+        for p_ in teacher.parameters():          # the reference leaves them trainable and back-propagates into the teacher
+            p_.requires_grad_(False)             # for nothing (no optimizer holds them); the student's gradients are the same
     log(rank, "model: %s, %.2f M parameters" % (args.model, sum(p.numel() for p in model.parameters()) / 1e6))
     optimizer = engine.make_optimizer(model, lr=args.lr, weight_decay=args.weight_decay)    # train.py:662
     start_epoch = 0
     if args.resume:                                                                         # train.py:691-706
-        ck = torch.load(args.resume, map_location=dev)
-        model.load_state_dict(ck["state_dict"])
-        if "optimizer" in ck:
+        ck = torch.load(args.resume, map_location=dev, weights_only=False)
+        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in ck["state_dict"].items()})
+        if "optimizer" in ck and not args.no_resume_opt:
             optimizer.load_state_dict(ck["optimizer"])
         start_epoch = ck.get("epoch", -1) + 1
     dp = parallel.DataParallel(model) if world > 1 else None                                # train.py:727
-    loss_fn = KDLossSoftandHard()
+    kd_both = KDLossSoftandHard()
+    kd_soft = KLLossSoft()
+    hard = torch.nn.CrossEntropyLoss(label_smoothing=args.smoothing)                         # train.py:764-769 (mixup off)
+
+    def loss_fn(out, target, soft):                                                          # train.py:896-913
+        if teacher is None:
+            return hard(out[0] if isinstance(out, tuple) else out, target)
+        if args.kd_hard_and_soft == 0:
+            return kd_soft(out, soft)
+        return kd_both(out, target, soft)
     qkr = bool(args.qk_reparam)
     hooks = engine.CGAHooks(model, args.wq_bitw, args.boundaryRange, qk_reparam=qkr, model_type=args.model_type) if cga else None
-    first, last = (args.epochs, args.epochs + args.freeze_for_n_epochs) if cga else (start_epoch, args.epochs)
-    total_steps = max(1, args.epochs * len(loader))
+    first, last = (args.epochs, args.epochs + args.freeze_for_n_epochs) if cga else (start_epoch, args.epochs + args.cooldown_epochs)
+    graphed = None
+    if not args.no_graph and hasattr(optimizer, "advance_for_replay"):
+        graphed = engine.GraphedTrainStep(model, optimizer, loss_fn, dp=dp, cga=hooks)
+    no_soft = torch.zeros(args.batch_size, args.num_classes, device=dev)
     for epoch in range(first, last):                                                        # cga.py:760 / train.py:816
         model.train()
         t_epoch = time.time()
         end = time.time()
         last_logged = -1
+        # cga.py fine-tunes at min-lr; train.py: one rate per epoch (timm's scheduler steps per epoch, train.py:840)
+        lr = args.min_lr if cga else cosine_lr(epoch, args.epochs, args.lr, args.min_lr, args.warmup_epochs, args.warmup_lr)
+        for gparam in optimizer.param_groups:
+            gparam["lr"] = lr
         for bi, (x, y) in enumerate(loader):
-            step = epoch * len(loader) + bi
-            lr = args.min_lr if cga else cosine_lr(step, total_steps, args.lr, args.min_lr,
-                                                   args.warmup_epochs * len(loader), args.warmup_lr)
-            for gparam in optimizer.param_groups:
-                gparam["lr"] = lr
             if teacher is not None:
                 with torch.no_grad():
-                    soft, _ = teacher(x)
+                    soft, _ = teacher(x)          # train mode, like the reference: ((cls, dist), attn); KLLossSoft takes [0]
                     soft = soft[0] if isinstance(soft, tuple) else soft
             else:
-                soft = torch.zeros(x.shape[0], args.num_classes, device=dev)
-            loss = engine.train_step(model, optimizer, x, y, soft, loss_fn, dp=dp, cga=hooks)
+                soft = no_soft
+            if graphed is not None:
+                loss = graphed(x, y, soft)
+            else:
+                loss = engine.train_step(model, optimizer, x, y, soft, loss_fn, dp=dp, cga=hooks)
             if bi % args.log_interval == 0 or bi == len(loader) - 1:
                 torch.cuda.synchronize()                                                    # train.py:944
                 bt = time.time() - end
-                lv = loss.detach()
+                lv = loss.detach().clone()
                 if world > 1:
                     lv = parallel.reduce_tensor(lv, world)                                  # train.py:952
                 n = bi - last_logged
@@ -201,12 +271,14 @@ def main_worker(local_rank, args, cga, spawned):
         metrics = validate(model, val_loader, world, rank)                                  # train.py:828
         log(rank, "epoch %d done in %.1fs  val top1 %.2f  val loss %.4f" % (epoch, time.time() - t_epoch,
                                                                            metrics["top1"], metrics["loss"]))
-        if args.output and rank == 0:                                                       # train.py:850
+        if args.output and rank == 0:                                                       # train.py:850 (timm CheckpointSaver)
             os.makedirs(args.output, exist_ok=True)
-            torch.save({"epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
-                        "args": vars(args)}, os.path.join(args.output, "last.pth.tar"))
+            torch.save({"epoch": epoch, "arch": args.model, "state_dict": model.state_dict(),
+                        "optimizer": optimizer.state_dict(), "version": 2, "args": vars(args), "metric": metrics["top1"]},
+                       os.path.join(args.output, "last.pth.tar"))
     if world > 1:
         dist.destroy_process_group()
+    return {"model": model, "optimizer": optimizer, "metrics": metrics if last > first else None}
 
 
 @torch.no_grad()
@@ -231,7 +303,7 @@ def validate(model, loader, world, rank):
 def main(argv=None, cga=False):
     args = parse_args(sys.argv[1:] if argv is None else argv, cga)
     if "WORLD_SIZE" in os.environ or int(args.world_size) <= 1:
-        main_worker(0, args, cga, spawned=False)
+        return main_worker(0, args, cga, spawned=False)
     else:
         if args.visible_gpu:
             os.environ["CUDA_VISIBLE_DEVICES"] = args.visible_gpu                           # train.py:1087

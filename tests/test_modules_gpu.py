@@ -563,8 +563,12 @@ def test_zero_rowsum_term_of_dxhat_is_rounding_residue():
         F_ofq.KEEP_ZERO_ROWSUM_TERM = False
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 50
     differs = False
+    # the offset gradients that are themselves identically zero in exact arithmetic (see _offset_grad_err) are compared on
+    # the common scale of the module's offset gradients
+    off_scale = max(float(v.abs().max()) for n, v in grads[1].items() if "move_" in n)
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         differs |= not torch.equal(a, b)
-        assert rel_err(a, b) < 1e-6, (n, rel_err(a, b))
+        e = float((a - b).abs().max()) / off_scale if "move_" in n else rel_err(a, b)
+        assert e < 1e-6, (n, e)
     assert differs          # the switch really changes the computation (it adds the residue)
