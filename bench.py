@@ -217,7 +217,7 @@ def main():
     n_warm = args.warmup
     if use_graph:
         # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures
-        gstep = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=cga, warmup=2)
+        gstep = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=cga, warmup=2, alias_inputs=True)
         n_warm = max(args.warmup, gstep.warmup + 1)          # the capture must not fall into the timed region
 
         def step():

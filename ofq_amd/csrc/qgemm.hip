@@ -186,21 +186,14 @@ __device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one m
 #ifndef I8_WPE
 #define I8_WPE 3                   // waves per SIMD the int8 kernel is compiled for (tools/probe/i8_probe.hip overrides it)
 #endif
-// EPI 0: linear layer   1: QKR attention scores   2: P*V
-template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
+// The k-loop of the int8 kernels: acc[2][2] (2x2 blocks of 32x32 per wave, 2x2 waves) += A[m0.., :] . B[n0.., :]^T over K.
+// Shared by the forward kernel and by the backward kernel that recomputes a layer output from the codes.
+__device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned char* A, const unsigned char* B, int m0, int n0,
+                                            unsigned char (*smem)[(128 + 128) * QI8_LD], i32x16 (&acc)[2][2]) {
   constexpr int BM = 128, BN = 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
-  I8_T(0);
-  int tm, tn, gby;
-  qgemm_tile_id(p, tm, tn, gby);
-  const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
-  const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
-  const unsigned char* B = (const unsigned char*)p.B + b0 * p.sB0 + b1 * p.sB1;
   const int K = p.K;
   const int nkt = (K + QI8_BK - 1) / QI8_BK;
 
@@ -218,33 +211,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + kq[i];
     offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + kq[i];
   }
-  // Epilogue parameters (per-row steps / offsets, per-column scales) are requested before the k-loop: a workgroup lives
-  // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
-  // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
-  // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
-  float pre_ra, pre_rb = 0.f, pre_c[2][5];
-  {
-    const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
-    pre_ra = p.s[m % p.S];
-    if (EPI == 0) {
-      const float* qsp = (p.qout && !p.qcolmode) ? p.qs + ((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS : p.s;
-      pre_rb = *qsp;
-    }
-    if (EPI == 1) pre_rb = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
-    if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
-    if (EPI == 0) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nc = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
-        pre_c[j][0] = p.cs[nc];
-        pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
-        pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
-        pre_c[j][3] = ((p.qout && p.qb4) ? p.qb4 : p.cs)[nc];
-        pre_c[j][4] = ((p.qout && p.qcolmode) ? p.qs : p.cs)[nc];
-      }
-    }
-  }
-
   // Two register slots: the loads of tile kt+3 are issued behind the staging of tile kt+1 and are first touched (masked)
   // two k-steps later, so a k-step never waits for the HBM / L2 latency of its own loads (k-steps are only 8 MFMAs
   // long here).  The loop body is branch-free (tiles past the end repeat the last one into a stage nobody reads): guards
@@ -287,7 +253,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     }
   };
 
-  i32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -337,6 +302,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     if (kt < nkt) step(kt, smem[0], smem[1], Slot1());
   }
 #endif
+}
+
+// EPI 0: linear layer   1: QKR attention scores   2: P*V
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
+  I8_T(0);
+  int tm, tn, gby;
+  qgemm_tile_id(p, tm, tn, gby);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b0 = gby / p.nb1, b1 = gby % p.nb1;
+  const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
+  const unsigned char* B = (const unsigned char*)p.B + b0 * p.sB0 + b1 * p.sB1;
+  const int K = p.K;
+  // Epilogue parameters (per-row steps / offsets, per-column scales) are requested before the k-loop: a workgroup lives
+  // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
+  // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
+  // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
+  float pre_ra, pre_rb = 0.f, pre_c[2][5];
+  {
+    const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
+    pre_ra = p.s[m % p.S];
+    if (EPI == 0) {
+      const float* qsp = (p.qout && !p.qcolmode) ? p.qs + ((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS : p.s;
+      pre_rb = *qsp;
+    }
+    if (EPI == 1) pre_rb = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
+    if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+    if (EPI == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nc = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
+        pre_c[j][0] = p.cs[nc];
+        pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
+        pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
+        pre_c[j][3] = ((p.qout && p.qb4) ? p.qb4 : p.cs)[nc];
+        pre_c[j][4] = ((p.qout && p.qcolmode) ? p.qs : p.cs)[nc];
+      }
+    }
+  }
+
+  i32x16 acc[2][2];
+  i8_mainloop(p, A, B, m0, n0, smem, acc);
   I8_T(2);
   float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
   int ncol[2];

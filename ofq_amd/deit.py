@@ -54,5 +54,6 @@ def create_model(name, **kwargs):
     """Stand-in for timm.create_model (train.py:503) restricted to the model families on the hot path."""
     if name not in _REGISTRY:
         raise ValueError("unknown model %r (available: %s)" % (name, sorted(_REGISTRY)))
-    kwargs.pop("drop_rate", None)
+    if kwargs.pop("drop_rate", 0.0):
+        raise ValueError("drop_rate is 0 in every OFQ recipe; the quantised modules do not apply dropout")
     return _REGISTRY[name](**kwargs)

@@ -261,21 +261,22 @@ class GraphedTrainStep:
     What is NOT in the graph, because it changes from step to step on the host:
       * lr and the AdamW bias corrections -- FusedAdamW keeps them in device memory and advance_for_replay() rewrites
         them before each replay (same host arithmetic as the eager step: the update is bit-identical);
-      * the batch: copied into the static input buffers (a device-to-device copy; skipped when the caller passes the
-        static buffers themselves, as bench.py does);
+      * the batch: copied into the graph's static input buffers (a device-to-device copy; with alias_inputs=True the
+        tensors of the capturing call are the static buffers and passing them again costs nothing -- bench.py);
       * DDP's per-forward buffer broadcast and the stem quantiser's signedness latch (lsq.py:338-355), a host decision:
         checked before the replay while the quantiser is still unsigned; if it flips, the step is re-captured.
 
     The first `warmup` calls run eagerly (real training steps: lazily created state -- optimizer moments, workspaces,
     CGA masks -- must exist before the capture); the next call captures and replays."""
 
-    def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2):
+    def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2, alias_inputs=False):
         if not hasattr(optimizer, "advance_for_replay"):
             raise RuntimeError("GraphedTrainStep needs ofq_amd.optim.FusedAdamW (per-step scalars in device memory)")
         self.model, self.optimizer, self.dp, self.cga = model, optimizer, dp, cga
         self.loss_fn = loss_fn or KDLossSoftandHard()
         self.warmup = int(warmup)
-        self.calls = 0
+        self.alias_inputs = bool(alias_inputs)   # True: the tensors of the capturing call ARE the static inputs (bench.py feeds
+        self.calls = 0                           # the same resident batch every step); False: private copies, filled per call
         self.graph = None
         self.static = None
         self.loss = None
@@ -292,7 +293,11 @@ class GraphedTrainStep:
 
     def _capture(self, images, target, soft_target):
         dev = images.device
-        self.static = (images, target, soft_target)          # the caller's tensors become the static inputs
+        if self.alias_inputs:
+            self.static = (images, target, soft_target)
+        else:
+            self.static = tuple(t.clone() for t in (images, target, soft_target))
+        images, target, soft_target = self.static
         self.optimizer.begin_capture(dev)
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()

@@ -60,6 +60,9 @@ class QAttention(deit_attention):
                  weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
                  input_quant_method="lsq", pretrained_initialized=False, **kwargs):
         assert type(m) == deit_attention
+        if m.attn_drop.p != 0:
+            raise ValueError("attention dropout is 0 in every OFQ recipe; the quantised attention core does not apply it "
+                             "(the reference applies attn_drop after the softmax quantiser, attention.py:100 / :217)")
         super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
                          proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
         self.weight_bits = weight_bits
@@ -123,6 +126,9 @@ class QAttention_qkreparam(deit_attention):
                  weight_channelwise=True, input_channelwise=True, weight_quant_method="statsq",
                  input_quant_method="lsq", pretrained_initialized=False, boundaryRange=0.005, **kwargs):
         assert type(m) == deit_attention
+        if m.attn_drop.p != 0:
+            raise ValueError("attention dropout is 0 in every OFQ recipe; the quantised attention core does not apply it "
+                             "(the reference applies attn_drop after the softmax quantiser, attention.py:100 / :217)")
         super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
                          proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
         self.weight_bits = weight_bits

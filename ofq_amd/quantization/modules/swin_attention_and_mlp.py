@@ -51,6 +51,8 @@ class QMLP_swin(torch.nn.Module):
 class _SwinQBase(ShiftedWindowAttention):
     def _base_init(self, m, weight_bits, input_bits, input_channelwise):
         assert type(m) == ShiftedWindowAttention
+        if m.attention_dropout != 0 or m.dropout != 0:
+            raise ValueError("dropout is 0 in every OFQ Swin recipe; the quantised window attention does not apply it")
         ShiftedWindowAttention.__init__(self, dim=m.dim, window_size=m.window_size, shift_size=m.shift_size,
                                         num_heads=m.num_heads, qkv_bias=True, proj_bias=True, attention_dropout=0.0,
                                         dropout=0.0, qqkkvv=m.qqkkvv)

@@ -69,6 +69,8 @@ class _LsqBase(nn.Module):
         super().__init__()
         if bit == 1:
             raise ValueError("1-bit LSQ (sign) is not on the OFQ hot path")
+        if not per_channel:
+            raise ValueError("per_channel=False (one step per tensor) is not used by any OFQ recipe and is not implemented")
         self.bit = bit
         self.per_channel = per_channel
         self.all_positive = all_positive

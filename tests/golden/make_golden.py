@@ -43,8 +43,11 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
+OUT_DIR = os.environ.get("OFQ_GOLDEN_OUT", HERE)       # tests/test_oracle_golden.py regenerates into a temp dir
+
+
 def save(name, d):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **d)
     print("wrote %s  (%d arrays, %.1f KB)" % (path, len(d), os.path.getsize(path) / 1024))
 
@@ -87,6 +90,7 @@ def run_module(mod, x, seed, out_index=None):
 # G1 StatsQ (+ G10: the cga twin is bit-identical)
 # ------------------------------------------------------------------------------------------------
 def g1_statsq():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     case = 0
     for (r, c) in [(8, 16), (12, 32), (48, 384), (6, 1536)]:
@@ -144,6 +148,7 @@ def _lsq_case(q, x, seed, plant=None):
 
 
 def g2_lsq():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
 
     def put(name, d):
@@ -203,6 +208,7 @@ def _linear(i, o, seed):
 
 
 def g3_qlinear():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     cases = [("toy_w2a2", 2, 5, 16, 24, 2, 2, True), ("toy_w4a4", 2, 5, 16, 24, 4, 4, True),
              ("toy_w3a3_unsigned", 2, 5, 16, 24, 3, 3, False), ("n198_w2a2", 2, 198, 96, 160, 2, 2, True)]
@@ -220,6 +226,7 @@ def g3_qlinear():
 
 
 def g5_qmlp():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     for k, (name, B, N, C, Hd, wb, ab) in enumerate([("toy_w2a2", 2, 5, 16, 64, 2, 2), ("toy_w4a4", 2, 7, 16, 48, 4, 4)]):
         m = Mlp(in_features=C, hidden_features=Hd, act_layer=nn.GELU)
@@ -251,6 +258,7 @@ def _attention(C, H, seed):
 
 
 def g4_attention():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     shapes = [("toy", 2, 7, 32, 2), ("n198", 2, 198, 64, 2)]
     k = 0
@@ -278,6 +286,7 @@ def g4_attention():
 # G6 patch embed + head   (LearnableBias4img is hard-wired to 224x224, qlinear.py:163-164)
 # ------------------------------------------------------------------------------------------------
 def g6_stem_head():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     conv = nn.Conv2d(3, 8, kernel_size=16, stride=16)
     with torch.no_grad():
@@ -318,6 +327,7 @@ def _qconfigs(names, wb, ab):
 
 
 def g7_tiny_deit():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     out = {}
     for k, (name, qkr, wb, ab) in enumerate([("plain_w4a4", False, 4, 4), ("qkr_w2a2", True, 2, 2)]):
         depth, dim, heads = 2, 32, 2
@@ -370,6 +380,7 @@ def g7_tiny_deit():
 # G8 CGA: freeze idx, masked grad, restored weights after one AdamW step
 # ------------------------------------------------------------------------------------------------
 def g8_cga():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     import importlib.util
     # cga.py is a script that imports timm training utilities at module import; the function we need
     # (cga.py:450-469) only uses torch/numpy, so execute just that function's source text.
@@ -418,6 +429,7 @@ def g8_cga():
 #          and a tiny full Swin model step
 # ------------------------------------------------------------------------------------------------
 def g9_swin():
+    torch.manual_seed(0)          # every generator starts from its own seed: any subset, any order, same files
     from src.swin import ShiftedWindowAttention, SwinTransformer
     from src.quantization.modules.swin_attention_and_mlp import (QAttention_swin, QAttention_swin_qkreparam,
                                                                  QAttention_swin_qkreparam_4_cga, QMLP_swin)
@@ -448,6 +460,25 @@ def g9_swin():
                 for kk, v in d.items():
                     out[name + ":" + kk] = v
                 k += 1
+    # config C4's bit-width (Swin-T W3A3, BASELINE.json configs[3]): shifted windows, all three attention variants
+    for j, (kind, cls) in enumerate([("plain", QAttention_swin), ("qkr", QAttention_swin_qkreparam),
+                                     ("qkrcga", QAttention_swin_qkreparam_4_cga)]):
+        B, Hh, Ww, C, H, shift, wb, ab = 2, 14, 13, 24, 3, 3, 3, 3
+        sd = 2000 + 10 * j
+        m = ShiftedWindowAttention(C, [7, 7], [shift, shift], H)
+        with torch.no_grad():
+            m.qkv.weight.copy_(T(det_normalish((3 * C, C), sd, 0.2)))
+            m.qkv.bias.copy_(T(det_uniform((3 * C,), sd + 1, -0.1, 0.1)))
+            m.proj.weight.copy_(T(det_normalish((C, C), sd + 2, 0.15)))
+            m.proj.bias.copy_(T(det_uniform((C,), sd + 3, -0.1, 0.1)))
+        q = cls(m=m, weight_bits=wb, input_bits=ab, pretrained_initialized=True)
+        with torch.no_grad():
+            q.relative_position_bias_table.copy_(T(det_normalish(tuple(q.relative_position_bias_table.shape), sd + 4, 0.5)))
+        x = T(det_normalish((B, Hh, Ww, C), sd + 5, 1.0))
+        d = run_module(q, x, sd + 6, out_index=0)
+        d["meta"] = np.array([B, Hh, Ww, C, H, wb, ab, shift, sd + 5])
+        for kk, v in d.items():
+            out["attn_%s_s%d_w%da%d:" % (kind, shift, wb, ab) + kk] = v
     # QLinear on a 4-D input (PatchMerging.reduction: bias-less source -> default-initialised QLinear bias)
     lin = nn.Linear(48, 24, bias=False)
     with torch.no_grad():
@@ -473,8 +504,9 @@ def g9_swin():
     save("g9_swin_modules", out)
 
     # tiny full Swin model
+    torch.manual_seed(1)          # independent of how many module cases ran above
     out = {}
-    for k, (name, qkr, wb, ab) in enumerate([("plain_w4a4", False, 4, 4), ("qkr_w2a2", True, 2, 2)]):
+    for k, (name, qkr, wb, ab) in enumerate([("plain_w4a4", False, 4, 4), ("qkr_w2a2", True, 2, 2), ("qkr_w3a3", True, 3, 3)]):
         depths, heads, dim, ncls = [2, 2], [2, 4], 16, 10
         model = SwinTransformer(patch_size=[4, 4], embed_dim=dim, depths=depths, num_heads=heads, window_size=[7, 7],
                                 num_classes=ncls)

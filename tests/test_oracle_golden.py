@@ -1,5 +1,7 @@
 """Pin oracle/ofq_oracle.py against golden vectors produced by the reference itself
 (tests/golden/make_golden.py, run in the build container against /root/reference).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -271,3 +273,25 @@ def test_g9_swin_tiny_full_step():
                 assert rel_err(gp, v) < 2e-4, k
                 n += 1
         assert n > 80
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree only exists in the build container")
+def test_committed_fixtures_are_what_the_generator_writes(tmp_path):
+    """tests/golden/make_golden.py (which imports the reference itself) regenerates every committed fixture bit for bit:
+    each generator seeds itself, so any subset in any order writes the same files."""
+    import subprocess
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OFQ_GOLDEN_OUT=str(tmp_path))
+    # reversed order on purpose: the files must not depend on which generators ran before
+    order = ["g9", "g8", "g7", "g6", "g5", "g4", "g3", "g2", "g1"]
+    subprocess.check_call([sys.executable, os.path.join(here, "golden", "make_golden.py")] + order, env=env,
+                          stdout=subprocess.DEVNULL)
+    committed = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith(".npz"))
+    assert committed == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    for f in committed:
+        a, b = np.load(os.path.join(here, "golden", f)), np.load(os.path.join(tmp_path, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (f, k)
