@@ -143,6 +143,22 @@ int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, const float* b
                       int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qcodes, int64_t ldq, const float* q_s,
                       int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu, int q_rowmul,
                       int64_t q_coldiv, int q_colmode, ofq_stream_t stream);
+
+/* ---- backward of "linear layer -> input quantiser of its only consumer" WITHOUT the saved activation (qlinear.py:58-73
+ *  followed by lsq.py:571-602 of the next module): ofq_qgemm_i8_nt_q accepts C = NULL and then writes only the consumer's
+ *  codes; this entry recomputes the fp32 layer output y[M][N] from the int8 operands (same k-loop, same epilogue
+ *  expression: bit-identical to the value the forward would have stored) and applies ofq_lsq_bwd's arithmetic to it in
+ *  registers.  gy: gradient w.r.t. the consumer quantiser's output [M][ldg]; dy: gradient w.r.t. y [M][ldd] (may alias gy);
+ *  ds / db4 / dbaft: gradients of the consumer's step / pre-offset / post-offset (any may be NULL).  Quantiser geometry as
+ *  in ofq_qgemm_i8_nt_q (q_rowmul, q_coldiv, q_colmode); row mode needs M % (q_S / q_rowmul) == 0. */
+size_t ofq_qgemm_i8_lsq_bwd_ws_bytes(int64_t M, int64_t N, int q_colmode);
+int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, const float* col_scale, float col_mult,
+                         const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int64_t ldb, const float* gy, int64_t ldg, float* dy, int64_t ldd,
+                         const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
+                         int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, float* ds, float* db4, float* dbaft,
+                         void* ws, size_t ws_bytes, ofq_stream_t stream);
+
 /*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
  *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.
  *            K % 8 == 0, lda % 4 == 0, ldb % 8 == 0. */

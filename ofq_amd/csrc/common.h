@@ -55,6 +55,41 @@ __device__ __forceinline__ float ofq_lsq_level_exact(float x, float a, float lo,
   return rintf(fminf(fmaxf(ofq_div(x, a), lo), hi));
 }
 
+// One element of the LSQ backward (lsq.py:593-601 under autograd): v = xin / a, q = rint(clamp(v)),
+// dq = in_range ? (g * a) / a : 0 (the reference's own operation order), dsc = g * (in_range ? q - v : q).
+__device__ __forceinline__ void ofq_lsq_bwd_exact(float xin, float g, float a, float lo, float hi, float& dq, float& dsc) {
+  float q, v;
+  ofq_lsq_quant(xin, a, lo, hi, q, v);
+  const bool inr = (v >= lo) && (v <= hi);
+  dq = inr ? ofq_div(__fmul_rn(g, a), a) : 0.f;
+  dsc = g * (inr ? (q - v) : q);
+}
+// The same without the two IEEE division sequences (~11 instructions each).  `ra` is the correctly rounded 1 / a.
+//  * v' = xin * ra is within 1.5 ulp of fl(xin / a): the level q and the range decision are the exact ones unless the
+//    clamped product lies within `tol` of a half-integer / v' within `tol` of lo or hi -> `risky`, the caller redoes the
+//    group with ofq_lsq_bwd_exact.  (q - v') differs from (q - v) by <= 1.5 ulp(v): it only enters the step gradient, a
+//    sum over >= 10^4 elements compared at 1e-5.)
+//  * (g * a) / a: t = fl(g * a); q0 = fl(t * ra); two residual corrections q <- fma(fma(-a, q, t), ra, q) -- the tail of
+//    the hardware's own division expansion with an exact reciprocal in place of its refined estimate -- give the correctly
+//    rounded quotient whenever nothing under- or overflows; |t| outside [2^-100, 2^100] is flagged risky as well.
+__device__ __forceinline__ void ofq_lsq_bwd_fast(float xin, float g, float a, float ra, float lo, float hi, float half_m_tol,
+                                                 float tol, bool& risky, float& dq, float& dsc) {
+  const float v = __fmul_rn(xin, ra);
+  const float u = __builtin_amdgcn_fmed3f(v, lo, hi);
+  const float q = rintf(u);
+  const bool inr = (v >= lo) && (v <= hi);
+  risky |= !(fabsf(__fsub_rn(u, q)) < half_m_tol);
+  risky |= (fabsf(__fsub_rn(v, lo)) < tol) | (fabsf(__fsub_rn(v, hi)) < tol);
+  const float t = __fmul_rn(g, a);
+  float qq = __fmul_rn(t, ra);
+  qq = __fmaf_rn(__fmaf_rn(-a, qq, t), ra, qq);
+  qq = __fmaf_rn(__fmaf_rn(-a, qq, t), ra, qq);
+  const float at = fabsf(t);
+  risky |= (at != 0.f) & !((at > 7.8886090522e-31f) & (at < 1.2676506002e30f));
+  dq = inr ? qq : 0.f;
+  dsc = g * (inr ? (q - v) : q);
+}
+
 __device__ __forceinline__ float ofq_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

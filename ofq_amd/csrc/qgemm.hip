@@ -116,9 +116,10 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
     const float* ra_t = row_a + wm_s * 64 + 4 * lh;
     const float qlo = p.qlo, qhi = p.qhi;
     const float half_m_tol = 0.5f - ofq_lsq_level_tol(qlo, qhi);
-    auto tile = [&](auto QMODE_, auto QGELU_) {
+    auto tile = [&](auto QMODE_, auto QGELU_, auto STORE_) {
       constexpr int QMODE = decltype(QMODE_)::value;          // 0 none, 1 per-row step, 2 per-column step
       constexpr bool QGELU = decltype(QGELU_)::value;
+      constexpr bool STORE_Y = decltype(STORE_)::value;       // false: only the by-product codes leave the kernel
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -138,8 +139,10 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
               const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
               // scalar row base + 32-bit lane offset + immediate: no per-element address arithmetic on the VALU
 #ifndef I8X_NO_F32_STORE
-              if (j == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
-              else asm volatile("global_store_dword %0, %1, %2 offset:128" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+              if (STORE_Y) {
+                if (j == 0) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+                else asm volatile("global_store_dword %0, %1, %2 offset:128" ::"v"(lane_off4), "v"(yv), "s"(rowp));
+              }
 #else
               if (yv == 123.456f) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
 #endif
@@ -171,9 +174,16 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    if (!p.qout) tile(I0(), std::false_type());
-    else if (p.qcolmode) { if (p.qgelu) tile(I2(), std::true_type()); else tile(I2(), std::false_type()); }
-    else { if (p.qgelu) tile(I1(), std::true_type()); else tile(I1(), std::false_type()); }
+    using Y = std::true_type;
+    using N = std::false_type;
+    if (!p.qout) tile(I0(), N(), Y());
+    else if (p.C) {
+      if (p.qcolmode) { if (p.qgelu) tile(I2(), Y(), Y()); else tile(I2(), N(), Y()); }
+      else { if (p.qgelu) tile(I1(), Y(), Y()); else tile(I1(), N(), Y()); }
+    } else {
+      if (p.qcolmode) { if (p.qgelu) tile(I2(), Y(), N()); else tile(I2(), N(), N()); }
+      else { if (p.qgelu) tile(I1(), Y(), N()); else tile(I1(), N(), N()); }
+    }
 }
 
 #ifdef I8X_TIMING
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
         for (int j = 0; j < 2; ++j)
           if (ncol[j] < p.N) {
             const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
-            Cb[(int64_t)m * p.ldc + ncol[j]] = yv;
+            if (p.C) Cb[(int64_t)m * p.ldc + ncol[j]] = yv;
             if (p.qout) {
               const float xe = p.qgelu ? ofq_gelu(yv) : yv;
               float q, v;
@@ -473,6 +483,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
             Cb[(int64_t)m * p.ldc + ncol[j]] =
                 __fmul_rn(ap, __fadd_rn(__fmul_rn(av[j], (float)acc[i][j][e]), __fmul_rn(bv2[j], rpm)));
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ int8 recompute + LSQ backward
+// Backward of "linear layer -> input quantiser of its only consumer" without the saved activation: the forward GEMM
+// (ofq_qgemm_i8_nt_q with C = NULL) wrote only the consumer's int8 codes; here the fp32 layer output y is RECOMPUTED
+// from the same integer codes with the same k-loop and the same epilogue expression (bit-identical to what the forward
+// would have stored), and the consumer quantiser's backward (ofq_lsq_bwd's arithmetic, element for element) runs on it in
+// registers:   dy = d/dy [ LSQ([gelu](y) + b4; step) ],  plus the partials of d(step), d(b4), d(baft).
+// HBM traffic per element: 4 B read (gy) + 4 B written (dy), against 4 B written forward + 8 B read + 4 B written backward
+// for the stored-activation pair; the extra int8 GEMM (K = C) is free next to that.
+// QMODE 1: per-row step, index ((m * qrowmul + n / qcoldiv) % qS); QMODE 2: per-column step.
+// Partials: lrow[m][2 * tiles_n] (row mode: sum of dsc over each 64-column half tile), lcol[tiles_m][nacc][N].
+template <int QMODE, bool GELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qgemm_i8_lsqbwd_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
+  int tm, tn, gby;
+  qgemm_tile_id(p, tm, tn, gby);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const unsigned char* A = (const unsigned char*)p.A;
+  const unsigned char* B = (const unsigned char*)p.B;
+  float pre_ra, pre_rb = 1.f, pre_c[2][5];
+  int ncol[2];
+  {
+    const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
+    pre_ra = p.s[m % p.S];
+    if (QMODE == 1) pre_rb = p.qs[((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      ncol[j] = n0 + wn * 64 + j * 32 + l31;
+      const int nc = min(ncol[j], p.N - 1);
+      pre_c[j][0] = p.cs[nc];
+      pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
+      pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
+      pre_c[j][3] = (p.qb4 ? p.qb4 : p.cs)[nc];
+      pre_c[j][4] = (QMODE == 2 ? p.qs : p.cs)[nc];
+    }
+  }
+  // the incoming gradients of the first half of the wave tile are requested BEFORE the k-loop (32 registers ride through
+  // it), those of the second half right after it: the epilogue never waits for a cold HBM round trip
+  const float* G = p.lx;
+  const int ncl[2] = {min(ncol[0], p.N - 1), min(ncol[1], p.N - 1)};
+  const bool cok[2] = {ncol[0] < p.N, ncol[1] < p.N};
+  float g0[16][2], g1[16][2];
+  auto gload = [&](float (&g)[16][2], int i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = min(m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, p.M - 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) g[e][j] = G[(int64_t)m * p.ldlx + ncl[j]];
+    }
+  };
+  gload(g0, 0);
+  i32x16 acc[2][2];
+  i8_mainloop(p, A, B, m0, n0, smem, acc);
+  gload(g1, 1);
+
+  float* row_a = reinterpret_cast<float*>(&smem[0][0]);       // [128] effective input step of the row
+  float* row_b = row_a + BM;                                  // [128] effective step of the consumer quantiser (row mode)
+  float* row_c = row_a + 2 * BM;                              // [128] its correctly rounded reciprocal
+  float* colred = row_a + 3 * BM;                             // [2 wm][3 acc][128] column partials
+  if (tid < BM) {
+    row_a[tid] = ofq_lsq_eff_scale(pre_ra, p.gscale);
+    const float rb = ofq_lsq_eff_scale(pre_rb, p.qgscale);
+    row_b[tid] = rb;
+    row_c[tid] = __fdiv_rn(1.f, rb);
+  }
+  __syncthreads();
+  float csn[2], rn[2], bz[2], qb[2], qsc[2], qrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    csn[j] = pre_c[j][0] * p.alpha;
+    rn[j] = p.r ? pre_c[j][1] : 0.f;
+    bz[j] = p.bias ? pre_c[j][2] : 0.f;
+    qb[j] = p.qb4 ? pre_c[j][3] : 0.f;
+    qsc[j] = QMODE == 2 ? ofq_lsq_eff_scale(pre_c[j][4], p.qgscale) : 1.f;
+    qrc[j] = QMODE == 2 ? __fdiv_rn(1.f, qsc[j]) : 1.f;
+  }
+  const float lo = p.qlo, hi = p.qhi;
+  const float tol = ofq_lsq_level_tol(lo, hi);
+  const float half_m_tol = 0.5f - tol;
+  float cb4[2] = {0.f, 0.f}, cba[2] = {0.f, 0.f}, cds[2] = {0.f, 0.f};
+  float rds[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) rds[k] = 0.f;
+  auto half = [&](const float (&g)[16][2], auto I_) {
+    constexpr int i = decltype(I_)::value;
+#pragma unroll
+    for (int eg = 0; eg < 4; ++eg) {
+      // 4 rows x 2 columns share one exactness check (see ofq_lsq_bwd_fast): a wave that raises it redoes the group with
+      // the IEEE division sequences, so every value equals ofq_lsq_bwd's bit for bit
+      float yv[4][2], xin[4][2], gev[4][2], alv[4][2], dq[4][2], dsc[4][2];
+      bool risky = false;
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int e = eg * 4 + ee;
+        const int mr = wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
+        const bool mok = (m0 + mr) < p.M;
+        const float ae = row_a[mr];
+        const float alr = row_b[mr], rar = row_c[mr];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          yv[ee][j] = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+          xin[ee][j] = __fadd_rn(GELU ? ofq_gelu(yv[ee][j]) : yv[ee][j], qb[j]);
+          gev[ee][j] = (mok && cok[j]) ? g[e][j] : 0.f;
+          alv[ee][j] = QMODE == 2 ? qsc[j] : alr;
+          ofq_lsq_bwd_fast(xin[ee][j], gev[ee][j], alv[ee][j], QMODE == 2 ? qrc[j] : rar, lo, hi, half_m_tol, tol, risky,
+                           dq[ee][j], dsc[ee][j]);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ofq_lsq_bwd_exact(xin[ee][j], gev[ee][j], alv[ee][j], lo, hi, dq[ee][j], dsc[ee][j]);
+      }
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        const int e = eg * 4 + ee;
+        const int m = m0 + wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          cb4[j] += dq[ee][j];
+          cba[j] += gev[ee][j];
+          if (QMODE == 2) cds[j] += dsc[ee][j]; else rds[i * 16 + e] += dsc[ee][j];
+          const float dy = GELU ? dq[ee][j] * ofq_gelu_grad(yv[ee][j]) : dq[ee][j];
+          if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
+        }
+      }
+    }
+  };
+  half(g0, std::integral_constant<int, 0>());
+  half(g1, std::integral_constant<int, 1>());
+  // ---- row partials (row mode): sum over the 32 lanes that hold the columns of one row; transpose-reduce, 31 exchanges:
+  // after the step with mask w a lane keeps the half of its slots selected by its bit w, so lane l31 ends with slot l31
+  if (QMODE == 1) {
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+      const bool up = (l31 & w) != 0;
+#pragma unroll
+      for (int k = 0; k < w; ++k) {
+        const float send = up ? rds[k] : rds[k + w];
+        const float keep = up ? rds[k + w] : rds[k];
+        rds[k] = keep + __shfl_xor(send, w, 64);
+      }
+    }
+    const int e = l31 & 15, i = l31 >> 4;
+    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    if (m < p.M) p.lrow[(int64_t)m * (2 * p.tiles_n) + 2 * tn + wn] = rds[0];
+  }
+  // ---- column partials: lane pair (lh) -> wave pair (wm) through LDS -> lcol[tm][acc][n]
+  constexpr int NACC = QMODE == 2 ? 3 : 2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    cb4[j] += __shfl_xor(cb4[j], 32, 64);
+    cba[j] += __shfl_xor(cba[j], 32, 64);
+    if (QMODE == 2) cds[j] += __shfl_xor(cds[j], 32, 64);
+    if (lh == 0) {
+      const int c = wn * 64 + j * 32 + l31;
+      colred[(wm * 3 + 0) * BN + c] = cb4[j];
+      colred[(wm * 3 + 1) * BN + c] = cba[j];
+      if (QMODE == 2) colred[(wm * 3 + 2) * BN + c] = cds[j];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NACC * BN; idx += 256) {
+    const int c = idx % BN, ac = idx / BN;
+    if (n0 + c < p.N)
+      p.lcol[((int64_t)tm * NACC + ac) * p.N + n0 + c] = colred[ac * BN + c] + colred[(3 + ac) * BN + c];
   }
 }
 
@@ -1848,7 +2031,7 @@ static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const flo
                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qout, int64_t ldq, const float* q_s,
                            int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi, int q_gelu, int q_rowmul,
                            int64_t q_coldiv, int q_colmode, ofq_stream_t stream) {
-  if (!A || !B || !C || !col_scale || !lsq_s || M <= 0 || N <= 0 || K <= 0 || S <= 0) return OFQ_EINVAL;
+  if (!A || !B || (!C && !qout) || !col_scale || !lsq_s || M <= 0 || N <= 0 || K <= 0 || S <= 0) return OFQ_EINVAL;
   if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30)) return OFQ_EINVAL;
   if (qout && (!q_s || q_S <= 0 || (N & 15) || (ldq & 15) || ldq < N || !al16(qout) || q_lo < -128 || q_hi > 255 || q_rowmul < 1 ||
                q_coldiv < 1 || (q_rowmul > 1 && (q_coldiv % 128 || q_rowmul * q_coldiv != N)) || (q_colmode && q_S != N)))
@@ -1881,6 +2064,73 @@ extern "C" int ofq_qgemm_i8_nt_q(const int8_t* A, const int8_t* B, float* C, con
   if (!qcodes) return OFQ_EINVAL;
   return qgemm_i8_linear(A, B, C, bias, col_scale, col_mult, r, lsq_s, S, gscale, M, N, K, lda, ldb, ldc, qcodes, ldq, q_s, q_S,
                          q_gscale, q_b4, q_lo, q_hi, q_gelu, q_rowmul, q_coldiv, q_colmode, stream);
+}
+
+static void i8_lsqbwd_ws(int64_t M, int64_t N, int colmode, size_t* rowf, size_t* colf) {
+  const int64_t tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
+  *rowf = colmode ? 0 : (size_t)M * 2 * tiles_n;
+  *colf = (size_t)tiles_m * (colmode ? 3 : 2) * N;
+}
+extern "C" size_t ofq_qgemm_i8_lsq_bwd_ws_bytes(int64_t M, int64_t N, int q_colmode) {
+  if (M <= 0 || N <= 0) return 0;
+  size_t rf, cf;
+  i8_lsqbwd_ws(M, N, q_colmode, &rf, &cf);
+  return (rf + cf) * sizeof(float) + 256;
+}
+
+extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, const float* col_scale, float col_mult,
+                                    const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N, int64_t K,
+                                    int64_t lda, int64_t ldb, const float* gy, int64_t ldg, float* dy, int64_t ldd,
+                                    const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
+                                    int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, float* ds, float* db4, float* dbaft,
+                                    void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  if (!A || !B || !col_scale || !lsq_s || !gy || !dy || !q_s || !ws || M <= 0 || N <= 0 || K <= 0 || S <= 0 || q_S <= 0)
+    return OFQ_EINVAL;
+  if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30) || ldg < N || ldd < N)
+    return OFQ_EINVAL;
+  if (q_rowmul < 1 || q_coldiv < 1 || (q_rowmul > 1 && (q_coldiv % 128 || q_rowmul * q_coldiv != N)) || (q_colmode && q_S != N))
+    return OFQ_EINVAL;
+  const int64_t T = q_colmode ? 1 : q_S / q_rowmul;          // quantiser rows per batch element (tokens)
+  if (!q_colmode && (T * q_rowmul != q_S || M % T)) return OFQ_EINVAL;
+  size_t rf, cf;
+  i8_lsqbwd_ws(M, N, q_colmode, &rf, &cf);
+  if (ws_bytes < (rf + cf) * sizeof(float)) return OFQ_ENOWS;
+  QGemmArgs a = {};
+  a.A = A; a.B = B; a.C = dy; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldd; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4; a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu;
+  a.qrowmul = q_rowmul; a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
+  a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
+  if (q_colmode) {
+    if (q_gelu) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<2, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<2, false>), grid, block, 0, st, a);
+  } else {
+    if (q_gelu) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<1, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<1, false>), grid, block, 0, st, a);
+  }
+  OFQ_LAUNCH_CHECK();
+  // second stage (fixed order, no atomics): ds over batches and half tiles / over row tiles; db4, dbaft over row tiles
+  const int nacc = q_colmode ? 3 : 2;
+  SumJobs jobs = {};
+  int64_t maxc = 0;
+  if (ds) {
+    if (q_colmode) jobs.j[0] = {a.lcol + 2 * N, ds, N, a.tiles_m, nacc * N, 1, q_gscale, 0, 0};
+    else {
+      const int64_t nparts = 2 * (int64_t)a.tiles_n, pph = nparts / q_rowmul;
+      jobs.j[0] = {a.lrow, ds, q_S, M / T, T * nparts, (int)pph, q_gscale, q_rowmul, nparts};
+    }
+    maxc = jobs.j[0].ncols;
+  }
+  if (db4) { jobs.j[1] = {a.lcol, db4, N, a.tiles_m, nacc * N, 1, 1.0f, 0, 0}; if (N > maxc) maxc = N; }
+  if (dbaft) { jobs.j[2] = {a.lcol + N, dbaft, N, a.tiles_m, nacc * N, 1, 1.0f, 0, 0}; if (N > maxc) maxc = N; }
+  if (maxc > 0) {
+    strided_sum_launch(jobs, maxc, 3, st);
+    OFQ_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 // Wide input-gradient kernel for the linear layers: 8 waves own a 128 x (128*NJ) tile of dX, so a row panel of dY is

@@ -76,8 +76,18 @@ class CodesLinearFn(torch.autograd.Function):
         r = aux.get("r")
         if r is None and aux["baft"] is not None:
             r = ops.rowdot_i8(aux["wcodes"], aux["baft"])
+        fuse = aux.get("fuse")
+        # the consumer of this output is a quantiser applied right here (fuse) that asked not to keep the fp32 values
+        # (store_y False): only its codes are written; its backward recomputes the output from the codes
+        store_y = not (fuse is not None and fuse.get("store_y") is False)
         y = ops.qgemm_i8_nt(aux["xcodes"].view(-1, K), aux["wcodes"], bias, aux["w_scale"], aux["w_mult"], r,
-                            aux["act_s"], aux["act_S"], aux["act_gscale"], fuse=aux.get("fuse"))
+                            aux["act_s"], aux["act_S"], aux["act_gscale"], fuse=fuse, store_y=store_y)
+        if not store_y:
+            fuse["producer"] = {"xcodes": aux["xcodes"].view(-1, K), "wcodes": aux["wcodes"],
+                                "bias": None if bias is None else bias.detach(), "w_scale": aux["w_scale"],
+                                "w_mult": aux["w_mult"], "r": r, "act_s": aux["act_s"], "act_S": aux["act_S"],
+                                "act_gscale": aux["act_gscale"]}
+            y = ops.placeholder((x2d.shape[0], Wq.shape[0]), xq.device)
         ctx.codes_only = xq.stride(-1) == 0           # x_hat exists only as codes (placeholder carrier tensor)
         ctx.save_for_backward(*(() if ctx.codes_only else (x2d,)))
         ctx.aux = aux

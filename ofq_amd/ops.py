@@ -326,13 +326,16 @@ def rowdot_i8(codes, vec):
     return out
 
 
-def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, fuse=None):
+def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, fuse=None, store_y=True):
     """y = col_mult*col_scale[n]*(a_eff[m % S]*(xcodes @ wcodes^T) + r[n]) + bias[n]
     fuse (optional): LsqGeom-like description of the next layer's input quantiser {s, S, gscale, b4, lo, hi, gelu};
-    the kernel then also emits that quantiser's int8 codes of y into fuse["codes_out"]."""
+    the kernel then also emits that quantiser's int8 codes of y into fuse["codes_out"].
+    store_y=False (needs fuse): only the codes are written; returns None (the backward recomputes y, qgemm_i8_lsq_bwd)."""
     M, K = xcodes.shape
     N = wcodes.shape[0]
-    y = torch.empty((M, N), dtype=torch.float32, device=xcodes.device)
+    if not store_y and fuse is None:
+        raise RuntimeError("ofq_amd: qgemm_i8_nt(store_y=False) needs a fused consumer quantiser")
+    y = torch.empty((M, N), dtype=torch.float32, device=xcodes.device) if store_y else None
     with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * M * N * K):
         if fuse is None:
             _chk(lib().ofq_qgemm_i8_nt(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
@@ -340,7 +343,7 @@ def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, 
                                        wcodes.stride(0), N, _stream()), "ofq_qgemm_i8_nt")
         else:
             qc = torch.empty((M, N), dtype=torch.int8, device=xcodes.device)
-            _chk(lib().ofq_qgemm_i8_nt_q(xcodes.data_ptr(), wcodes.data_ptr(), y.data_ptr(), _p(bias), col_scale.data_ptr(),
+            _chk(lib().ofq_qgemm_i8_nt_q(xcodes.data_ptr(), wcodes.data_ptr(), _p(y), _p(bias), col_scale.data_ptr(),
                                          col_mult, _p(r), lsq_s.data_ptr(), S, gscale, M, N, K, xcodes.stride(0),
                                          wcodes.stride(0), N, qc.data_ptr(), N, fuse["s"].data_ptr(), fuse["S"],
                                          fuse["gscale"], _p(fuse["b4"]), fuse["lo"], fuse["hi"], int(fuse["gelu"]),
@@ -348,6 +351,35 @@ def qgemm_i8_nt(xcodes, wcodes, bias, col_scale, col_mult, r, lsq_s, S, gscale, 
                                          _stream()), "ofq_qgemm_i8_nt_q")
             fuse["codes_out"] = qc
     return y
+
+
+def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
+    """Backward of [linear layer -> its consumer's input quantiser] with the layer output recomputed from the codes.
+    prod: the producing GEMM's operands {xcodes (M,K) int8, wcodes (N,K) int8, bias, w_scale, w_mult, r, act_s, act_S,
+    act_gscale}; q: the consumer quantiser as handed to qgemm_i8_nt's `fuse` {s, S, gscale, b4, lo, hi, gelu, rowmul,
+    coldiv, colmode}.  Returns (dy (M,N): gradient w.r.t. the layer output, ds, db4, dbaft) like lsq_bwd."""
+    xc, wc = prod["xcodes"], prod["wcodes"]
+    M, K = xc.shape
+    N = wc.shape[0]
+    dev = gy2d.device
+    if gy2d.shape != (M, N) or gy2d.stride(1) != 1:
+        raise RuntimeError("ofq_amd: qgemm_i8_lsq_bwd: gradient of shape %s for a %dx%d layer output" % (tuple(gy2d.shape), M, N))
+    dy = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ds = torch.empty_like(q["s"])
+    has_bias = q["b4"] is not None and want_bias_grads
+    db4 = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
+    dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
+    colmode = int(q.get("colmode", 0))
+    ws = workspace(lib().ofq_qgemm_i8_lsq_bwd_ws_bytes(M, N, colmode), dev)
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * M * N * K):
+        _chk(lib().ofq_qgemm_i8_lsq_bwd(xc.data_ptr(), wc.data_ptr(), _p(prod["bias"]), prod["w_scale"].data_ptr(),
+                                        prod["w_mult"], _p(prod["r"]), prod["act_s"].data_ptr(), prod["act_S"],
+                                        prod["act_gscale"], M, N, K, xc.stride(0), wc.stride(0), gy2d.data_ptr(),
+                                        gy2d.stride(0), dy.data_ptr(), N, q["s"].data_ptr(), q["S"], q["gscale"], _p(q["b4"]),
+                                        q["lo"], q["hi"], int(q["gelu"]), int(q.get("rowmul", 1)), int(q.get("coldiv", N)),
+                                        colmode, ds.data_ptr(), _p(db4), _p(dbaft), ws.data_ptr(), ws.numel(), _stream()),
+             "ofq_qgemm_i8_lsq_bwd")
+    return dy, ds, db4, dbaft
 
 
 def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3):

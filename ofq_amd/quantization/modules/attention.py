@@ -206,6 +206,11 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
             fuse_ok = attn_codes and _ql.FUSE_NEXT_CODES
             vspec = self.quan_a_v_fn.fusable((B, N, C), self.move_v_b4.bias, 0) if fuse_ok else None
             qspec = self.quan_a_qkx_fn.fusable((B, N * H, C), self.move_qkx_b4.bias, 0) if fuse_ok else None
+            # v / qkx leave their GEMMs as codes only where qlinear.RECOMPUTE_SITES says so (backward recomputes them)
+            if vspec is not None and "v" in _ql.RECOMPUTE_SITES:
+                vspec["store_y"] = False
+            if qspec is not None and "qkx" in _ql.RECOMPUTE_SITES:
+                qspec["store_y"] = False
             # x_hat has three consumers (v GEMM, W_qk GEMM, scores): their backward passes accumulate into one buffer
             xacc = {} if (attn_codes and torch.is_grad_enabled()) else None
             v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
@@ -216,7 +221,7 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
         if attn_codes:
             v, vcodes, vgeom = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias, want_codes=True,
                                                       need_values=False,
-                                                      pre_codes=None if vspec is None else vspec.get("codes_out"))
+                                                      pre_codes=None if vspec is None else vspec.get("codes_out"), fused=vspec)
         else:
             v = self.quan_a_v_fn.quant(v, self.move_v_b4.bias, self.move_v_aft.bias)
         # ---- QK branch (:190-207): W_qk = per-head W_q^T W_k, StatsQ over its H*C rows
@@ -238,7 +243,8 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
             qkx, qcodes, qgeom = self.quan_a_qkx_fn.quant(qkx, self.move_qkx_b4.bias, self.move_qkx_aft.bias,
                                                           shape=(B, N * H, C), out_shape=(B, N, H, C), want_codes=True,
                                                           need_values=False,
-                                                          pre_codes=None if qspec is None else qspec.get("codes_out"))
+                                                          pre_codes=None if qspec is None else qspec.get("codes_out"),
+                                                          fused=qspec)
             link = {}
             S = QKRScoresCodesFn.apply(xq, qkx, {
                 "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,

@@ -28,6 +28,13 @@ FUSE_NEXT_CODES_MLP = os.environ.get("OFQ_NO_EPILOGUE_FUSE_MLP") is None
 FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None
 # LayerNorm + the per-token LSQ of its single consumer in one kernel each way (A/B switch: OFQ_NO_NORM_QUANT_FUSE=1)
 FUSE_NORM_QUANT = os.environ.get("OFQ_NO_NORM_QUANT_FUSE") is None
+# A GEMM whose epilogue applies its only consumer's quantiser writes that quantiser's codes and nothing else; the
+# quantiser's backward recomputes the fp32 layer output from the integer operands (ofq_qgemm_i8_lsq_bwd) instead of
+# reading a saved copy: -8 B/element of HBM traffic.  Sites: "qkx" (H*C wide, the largest activation of a QKR block),
+# "fc1" (GELU in front of fc2's quantiser), "v".  Measured on MI355X the recompute kernel wins for qkx only (its
+# epilogue is the consumer's whole backward at two waves per SIMD; the GELU variant loses to the HBM-bound elementwise
+# kernel), so that is the default.  OFQ_RECOMPUTE=qkx,fc1,v / OFQ_RECOMPUTE= (none) select others.
+RECOMPUTE_SITES = frozenset(x for x in os.environ.get("OFQ_RECOMPUTE", "qkx").split(",") if x)
 
 
 class LSQ_input(nn.Module):
@@ -92,7 +99,7 @@ class QLinear(nn.Linear):
             return None
         return {"quant": self.input_quant_fn, "b4": self.move_b4.bias, "baft": self.move_aft.bias}
 
-    def forward(self, input, fuse_next=None, pre_codes=None, pre_quant=None):
+    def forward(self, input, fuse_next=None, pre_codes=None, pre_quant=None, fused=None):
         """fuse_next: input_fuse_spec() of the layer consuming this output (its codes come back in fuse_next["codes_out"]);
         pre_codes: this layer's own input codes when a producer already computed them;
         pre_quant: (x_hat carrier, codes, geom) when the producer ran this layer's whole input quantiser (norm_quant)."""
@@ -108,7 +115,7 @@ class QLinear(nn.Linear):
             xq, xcodes, geom = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias,
                                                          prologue=self._prologue, want_codes=True,
                                                          need_values=not codes_only_ok(self.in_features, self.out_features),
-                                                         pre_codes=pre_codes, link=link)
+                                                         pre_codes=pre_codes, link=link, fused=fused)
             return codes_linear(xq, xcodes, geom, self.input_quant_fn, self.move_aft.bias, self.weight,
                                 self.statsq_fn, self.bias, fuse=fuse_next, lsq_link=link)
         weight = self.statsq_fn(self.weight)                                     # qlinear.py:62
@@ -154,8 +161,10 @@ class QMLP(Mlp):
         if FUSE_NEXT_CODES and FUSE_NEXT_CODES_MLP and self._fuse_gelu and self.fc1.code_path():
             # fc1's GEMM epilogue also applies GELU + fc2's offset and LSQ, so fc2 never re-reads the fp32 activation
             spec = self.fc2.input_fuse_spec(tuple(x.shape[:-1]) + (self.fc1.out_features,))
+            if spec is not None and "fc1" in RECOMPUTE_SITES and not FUSE_LSQ_BWD:
+                spec["store_y"] = False
             h = self.fc1(x, fuse_next=spec, pre_quant=pre_quant)
-            x = self.fc2(h, pre_codes=None if spec is None else spec.get("codes_out"))
+            x = self.fc2(h, pre_codes=None if spec is None else spec.get("codes_out"), fused=spec)
             return self.drop2(x)
         x = self.fc1(x, pre_quant=pre_quant)
         if not self._fuse_gelu:

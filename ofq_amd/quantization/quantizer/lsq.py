@@ -26,10 +26,13 @@ class _LsqFn(torch.autograd.Function):
     """y = LSQ(pre(x) + b4) + baft with the closed-form backward."""
 
     @staticmethod
-    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True, pre_codes=None, link=None):
+    def forward(ctx, x, s, b4, baft, geom, want_codes, need_values=True, pre_codes=None, link=None, fused=None):
         # link: dict shared with the single consumer of the codes (CodesLinearFn); when its backward fuses this
         # quantiser's backward into the dX GEMM epilogue it leaves the four gradients in link["done"]
+        # fused: the spec this quantiser handed to the GEMM that produces x (fusable()); when that GEMM did not store x
+        # (fused["producer"] present, x is a placeholder) the backward recomputes x from the producer's integer operands
         ctx.link = link
+        ctx.fused = fused if (fused is not None and pre_codes is not None and "producer" in fused) else None
         if link is not None:
             link.update(x=x, s=s, b4=b4, geom=geom)
         if pre_codes is not None:
@@ -52,16 +55,21 @@ class _LsqFn(torch.autograd.Function):
         if ctx.link is not None and "done" in ctx.link:
             dx, ds, db4, dbaft = ctx.link.pop("done")
             ctx.link.clear()
-            return dx, ds, db4, dbaft, None, None, None, None, None
+            return dx, ds, db4, dbaft, None, None, None, None, None, None
         if ctx.link is not None:
             ctx.link.clear()
         if gy is None:
-            return None, None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None
         x, s, b4 = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
+        if ctx.fused is not None:
+            q = ctx.fused
+            n_out = q["producer"]["wcodes"].shape[0]
+            dx, ds, db4, dbaft = ops.qgemm_i8_lsq_bwd(gy.view(-1, n_out), q["producer"], q)
+            return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None, None
         dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
-        return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None
+        return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None, None
 
 
 class _LsqBase(nn.Module):
@@ -114,13 +122,16 @@ class _LsqBase(nn.Module):
         return spec
 
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
-              want_codes=False, need_values=True, pre_codes=None, link=None):
+              want_codes=False, need_values=True, pre_codes=None, link=None, fused=None):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
         is a strided column slice)."""
         if not x.is_cuda:
             raise RuntimeError("ofq_amd LSQ: input must be on a HIP device; there is no CPU fallback")
-        if ldx is None:
+        carrier = x.dim() > 0 and x.stride(-1) == 0          # zero-stride placeholder: the values only exist as codes
+        if ldx is None and not carrier:
             x = x.contiguous()
+        if carrier and (pre_codes is None or need_values):
+            raise RuntimeError("ofq_amd LSQ: input is a code-only placeholder but its values are needed")
         shp = tuple(shape) if shape is not None else tuple(x.shape)
         if not self.initialized_alpha or self.s is None:
             xin = x.detach().reshape(shp) if ldx is None else x.detach()
@@ -135,7 +146,9 @@ class _LsqBase(nn.Module):
         if link is not None and (need_values or not want_codes or geom.mode != 0 or geom.bias_len not in (0, geom.inner)
                                  or geom.inner <= 128 or ldx is not None or not torch.is_grad_enabled()):
             link = None                       # the fused backward needs codes-only output, per-token step, one offset phase
-        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values, pre_codes, link)
+        if fused is not None and "producer" in fused and pre_codes is None:
+            raise RuntimeError("ofq_amd LSQ: the producing GEMM kept no fp32 output, but its codes are not used")
+        y, codes = _LsqFn.apply(x, self.s, b4, baft, geom, want_codes, need_values, pre_codes, link, fused)
         y = y.view(out_shape if out_shape is not None else shp)
         if want_codes:
             return y, codes, geom

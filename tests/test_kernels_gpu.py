@@ -724,3 +724,64 @@ def test_qattn_dxq_wide_kernel_vs_fp64(ops, N):
     base = T(rs.randn(B, N, C).astype(np.float32))
     dxq2 = ops.qattn_dxq(cu(dS), cu(qcodes), cu(sq), gq, B, H, N, C, Np, out=base.clone().cuda(), accumulate=True)
     assert rel_err(dxq2.cpu(), (ref + base.double()).float()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (M, N, K, S, mode, rowmul, gelu, lo, hi)
+    ("row", 2 * 198, 384, 64, 198, 0, 1, 0, -2, 1),            # proj/fc1-like, per-token step
+    ("row_gelu", 3 * 50, 256, 48, 50, 0, 1, 1, 0, 3),          # fc1 -> fc2's unsigned quantiser behind the GELU; ragged M
+    ("heads", 2 * 70, 3 * 128, 32, 70, 0, 3, 0, -4, 3),        # qkx-like: 3 heads side by side, step per (token, head)
+    ("col", 2 * 198, 192, 64, 198, 1, 1, 0, -2, 1),            # v-like: per-channel step; N not a multiple of 128
+    ("row_wide_range", 16 * 256, 512, 32, 256, 0, 1, 0, -8, 7),  # 2M elements, gradients over 9 decades: the division
+    ("col_wide_range", 16 * 256, 256, 32, 256, 1, 1, 0, -2, 1),  # shortcut (ofq_lsq_bwd_fast) against the IEEE sequence
+])
+def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
+    """ofq_qgemm_i8_lsq_bwd (layer output recomputed from the integer codes, consumer quantiser's backward in registers)
+    against the pair it replaces: ofq_qgemm_i8_nt storing y, then ofq_lsq_bwd on the stored y (qlinear.py:58-73 +
+    lsq.py:571-602).  The codes-only forward must emit the same codes; dy bit for bit (same expression on the same
+    values); the reduced gradients to 1e-5 (different summation order)."""
+    name, M, N, K, S, colmode, rowmul, gelu, lo, hi = case
+    g = torch.Generator(device="cuda").manual_seed(len(name) * 7 + M)
+    xc = torch.randint(-2, 2, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    wc = (2 * torch.randint(-2, 2, (N, K), device="cuda", generator=g) + 1).to(torch.int8)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    cs = torch.rand(N, device="cuda", generator=g) * 0.05 + 0.01
+    r = torch.randn(N, device="cuda", generator=g) * 0.3
+    s_in = torch.rand(S, device="cuda", generator=g) * 0.3 + 0.05
+    gscale_in = 0.013
+    T_tok = S
+    coldiv = N // rowmul
+    if colmode:
+        qs = torch.rand(N, device="cuda", generator=g) * 0.3 + 0.1
+        qS = N
+    else:
+        qs = torch.rand(T_tok * rowmul, device="cuda", generator=g) * 0.3 + 0.1
+        qS = T_tok * rowmul
+    qb4 = torch.randn(N, device="cuda", generator=g) * 0.05
+    qg = 0.021
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    if "wide_range" in name:
+        gy = gy * torch.pow(10.0, torch.randint(-6, 4, (M, N), device="cuda", generator=g).float())
+
+    def spec():
+        return dict(s=qs, S=qS, gscale=qg, b4=qb4, lo=lo, hi=hi, gelu=gelu, rowmul=rowmul, coldiv=coldiv, colmode=colmode)
+    f1 = spec()
+    y = ops.qgemm_i8_nt(xc, wc, bias, cs, 0.25, r, s_in, S, gscale_in, fuse=f1)
+    f2 = spec()
+    none = ops.qgemm_i8_nt(xc, wc, bias, cs, 0.25, r, s_in, S, gscale_in, fuse=f2, store_y=False)
+    assert none is None and torch.equal(f1["codes_out"], f2["codes_out"])
+    # the pair being replaced: LSQ backward on the stored y, quantiser rows = GEMM rows x heads
+    geom = ops.LsqGeom(M * rowmul if not colmode else M, 1, coldiv if not colmode else N, N if not colmode else N,
+                       colmode, lo, hi, 1, prologue=gelu)
+    if not colmode:
+        geom = ops.LsqGeom(M // T_tok, T_tok * rowmul, coldiv, N, 0, lo, hi, 1, prologue=gelu)
+    geom.gscale = qg
+    dx_ref, ds_ref, db4_ref, dba_ref = ops.lsq_bwd(gy, y.view(-1, geom.inner), qs, qb4, geom)
+    prod = {"xcodes": xc, "wcodes": wc, "bias": bias, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": s_in, "act_S": S,
+            "act_gscale": gscale_in}
+    dy, ds, db4, dba = ops.qgemm_i8_lsq_bwd(gy, prod, f2)
+    assert torch.equal(dy, dx_ref.view(M, N))
+    assert rel_err(ds, ds_ref) < 1e-5 and rel_err(db4, db4_ref) < 1e-5 and rel_err(dba, dba_ref) < 1e-5
+    # not everything was clipped (the pass-through branch of the straight-through estimator ran)
+    assert float((dy == 0).float().mean()) < 0.98
