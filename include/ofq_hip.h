@@ -195,6 +195,19 @@ int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t row
 int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, const float* sx, float gscale_x,
                         const float* sq, float gscale_q, const float* u, const float* tq, const float* z, int64_t B,
                         int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+
+/*  Plain (non-reparameterised) attention on the codes, attention.py:67-105: q_hat = aq[n]*qq + bq[c], k_hat = ak[m]*qk + bk[c]
+ *  (per-token steps sq / sk [N], per-channel offsets), S[b][h][n][m] = q_hat[b,n,hd:hd+d] . k_hat[b,m,hd:hd+d] =
+ *  aq[n]*(ak[m]*I + u[b,n,h]) + ak[m]*tq[b,m,h] + z[h]; qcodes / kcodes [B][N][H*d], u / tq [B][N][H], z [H].
+ *  Backward of the scores: dq[b,n,hd+c] = sum_m (dS*ak[m])*qk, dk[b,m,hd+c] = sum_n dS*(aq[n]*qq + bq[hd+c]). */
+int ofq_qattn_scores_plain_i8(const int8_t* qcodes, const int8_t* kcodes, float* S, const float* sq, float gscale_q,
+                              const float* sk, float gscale_k, const float* u, const float* tq, const float* z,
+                              int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream);
+int ofq_qattn_dq_plain_bf16s(const float* dS, const int8_t* kcodes, float* dq, const float* sk, float gscale_k,
+                             int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream);
+int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, float* dk, const float* sq, float gscale_q,
+                             const float* bq, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream);
+
 int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, float* O, const float* sp, float gscale_p,
                     const float* sv, float gscale_v, const float* bav, const float* rp, int64_t B, int64_t H, int64_t N,
                     int64_t d, int64_t Np, ofq_stream_t stream);

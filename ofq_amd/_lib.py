@@ -55,6 +55,9 @@ SIGNATURES = {
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_scores_plain_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dq_plain_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dk_plain_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_pv_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),

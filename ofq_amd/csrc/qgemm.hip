@@ -43,6 +43,7 @@ struct QGemmArgs {
   int64_t sA0, sA1, sB0, sB1, sC0, sC1;   // batch strides (elements)
   int64_t sK1;           // bf16s: offset of the k-scale vector per inner batch index b1
   int M, N, K, S, nb1;
+  int s2s0, s2s1;        // scores: the column step is s2[n * s2s0 + b1 * s2s1] (QKR: one per (token, head); plain: per token)
   int tiles_m, tiles_n, accumulate, b_is_i8;
   float gscale, gscale2, alpha;
   // i8 linear, optional by-product: the int8 codes of the NEXT layer's input quantiser applied to this output,
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int nc = min(ncol[j], p.N - 1);
-      aq[j] = ofq_lsq_eff_scale(p.s2[nc * p.nb1 + b1], p.gscale2);
+      aq[j] = ofq_lsq_eff_scale(p.s2[nc * p.s2s0 + b1 * p.s2s1], p.gscale2);
       tqa[j] = __fadd_rn(__fmul_rn(aq[j], p.tq[((int64_t)b0 * p.N + nc) * p.nb1 + b1]), zz);
     }
 #pragma unroll
@@ -978,7 +979,8 @@ struct QTnArgs {
   const float* s;        // LSQ step vector [S]
   // direct (batched, un-split) mode: C written by the GEMM kernel itself
   float* C;              // NULL = split-K mode
-  const float* baft;     // direct mode: + colsum_k(A)[m] * baft[n]
+  const float* baft;     // direct mode: + colsum_k(A)[m] * baft[n + b1 * sBf1]
+  int64_t sBf1;          // (plain attention: the offset vector of head b1 starts at b1 * d)
   int64_t lda, ldb, ldc;
   int64_t sA0, sA1, sB0, sB1, sC0, sC1;
   int M, N, Ktok, S, split, tiles_m, tiles_n, nb1, Mstore, Nstore, trans_out;
@@ -1175,7 +1177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + l31;
       if (n >= p.Nstore) continue;
-      const float bf = p.baft ? p.baft[n] : 0.f;
+      const float bf = p.baft ? p.baft[n + b1 * p.sBf1] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1598,7 +1600,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
     for (int j = 0; j < NJ; ++j) {
       const int n = n0 + wn * 32 * NJ + j * 32 + l31;
       if (n >= p.Nstore) continue;
-      const float bf = p.baft ? p.baft[n] : 0.f;
+      const float bf = p.baft ? p.baft[n + b1 * p.sBf1] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1774,6 +1776,8 @@ struct QNnArgs {
   int64_t lda, ldb, ldc, sA0, sB0, sC0, sAk, sBk;
   int M, N, K, nkb, ks_stride, tiles_m, tiles_n, accumulate;
   float gscale;
+  int64_t sA1, sB1, sC1;  // inner batch (grid.y = batches * nb1): plain attention runs one head per batch entry
+  int nb1;                // 0 / 1: no inner batch
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_nn_kernel(QNnArgs p) {
@@ -1781,15 +1785,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   constexpr int PLANE_A = BM * QBS_LD;              // [row][k] bf16, 80 B rows
   constexpr int PLANE_B = QTN_BK * QTN_LD;          // [k][c]  bf16, 320 B rows
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + PLANE_B];
-  int tile, b0;
-  xcd_remap_grid(tile, b0);
+  int tile, gby;
+  xcd_remap_grid(tile, gby);
+  const int nb1 = p.nb1 > 1 ? p.nb1 : 1;
+  const int b0 = gby / nb1, b1 = gby % nb1;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const float* Ab = p.A + b0 * p.sA0;
-  const int8_t* Bb = p.B + b0 * p.sB0;
+  const float* Ab = p.A + b0 * p.sA0 + b1 * p.sA1;
+  const int8_t* Bb = p.B + b0 * p.sB0 + b1 * p.sB1;
   const int K = p.K;
   const int nkt = (K + QBS_BK - 1) / QBS_BK;
   const int T = nkt * p.nkb;
@@ -1906,7 +1912,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     __syncthreads();
   }
-  float* Cb = p.C + b0 * p.sC0;
+  float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
   if (!p.accumulate) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2729,8 +2735,28 @@ extern "C" int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, f
   a.A = xcodes; a.B = qcodes; a.C = S; a.s = sx; a.s2 = sq; a.u = u; a.tq = tq; a.z = z;
   a.lda = C; a.ldb = H * C; a.ldc = ldS;
   a.sA0 = N * C; a.sA1 = 0; a.sB0 = N * H * C; a.sB1 = C; a.sC0 = H * N * ldS; a.sC1 = N * ldS;
-  a.M = (int)N; a.N = (int)N; a.K = (int)C; a.S = (int)N; a.nb1 = (int)H;
+  a.M = (int)N; a.N = (int)N; a.K = (int)C; a.S = (int)N; a.nb1 = (int)H; a.s2s0 = (int)H; a.s2s1 = 1;
   a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale_x; a.gscale2 = gscale_q;
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// Plain attention (attention.py:92-96) on the codes: S[b,h,n,m] = q_hat[b,n,hd:hd+d] . k_hat[b,m,hd:hd+d] with
+// q_hat = aq[n]*qq + bq[c], k_hat = ak[m]*qk + bk[c] (per-token steps, per-channel offsets):
+//   S = aq[n]*(ak[m]*I + u[b,n,h]) + ak[m]*tq[b,m,h] + z[h],  u = qq . bk|head, tq = bq|head . qk, z = bq|head . bk|head
+extern "C" int ofq_qattn_scores_plain_i8(const int8_t* qcodes, const int8_t* kcodes, float* S, const float* sq, float gscale_q,
+                                         const float* sk, float gscale_k, const float* u, const float* tq, const float* z,
+                                         int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream) {
+  if (!qcodes || !kcodes || !S || !sq || !sk || !u || !tq || !z || B <= 0 || H <= 0 || N <= 0 || (d & 15) || ldS < N)
+    return OFQ_EINVAL;
+  QGemmArgs a = {};
+  const int64_t C = H * d;
+  a.A = qcodes; a.B = kcodes; a.C = S; a.s = sq; a.s2 = sk; a.u = u; a.tq = tq; a.z = z;
+  a.lda = C; a.ldb = C; a.ldc = ldS;
+  a.sA0 = N * C; a.sA1 = d; a.sB0 = N * C; a.sB1 = d; a.sC0 = H * N * ldS; a.sC1 = N * ldS;
+  a.M = (int)N; a.N = (int)N; a.K = (int)d; a.S = (int)N; a.nb1 = (int)H; a.s2s0 = 1; a.s2s1 = 0;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale_q; a.gscale2 = gscale_k;
   hipLaunchKernelGGL((qgemm_i8_nt_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
@@ -2803,6 +2829,40 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
     OFQ_LAUNCH_CHECK();
     return 0;
   }
+  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// Plain attention, backward of the scores (autograd of attention.py:96):
+//   dq_hat[b,n,hd+c] = sum_m (dS[b,h,n,m] * ak[m]) * qk[b,m,hd+c]                     (+ bk[c] * rowsum(dS): rows of a
+//                      softmax backward sum to zero, see functional.KEEP_ZERO_ROWSUM_TERM)
+//   dk_hat[b,m,hd+c] = sum_n dS[b,h,n,m] * (aq[n] * qq[b,n,hd+c] + bq[hd+c])
+extern "C" int ofq_qattn_dq_plain_bf16s(const float* dS, const int8_t* kcodes, float* dq, const float* sk, float gscale_k,
+                                        int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream) {
+  if (!dS || !kcodes || !dq || !sk || B <= 0 || H <= 0 || N <= 0 || (d & 15) || (ldS & 7) || ldS < N) return OFQ_EINVAL;
+  QNnArgs a = {};
+  const int64_t C = H * d;
+  a.A = dS; a.B = kcodes; a.C = dq; a.s = sk; a.lda = ldS; a.ldb = C; a.ldc = C;
+  a.sA0 = H * N * ldS; a.sA1 = N * ldS; a.sB0 = N * C; a.sB1 = d; a.sC0 = N * C; a.sC1 = d; a.nb1 = (int)H;
+  a.M = (int)N; a.N = (int)d; a.K = (int)N; a.nkb = 1; a.ks_stride = 1; a.accumulate = 0; a.gscale = gscale_k;
+  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(d, 128);
+  hipLaunchKernelGGL(qgemm_bf16s_nn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, float* dk, const float* sq, float gscale_q,
+                                        const float* bq, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS,
+                                        ofq_stream_t stream) {
+  if (!dS || !qcodes || !dk || !sq || B <= 0 || H <= 0 || N <= 0 || (d & 15) || (ldS & 3) || ldS < N) return OFQ_EINVAL;
+  QTnArgs a = {};
+  const int64_t C = H * d;
+  a.A = dS; a.B = qcodes; a.C = dk; a.s = sq; a.baft = bq; a.sBf1 = d; a.lda = ldS; a.ldb = C; a.ldc = C;
+  a.sA0 = H * N * ldS; a.sA1 = N * ldS; a.sB0 = N * C; a.sB1 = d; a.sC0 = N * C; a.sC1 = d;
+  a.M = (int)ldS; a.N = (int)d; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
+  a.Mstore = (int)N; a.Nstore = (int)d; a.trans_out = 0; a.gscale = gscale_q;
+  a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(d, 128);
   hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();

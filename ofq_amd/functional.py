@@ -418,6 +418,82 @@ class QKVSplitLsqFn(torch.autograd.Function):
                 res[2][1], None, None, None)
 
 
+class QKVSplitLsqCodesFn(torch.autograd.Function):
+    """QKVSplitLsqFn with the three outputs as integer codes only (operands of the code GEMMs of the plain attention
+    core): q / k per-token steps, v per-channel step, on column slices of the (B*N, 3C) projection.  The fp32 q_hat, k_hat,
+    v_hat are never written; zero-stride carriers take the autograd edges.  Backward = QKVSplitLsqFn's."""
+
+    @staticmethod
+    def forward(ctx, qkv, b4, sq, sk, sv, baq, bak, bav, gq, gk, gv):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        qkv2 = qkv.reshape(B * N, C3)
+        codes = []
+        for i, (s, g) in enumerate(((sq, gq), (sk, gk), (sv, gv))):
+            _, cd = ops.lsq_fwd(qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], None, g, want_codes=True, need_values=False)
+            codes.append(cd.view(B, N, C))
+        ctx.save_for_backward(qkv2, b4, sq, sk, sv)
+        ctx.geoms = (gq, gk, gv)
+        ctx.shape = (B, N, C)
+        ctx.mark_non_differentiable(*codes)
+        ctx.set_materialize_grads(False)
+        ph = [ops.placeholder((B, N, C), qkv.device) for _ in range(3)]
+        return ph[0], ph[1], ph[2], codes[0], codes[1], codes[2]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv, _c0, _c1, _c2):
+        qkv2, b4, sq, sk, sv = ctx.saved_tensors
+        B, N, C = ctx.shape
+        dqkv = torch.empty_like(qkv2)
+        db4s, res = [], []
+        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):
+            dy = dy.contiguous()
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:])
+            db4s.append(db4)
+            res.append((ds, dbaft))
+        return (dqkv.view(B, N, 3 * C), torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+                res[2][1], None, None, None)
+
+
+class QKScoresCodesFn(torch.autograd.Function):
+    """Plain attention scores on the codes: S[b,h,n,m] = q_hat[b,n,hd:hd+d] . k_hat[b,m,hd:hd+d], one exact int8 GEMM
+    per (b, h) plus the offset terms in its epilogue; backward = two bf16-split GEMMs per (b, h)."""
+
+    @staticmethod
+    def forward(ctx, q, k, aux):
+        B, N, C = q.shape
+        H = aux["H"]
+        d = C // H
+        Np = pad16(N)
+        dev = q.device
+        # per-head offset vectors as H rows of length C with zeros outside the head's channels: the per-head dot products
+        # of the codes with the other operand's offsets are plain row dots against them
+        eye = torch.eye(H, device=dev, dtype=torch.float32).repeat_interleave(d, dim=1)       # (H, C)
+        u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), eye * aux["bk"])                 # [B*N, H]: qq . bk|head
+        tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), eye * aux["bq"])                # [B*N, H]: bq|head . qk
+        z = (aux["bq"] * aux["bk"]).view(H, d).sum(1)
+        S = ops.qattn_scores_plain(aux["qcodes"], aux["kcodes"], aux["sq"], aux["gq"], aux["sk"], aux["gk"], u, tq, z,
+                                   B, H, N, d, Np)
+        ctx.aux = aux
+        ctx.dims = (B, H, N, d, Np)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        aux = ctx.aux
+        B, H, N, d, Np = ctx.dims
+        dS = dS.contiguous()
+        dq = ops.qattn_dq_plain(dS, aux["kcodes"], aux["sk"], aux["gk"], B, H, N, d, Np)
+        dk = ops.qattn_dk_plain(dS, aux["qcodes"], aux["sq"], aux["gq"], aux["bq"], B, H, N, d, Np)
+        rs = aux["link"].pop("ds_rowsum", None)
+        if KEEP_ZERO_ROWSUM_TERM:
+            # + rowsum_m(dS)[b,h,n] * bk[hd+c]: rows of a softmax backward sum to zero (see QKRScoresCodesFn.backward)
+            if rs is None:
+                rs = dS[..., :N].sum(-1).reshape(-1)
+            dq.view(B, N, H, d).add_(rs.view(B, H, N, 1).permute(0, 2, 1, 3) * aux["bk"].view(1, 1, H, d))
+        return dq, dk, None
+
+
 # =====================================================================================================
 # QKR attention core on the integer codes (same functions as QKRScoresFn / SoftmaxLsqFn / PVFn above)
 # =====================================================================================================

@@ -479,6 +479,31 @@ def qattn_scores(xcodes, qcodes, sx, gx, sq, gq, u, tq, z, B, H, N, C, ldS):
     return S
 
 
+def qattn_scores_plain(qcodes, kcodes, sq, gq, sk, gk, u, tq, z, B, H, N, d, ldS):
+    S = torch.empty((B, H, N, ldS), dtype=torch.float32, device=qcodes.device)
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_scores_plain_i8(qcodes.data_ptr(), kcodes.data_ptr(), S.data_ptr(), sq.data_ptr(), gq, sk.data_ptr(),
+                                             gk, u.data_ptr(), tq.data_ptr(), z.data_ptr(), B, H, N, d, ldS, _stream()),
+             "ofq_qattn_scores_plain_i8")
+    return S
+
+
+def qattn_dq_plain(dS, kcodes, sk, gk, B, H, N, d, ldS):
+    dq = torch.empty((B, N, H * d), dtype=torch.float32, device=dS.device)
+    with _Timed('qgemm_bf16s_nn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_dq_plain_bf16s(dS.data_ptr(), kcodes.data_ptr(), dq.data_ptr(), sk.data_ptr(), gk, B, H, N, d, ldS,
+                                            _stream()), "ofq_qattn_dq_plain_bf16s")
+    return dq
+
+
+def qattn_dk_plain(dS, qcodes, sq, gq, bq, B, H, N, d, ldS):
+    dk = torch.empty((B, N, H * d), dtype=torch.float32, device=dS.device)
+    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_dk_plain_bf16s(dS.data_ptr(), qcodes.data_ptr(), dk.data_ptr(), sq.data_ptr(), gq, _p(bq), B, H, N,
+                                            d, ldS, _stream()), "ofq_qattn_dk_plain_bf16s")
+    return dk
+
+
 def qattn_pv(pcodes, vcodesT, sp, gp, sv, gv, bav, rp, B, H, N, d, Np):
     O = torch.empty((B, N, H * d), dtype=torch.float32, device=pcodes.device)
     with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * d):

@@ -15,7 +15,8 @@ from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkrepar
 from ...deit_vision_transformer import Attention as deit_attention
 from ... import ops
 from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn, codes_linear,
-                           codes_linear_ok, QKRScoresCodesFn, SoftmaxLsqCodesFn, PVCodesFn)
+                           codes_linear_ok, QKRScoresCodesFn, SoftmaxLsqCodesFn, PVCodesFn, QKVSplitLsqCodesFn,
+                           QKScoresCodesFn)
 from . import qlinear as _ql
 
 
@@ -109,6 +110,27 @@ def plain_attention_core(self, x, scale, addend=None):
         lo, hi = self.quan_a_q_fn.thd_neg, self.quan_a_q_fn.thd_pos
         gq = ops.LsqGeom(B, N, C, C, 0, lo, hi, B * C, ldx=3 * C, ldy=C)         # s per token, M = B*H*d
         gv = ops.LsqGeom(B * N, 1, C, C, 1, lo, hi, B * N, ldx=3 * C, ldy=C)     # s per channel, M = B*N
+        d = C // H
+        sm = self.quan_a_softmax_fn
+        if _ql.USE_CODE_GEMM and _ql.PLAIN_ATTN_CODES and C % 16 == 0 and d % 16 == 0 and N <= 256 and lo >= -128 \
+                and hi <= 127 and sm.thd_pos <= 127:
+            # the core on the integer codes, like the QKR path: q_hat / k_hat / v_hat / P_hat exist only as int8 codes, the
+            # scores and P.V are exact int8 GEMMs with the offsets as epilogue terms, the backward products bf16-split GEMMs
+            q, k, v, qc, kc, vc = QKVSplitLsqCodesFn.apply(qkv, self.move_qkv_b4.bias, self.quan_a_q_fn.s,
+                                                           self.quan_a_k_fn.s, self.quan_a_v_fn.s, self.move_q_aft.bias,
+                                                           self.move_k_aft.bias, self.move_v_aft.bias, gq, gq, gv)   # :71-90
+            link = {}
+            S = QKScoresCodesFn.apply(q, k, {
+                "qcodes": qc, "kcodes": kc, "sq": self.quan_a_q_fn.s.detach(), "gq": gq.gscale,
+                "sk": self.quan_a_k_fn.s.detach(), "gk": gq.gscale, "bq": self.move_q_aft.bias.detach(),
+                "bk": self.move_k_aft.bias.detach(), "H": H, "link": link})                                           # :96
+            addend = _fit_addend(addend, S)
+            _softmax_init(sm, S, N, scale, addend)
+            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)                      # :97-99
+            gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
+            return PVCodesFn.apply(P, v, {
+                "pcodes": pcodes, "rp": rp, "vcodes": vc, "sp": sm.s.detach(), "gp": gp,
+                "sv": self.quan_a_v_fn.s.detach(), "gv": gv.gscale, "bav": self.move_v_aft.bias.detach()})            # :102
         q, k, v = QKVSplitLsqFn.apply(qkv, self.move_qkv_b4.bias, self.quan_a_q_fn.s, self.quan_a_k_fn.s,
                                       self.quan_a_v_fn.s, self.move_q_aft.bias, self.move_k_aft.bias,
                                       self.move_v_aft.bias, gq, gq, gv)          # :71-90

@@ -18,6 +18,9 @@ from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
 # Exact integer-code GEMMs (int8 forward, bf16-split dX) instead of the fp32-MFMA GEMM on fake-quant values.
 # Same mathematical function; toggled off by the parity tests that compare the two paths.
 USE_CODE_GEMM = True
+# The plain (non-QKR) attention core on integer codes as well (int8 scores / P.V, bf16-split backward) instead of the
+# fp32-MFMA batched GEMMs on fake-quant values (A/B switch: OFQ_NO_PLAIN_ATTN_CODES=1)
+PLAIN_ATTN_CODES = os.environ.get("OFQ_NO_PLAIN_ATTN_CODES") is None
 # fc1's GEMM epilogue emits fc2's input codes (A/B switch for bench runs: OFQ_NO_EPILOGUE_FUSE=1)
 FUSE_NEXT_CODES = os.environ.get("OFQ_NO_EPILOGUE_FUSE") is None
 FUSE_NEXT_CODES_MLP = os.environ.get("OFQ_NO_EPILOGUE_FUSE_MLP") is None

@@ -159,3 +159,153 @@ def test_data_parallel_over_rccl_one_rank_equals_plain_step_and_graph():
         _same(se, sg)
     finally:
         dist.destroy_process_group()
+
+
+def test_cga_hooks_in_train_step_follow_the_reference_sequence():
+    """engine.CGAHooks around engine.train_step (config C5: qk_reparam_type=1 model, mask / restore folded into the HIP
+    AdamW) for three steps against the reference's own sequence (cga.py:953-1013) replayed through the oracle on CPU:
+    loss.backward -> freeze_idx from the weights -> grad * (1 - idx) -> optimizer.step -> frozen weights restored.
+    The frozen weights must come out of every step bit-identical to what went in; the losses follow the oracle's; the other
+    parameters stay within the AdamW step bound of the oracle's (Adam normalises the gradient, so an element whose
+    gradient is rounding noise moves by +-lr on either side: the 2-D weights are compared norm-wise, the rest by bound)."""
+    import sys
+    import ofq_oracle as O
+    from functools import partial
+    from types import SimpleNamespace
+    import torch.nn as nn
+    from ofq_amd import engine
+    from ofq_amd.deit import DistilledVisionTransformer
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    torch.manual_seed(0)
+    depth, dim, heads, ncls, B, bits, br = 2, 64, 2, 10, 4, 2, 0.05
+    model = DistilledVisionTransformer(img_size=224, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4,
+                                       qkv_bias=True, num_classes=ncls, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                       act_layer=nn.GELU)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() >= 2:
+                p.mul_(4.0)
+            else:
+                p.add_(0.05 * torch.randn_like(p))
+    args = SimpleNamespace(qmodules=engine.default_qmodules(depth), wq_mode="statsq", wq_enable=True, wq_bitw=bits,
+                           aq_enable=True, aq_mode="lsq", aq_bitw=bits, wq_per_channel=True, aq_per_channel=True,
+                           model_type="deit", pretrained_initialized=True, qk_reparam=True, qk_reparam_type=1,
+                           boundaryRange=br)
+    model = engine.get_qat_model(model, args).cuda()
+    img = torch.randn(B, 3, 224, 224, device="cuda")
+    tgt = torch.randint(0, ncls, (B,), device="cuda")
+    soft = torch.randn(B, ncls, device="cuda")
+    engine.setup_alpha(model, img)
+    model.train()
+    lr, wd = 1e-4, 0.05
+    # ---- the reference sequence on CPU through the oracle
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "clip_val" not in k and "signed" not in k else v)
+              for k, v in sd.items()}
+    names = {id(p): n for n, p in model.named_parameters()}
+    groups = engine.param_groups_weight_decay(model, wd)
+    ref_groups = [{"params": [leaves[names[id(p)]] for p in g["params"]], "weight_decay": g["weight_decay"]} for g in groups]
+    ref_opt = torch.optim.AdamW(ref_groups, lr=lr, weight_decay=wd)
+    cfg = dict(depth=depth, num_heads=heads, patch=16, wbits=bits, abits=bits, qkr=True)
+    cga_names = [k + ".weight" for k, _ in engine.cga_modules(model, qk_reparam=True)]
+    assert len(cga_names) == 4 * depth
+    # ---- the product path
+    opt = engine.make_optimizer(model, lr=lr, weight_decay=wd)
+    hooks = engine.CGAHooks(model, bits, br, qk_reparam=True)
+    loss_fn = KDLossSoftandHard()
+    frozen_share = []
+    for step in range(3):
+        before = {n: dict(model.named_parameters())[n].detach().clone() for n in cga_names}
+        loss = engine.train_step(model, opt, img, tgt, soft, loss_fn, cga=hooks)
+        ref_opt.zero_grad(set_to_none=True)
+        c, d = O.deit_forward(img.cpu(), leaves, cfg, training=True)
+        lo = O.kd_loss_soft_and_hard(c, d, tgt.cpu(), soft.cpu())
+        lo.backward()
+        saved, idx = {}, {}
+        for n in cga_names:                                                    # cga.py:958-964
+            W = leaves[n]
+            idx[n] = O.cga_freeze_idx(W.detach(), bits, br)
+            W.grad = O.cga_mask_grad(W.grad, idx[n])
+            saved[n] = W.detach().clone()
+        ref_opt.step()
+        with torch.no_grad():
+            for n in cga_names:                                                # cga.py:994-997
+                leaves[n].copy_(O.cga_restore(leaves[n].detach(), saved[n], idx[n]))
+        assert abs(float(loss.detach()) - float(lo)) < 1e-4 * abs(float(lo)), (step, float(loss.detach()), float(lo))
+        for n, p in model.named_parameters():
+            ref = leaves[n].detach()
+            got = p.detach().cpu()
+            if n in cga_names:
+                frz = idx[n].bool()
+                frozen_share.append(float(frz.float().mean()))
+                # frozen weights: untouched, bit for bit (on both sides)
+                assert torch.equal(got[frz], before[n].cpu()[frz]), (step, n)
+                assert torch.equal(ref[frz], saved[n][frz])
+                moved = got[~frz] != before[n].cpu()[~frz]
+                assert float(moved.float().mean()) > 0.9, (step, n)           # ... and the others took their AdamW step
+            assert float((got - ref).abs().max()) <= 2.5 * lr * (step + 1), (step, n)
+            if got.dim() >= 2:
+                err = float((got.double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+                assert err < 1e-3, (step, n, err)
+    assert 0.05 < sum(frozen_share) / len(frozen_share) < 0.95      # the mask froze a real share of the weights
+
+
+def test_train_cli_two_steps_save_resume_and_validate(tmp_path):
+    """train.py's entry point (ofq_amd.train_cli.main): reference flag names, a KD teacher loaded from --teacher-checkpoint,
+    two epochs of two steps, checkpoint -> --resume continues with the same losses as an uninterrupted run (model, LSQ
+    steps, AdamW state and epoch all restored, train.py:691-706), and validate() (train.py:1012-1083) equals the oracle's
+    eval-mode logits on the same batches."""
+    import io
+    import contextlib
+    import ofq_oracle as O
+    from ofq_amd import train_cli
+    from ofq_amd.deit import create_model
+    torch.manual_seed(0)
+    teacher = create_model("deit_tiny_distilled_patch16_224", num_classes=1000)
+    tpath = str(tmp_path / "teacher.pth")
+    torch.save({"state_dict": {"module." + k: v for k, v in teacher.state_dict().items()}}, tpath)   # DDP-style prefix
+    common = ["--model", "deit_tiny_distilled_patch16_224", "--batch-size", "4", "--steps-per-epoch", "2", "--val-steps", "1",
+              "--lr", "5e-4", "--weight-decay", "0.05", "--aq-enable", "--aq-mode", "lsq", "--aq-per-channel",
+              "--aq_clip_learnable", "--aq-bitw", "3", "--wq-enable", "--wq-per-channel", "--wq-bitw", "3", "--wq-mode",
+              "statsq", "--model_type", "deit", "--quantized", "--pretrained_initialized", "--use-kd", "--teacher",
+              "deit_tiny_distilled_patch16_224", "--teacher-checkpoint", tpath, "--kd_hard_and_soft", "1", "--qk_reparam",
+              "--qk_reparam_type", "0", "--log-interval", "1", "--warmup-epochs", "0"]
+
+    def run(extra):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = train_cli.main(common + extra)
+        losses = [float(l.split("Loss:")[1].split()[0]) for l in buf.getvalue().splitlines() if l.startswith("Train:")]
+        return res, losses
+    full, losses_full = run(["--epochs", "2", "--output", str(tmp_path / "full")])
+    assert len(losses_full) == 4
+    first, losses_a = run(["--epochs", "1", "--output", str(tmp_path / "half")])
+    # (the cosine schedule depends on --epochs: give the resumed run the full run's horizon)
+    _, losses_b = run(["--epochs", "2", "--resume", str(tmp_path / "half" / "last.pth.tar"), "--output", str(tmp_path / "res")])
+    assert len(losses_a) == 2 and len(losses_b) == 2
+    assert losses_b[0] == pytest.approx(losses_full[2], rel=1e-6) and losses_b[1] == pytest.approx(losses_full[3], rel=1e-6)
+    # unsupported flags do not pass silently
+    with pytest.raises(SystemExit):
+        train_cli.main(common + ["--epochs", "1", "--mixup", "0.8"])
+    with pytest.raises(SystemExit):
+        train_cli.main([a for a in common if a not in ("--teacher-checkpoint", tpath)] + ["--epochs", "1"])
+    # validate() against the oracle's eval forward on the same synthetic validation batch
+    model = full["model"]
+    dev = next(model.parameters()).device
+    vl = train_cli.SyntheticLoader(1, 4, 1000, dev, 42 + 1000)
+    got = train_cli.validate(model, vl, 1, 0)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(depth=12, num_heads=3, patch=16, wbits=3, abits=3, qkr=True)
+    x, y = vl.pool[0]
+    with torch.no_grad():
+        logits = O.deit_forward(x.cpu(), sd, cfg, training=False)
+    want_loss = float(torch.nn.functional.cross_entropy(logits, y.cpu()))
+    # validate()'s numbers are the metrics of the model's own eval-mode logits ...
+    model.eval()
+    with torch.no_grad():
+        own, _ = model(x)
+    assert got["loss"] == pytest.approx(float(torch.nn.functional.cross_entropy(own, y)), rel=1e-6)
+    assert got["top1"] == pytest.approx(100.0 * float((own.argmax(1) == y).float().mean()))
+    # ... which follow the oracle's through 12 three-bit blocks (level flips on rounding ties included) to 2e-3
+    assert got["loss"] == pytest.approx(want_loss, rel=2e-3)
+    assert float((own.cpu().double() - logits.double()).norm() / logits.double().norm()) < 5e-2
