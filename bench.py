@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-qkr", action="store_true")
     ap.add_argument("--cga", action="store_true", help="add the CGA mask/restore hooks (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c1-baseline", action="store_true", help="skip the second CPU line (BASELINE config 1, DeiT-T W4A4 B=32)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-roofline-events", action="store_true")
@@ -93,10 +94,44 @@ def cpu_baseline(model, args):
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
     med = times[len(times) // 2]
-    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+    c1 = None
+    if not args.no_c1_baseline:
+        c1 = cpu_baseline_c1(cores)
+    return {"value": round(B / med, 3), "unit": "images/s", "cores": cores, "kind": "port", "also": c1,
             "sample": "oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path), %s W%dA%d%s, batch %d, "
                       "median of %d steps after 1 warm-up, fwd+bwd+AdamW, %d threads"
                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR", B, args.cpu_steps, cores)}
+
+
+def cpu_baseline_c1(cores):
+    """BASELINE.json configs[0] / BASELINE.md section 3: DeiT-T W4A4, plain attention, batch 32, the reference's own
+    CPU-runnable case, timed on the same host cores through the oracle (fwd + bwd + AdamW, median of 3 after 1 warm-up)."""
+    import ofq_oracle as O
+    from ofq_amd import engine
+    dev = torch.device("cuda", 0)
+    m = engine.build_student("deit_tiny_distilled_patch16_224", 4, 4, qk_reparam=False).to(dev)
+    g = torch.Generator().manual_seed(42)
+    img = torch.randn(32, 3, 224, 224, generator=g)
+    tgt = torch.randint(0, 1000, (32,), generator=g)
+    soft = torch.randn(32, 1000, generator=g)
+    engine.setup_alpha(m, img.to(dev))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    del m
+    leaves = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "clip_val" not in k and "signed" not in k
+                  else v) for k, v in sd.items()}
+    cfg = dict(depth=12, num_heads=3, patch=16, wbits=4, abits=4, qkr=False)
+    opt = torch.optim.AdamW([v for v in leaves.values() if v.requires_grad], lr=5e-4, weight_decay=0.05)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        c, d = O.deit_forward(img, leaves, cfg, training=True)
+        O.kd_loss_soft_and_hard(c, d, tgt, soft).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[1]
+    return {"value": round(32 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "BASELINE config 1: deit_tiny W4A4 plain attention, batch 32, oracle, median of 3 steps after 1 warm-up"}
 
 
 class _c_stdout_to_stderr:
@@ -200,20 +235,24 @@ def main():
     teacher = None
     if args.with_teacher:
         from ofq_amd.deit import create_model
-        teacher = create_model(args.model, num_classes=1000).to(dev).eval()      # train.py:428-437 (fp32, frozen)
+        # train.py:428-437, :526-531: the teacher is created and moved to the device, never put in eval mode: it returns
+        # ((cls, dist), attn) and KLLossSoft distils from the cls logits (quantization/utils.py:46-47)
+        teacher = create_model(args.model, num_classes=1000).to(dev)
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
 
+    def soft_targets():
+        if teacher is None:
+            return soft
+        with torch.no_grad():
+            t_out, _ = teacher(images)
+        return t_out[0] if isinstance(t_out, tuple) else t_out
+
     def step():
-        s_t = soft
-        if teacher is not None:
-            with torch.no_grad():
-                t_out, _ = teacher(images)                    # eval mode: (cls + dist) / 2 logits
-                s_t = t_out
-        return engine.train_step(model, opt, images, target, s_t, loss_fn, dp=dp, cga=cga)
+        return engine.train_step(model, opt, images, target, soft_targets(), loss_fn, dp=dp, cga=cga)
 
     eager_step = step
-    use_graph = not args.no_graph and teacher is None
+    use_graph = not args.no_graph
     n_warm = args.warmup
     if use_graph:
         # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures
@@ -221,7 +260,8 @@ def main():
         n_warm = max(args.warmup, gstep.warmup + 1)          # the capture must not fall into the timed region
 
         def step():
-            return gstep(images, target, soft)
+            return gstep(images, target, soft_targets())      # (the teacher runs eagerly; its logits are copied into the
+                                                              # graph's static soft-target buffer)
 
     for i in range(n_warm):
         step()
@@ -270,10 +310,19 @@ def main():
             sm = sums[name]
             peak = [v for k, v in PEAKS.items() if name.startswith(k)][0]
             achieved = sm["total_units"] / (sm["total_ms"] * 1e-3) / 1e12 if sm["total_ms"] > 0 else 0.0
-            traffic = None                       # HBM bytes per launch of this kernel class from the committed PMC passes
+            # HBM bytes per launch of this kernel class from the committed PMC passes -- only if they were taken on THESE
+            # kernels (content hash of csrc/ + the header, ofq_amd/build.py); stale counters are not reported
+            traffic, traffic_note = None, "no profiles/r02_traffic.json"
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                    traffic = json.load(fh).get(name.split(" ")[0], {}).get("traffic_bytes_per_launch")
+                from ofq_amd import build as _build
+                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+                    tj = json.load(fh)
+                if tj.get("source_hash") == _build.source_hash():
+                    traffic = tj.get(name.split(" ")[0], {}).get("traffic_bytes_per_launch")
+                    traffic_note = "profiles/r02_traffic.json (kernel sources %s)" % tj.get("source_hash")
+                else:
+                    traffic_note = ("profiles/r02_traffic.json was measured on kernel sources %s, this library is %s: not reported"
+                                    % (tj.get("source_hash"), _build.source_hash()))
             except (OSError, ValueError):
                 pass
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -281,7 +330,7 @@ def main():
                     "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over a second, "
                             "instrumented pass of the same --steps steps (the throughput pass carries no events: they cost "
                             "2-4 ms/step); for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "
-                            "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/r01_traffic.json)",
+                            "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes: " + traffic_note,
                     "launches_per_step": sm["launches"] / args.steps, "avg_launch_ms": round(sm["avg_ms"], 4),
                     "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),
                     "ms_per_step": round(sm["total_ms"] / args.steps, 3),
