@@ -55,6 +55,9 @@ def parse():
                          "that produces the KD soft targets to every step (train.py:906-910)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the captured step with more than one rank as well (default there: eager launches; the capture "
+                         "of RCCL collectives is validated with one rank only, tests/test_graph_gpu.py)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -252,7 +255,10 @@ def main():
         return engine.train_step(model, opt, images, target, soft_targets(), loss_fn, dp=dp, cga=cga)
 
     eager_step = step
-    use_graph = not args.no_graph
+    # one rank: graph replay.  Several ranks: the step is GPU-bound at 128 img/GPU either way (the launch queue never runs dry,
+    # profiles/r02_graph_gaps_*), and RCCL collectives inside a hipGraph could only be exercised with one rank on the
+    # one-GPU development boxes, so the multi-rank default is the eager path; --graph turns the replay on there too.
+    use_graph = not args.no_graph and (world == 1 or args.graph)
     n_warm = args.warmup
     if use_graph:
         # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel MFMA utilisation from a rocprofv3 --pmc pass (rocpd database):
-   MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) as in the gfx94x derived metric; also the share of
-   wave time spent issuing / stalled at issue / parked (SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES)."""
+   raw = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) as in the gfx94x derived metric; calibration:
+   tools/probe/mfma_rate_probe (back-to-back v_mfma_f32_32x32x16_bf16 on every SIMD = 100 % by construction) reads raw = 11.6
+   under the same pass on this pool, so MfmaUtil = raw / 0.116.  Also the share of wave time spent issuing / stalled at
+   issue / parked (SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES; a SIMD hosts 2-5 waves)."""
 import sqlite3, sys, collections
 con = sqlite3.connect(sys.argv[1])
 cur = con.cursor()
@@ -25,6 +27,7 @@ for k, v in d.items():
                  100.0 * v.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100.0 * v.get("SQ_WAIT_INST_ANY", 0) / wc,
                  100.0 * v.get("SQ_WAIT_ANY", 0) / wc, 100.0 * v.get("SQ_ACTIVE_INST_VALU", 0) / wc))
 rows.sort(reverse=True)
-print("%-86s %6s %9s %8s %8s %8s %8s" % ("kernel", "calls", "MfmaUtil%", "issue%", "istall%", "parked%", "valu%"))
+print(__doc__)
+print("%-86s %6s %6s %9s %8s %8s %8s %8s" % ("kernel", "calls", "raw", "MfmaUtil%", "issue%", "istall%", "parked%", "valu%"))
 for r in rows[:28]:
-    print("%-86s %6d %9.1f %8.1f %8.1f %8.1f %8.1f" % (str(r[1])[:86], r[2], r[3], r[4], r[5], r[6], r[7]))
+    print("%-86s %6d %6.1f %9.1f %8.1f %8.1f %8.1f %8.1f" % (str(r[1])[:86], r[2], r[3], r[3] / 0.116, r[4], r[5], r[6], r[7]))
