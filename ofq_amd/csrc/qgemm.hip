@@ -199,21 +199,24 @@ __device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one m
 #endif
 // The k-loop of the int8 kernels: acc[2][2] (2x2 blocks of 32x32 per wave, 2x2 waves) += A[m0.., :] . B[n0.., :]^T over K.
 // Shared by the forward kernel and by the backward kernel that recomputes a layer output from the codes.
+// T = 2: 128 x 128 tile (each of the 2 x 2 waves owns 64 x 64 = 2 x 2 MFMA blocks); T = 1: 64 x 64 tile (one 32 x 32 block per
+// wave) for the 49-token Swin windows, where a 128 x 128 tile is 85 % padding.
+template <int T>
 __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned char* A, const unsigned char* B, int m0, int n0,
-                                            unsigned char (*smem)[(128 + 128) * QI8_LD], i32x16 (&acc)[2][2]) {
-  constexpr int BM = 128, BN = 128;
+                                            unsigned char (*smem)[(128 * T) * QI8_LD], i32x16 (&acc)[T][T]) {
+  constexpr int BM = 64 * T, BN = 64 * T;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
   const int K = p.K;
   const int nkt = (K + QI8_BK - 1) / QI8_BK;
 
-  // staging: 128 rows x 64 B per operand = 512 x 16 B -> 2 chunks per thread per operand
-  int64_t offA[2], offB[2];
-  bool okA[2], okB[2];
-  int kq[2];
+  // staging: BM rows x 64 B per operand = 4 * BM x 16 B -> T chunks per thread per operand
+  int64_t offA[T], offB[T];
+  bool okA[T], okB[T];
+  int kq[T];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < T; ++i) {
     const int f = tid + 256 * i;
     const int row = f >> 2;
     kq[i] = (f & 3) * 16;
@@ -226,14 +229,14 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
   // two k-steps later, so a k-step never waits for the HBM / L2 latency of its own loads (k-steps are only 8 MFMAs
   // long here).  The loop body is branch-free (tiles past the end repeat the last one into a stage nobody reads): guards
   // around the loads make the compiler's wait-count pass wait for every outstanding load at each k-step.
-  i32x4 ra[2][2], rb[2][2];
+  i32x4 ra[2][T], rb[2][T];
   const int klast = nkt - 1;
   const bool nomask = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (K % QI8_BK) == 0;
   auto gload = [&](int kt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
     const int k0 = kt * QI8_BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < T; ++i) {
       const bool kin = (k0 + kq[i]) < K;                 // K % 16 == 0 (host check): a chunk is all in or all out
       ra[sl][i] = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq[i]));
       rb[sl][i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq[i]));
@@ -242,18 +245,18 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
   auto lstore = [&](unsigned char* sb, int kt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rb[sl][i]));
+    for (int i = 0; i < T; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rb[sl][i]));
     const int k0 = kt * QI8_BK;
     if (nomask) {      // interior tile, no k tail (every tile of the DeiT-S shapes): 16 v_and + the mask selects per k-step gone
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < T; ++i) {
         const int row = (tid + 256 * i) >> 2;
         *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i];
         *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < T; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 2;
         const bool kin = (k0 + kq[i]) < K;
@@ -265,26 +268,26 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
   };
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < T; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
   auto compute = [&](const unsigned char* sb) {
-    const unsigned char* a = &sb[(wm * 64 + l31) * QI8_LD + lh * 16];
-    const unsigned char* b = &sb[(BM + wn * 64 + l31) * QI8_LD + lh * 16];
+    const unsigned char* a = &sb[(wm * 32 * T + l31) * QI8_LD + lh * 16];
+    const unsigned char* b = &sb[(BM + wn * 32 * T + l31) * QI8_LD + lh * 16];
 #pragma unroll
     for (int ks = 0; ks < QI8_BK / 32; ++ks) {
-      i32x4 av[2], bv[2];
+      i32x4 av[T], bv[T];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const i32x4*>(a + i * 32 * QI8_LD + ks * 32);
+      for (int i = 0; i < T; ++i) av[i] = *reinterpret_cast<const i32x4*>(a + i * 32 * QI8_LD + ks * 32);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const i32x4*>(b + j * 32 * QI8_LD + ks * 32);
+      for (int j = 0; j < T; ++j) bv[j] = *reinterpret_cast<const i32x4*>(b + j * 32 * QI8_LD + ks * 32);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < T; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -316,9 +319,10 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
 }
 
 // EPI 0: linear layer   1: QKR attention scores   2: P*V
-template <int EPI>
+template <int EPI, int T = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
-  constexpr int BM = 128, BN = 128;
+  static_assert(T == 2 || EPI != 0, "the linear-layer epilogue is written for 128 x 128 tiles");
+  constexpr int BM = 64 * T, BN = 64 * T;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
   I8_T(0);
   int tm, tn, gby;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
   // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
   // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
   // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
-  float pre_ra, pre_rb = 0.f, pre_c[2][5];
+  float pre_ra, pre_rb = 0.f, pre_c[T][5];
   {
     const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
     pre_ra = p.s[m % p.S];
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
     if (EPI == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nc = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
+      for (int j = 0; j < T; ++j) {
+        const int nc = min(n0 + wn * 32 * T + j * 32 + l31, p.N - 1);
         pre_c[j][0] = p.cs[nc];
         pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
         pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
@@ -358,13 +362,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     }
   }
 
-  i32x16 acc[2][2];
-  i8_mainloop(p, A, B, m0, n0, smem, acc);
+  i32x16 acc[T][T];
+  i8_mainloop<T>(p, A, B, m0, n0, smem, acc);
   I8_T(2);
   float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
-  int ncol[2];
+  int ncol[T];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) ncol[j] = n0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < T; ++j) ncol[j] = n0 + wn * 32 * T + j * 32 + l31;
   // per-row epilogue terms of the 128 tile rows go through LDS once (the k-loop's last barrier has released smem):
   // row_a = effective LSQ step of the row, row_b = the row's offset term (u / rp); every lane then reads 32 of them as
   // broadcasts instead of issuing 32 dependent global loads + integer modulos
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
   }
   __syncthreads();
   I8_T(3);
-  if (EPI == 0) {
+  if constexpr (EPI == 0) {
     // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
     float csn[2], rn[2], bz[2], qb[2], qsc[2];
     signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [128][128] codes, behind row_a / row_b
@@ -437,49 +441,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
       }
     }
     I8_T(5);
-  } else if (EPI == 1) {
+  } else if constexpr (EPI == 1) {
     // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
-    float aq[2], tqa[2];
+    float aq[T], tqa[T];
     const float zz = p.z[b1];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < T; ++j) {
       const int nc = min(ncol[j], p.N - 1);
       aq[j] = ofq_lsq_eff_scale(p.s2[nc * p.s2s0 + b1 * p.s2s1], p.gscale2);
       tqa[j] = __fadd_rn(__fmul_rn(aq[j], p.tq[((int64_t)b0 * p.N + nc) * p.nb1 + b1]), zz);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 * T + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
         const float ax = row_a[m - m0];
         const float uu = row_b[m - m0];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < T; ++j)
           if (ncol[j] < p.N)
             Cb[(int64_t)m * p.ldc + ncol[j]] =
                 __fadd_rn(__fmul_rn(ax, __fadd_rn(__fmul_rn(aq[j], (float)acc[i][j][e]), uu)), tqa[j]);
       }
   } else {
     // O[n,c] = ap[n] * (av[c] * I + bav[c] * rp[n])                                 (P_hat . V_hat, attention.py:219)
-    float av[2], bv2[2];
+    float av[T], bv2[T];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < T; ++j) {
       const int nc = min(ncol[j], p.N - 1) + b1 * p.N;
       av[j] = ofq_lsq_eff_scale(p.s2[nc], p.gscale2);
       bv2[j] = p.z ? p.z[nc] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 * T + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
         const float ap = row_a[m - m0];
         const float rpm = row_b[m - m0];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < T; ++j)
           if (ncol[j] < p.N)
             Cb[(int64_t)m * p.ldc + ncol[j]] =
                 __fmul_rn(ap, __fadd_rn(__fmul_rn(av[j], (float)acc[i][j][e]), __fmul_rn(bv2[j], rpm)));
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   gload(g0, 0);
   i32x16 acc[2][2];
-  i8_mainloop(p, A, B, m0, n0, smem, acc);
+  i8_mainloop<2>(p, A, B, m0, n0, smem, acc);
   gload(g1, 1);
 
   float* row_a = reinterpret_cast<float*>(&smem[0][0]);       // [128] effective input step of the row
@@ -2724,6 +2728,20 @@ extern "C" int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t bat
   return 0;
 }
 
+// Batched attention GEMMs on int8 codes: 64 x 64 tiles when the whole (tokens x tokens) / (tokens x head_dim) matrix of a
+// batch entry fits in one (the 49-token Swin windows: a 128 x 128 tile would be 85 % padding), 128 x 128 tiles otherwise.
+template <int EPI>
+static void i8_attn_launch(QGemmArgs& a, int64_t M, int64_t N, int64_t batches, hipStream_t st) {
+  static const bool no_small = getenv("OFQ_NO_SMALL_TILES") != nullptr;          // A/B switch (tools/)
+  if (M <= 64 && N <= 64 && !no_small) {
+    a.tiles_m = a.tiles_n = 1;
+    hipLaunchKernelGGL((qgemm_i8_nt_kernel<EPI, 1>), dim3(1u, (unsigned)batches), dim3(256), 0, st, a);
+  } else {
+    a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128);
+    hipLaunchKernelGGL((qgemm_i8_nt_kernel<EPI, 2>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)batches), dim3(256), 0, st, a);
+  }
+}
+
 // ---- attention products on the codes -------------------------------------------------------------------------
 // scores: S[b,h,n,m] = ax[n]*(aq[m,h]*(qx[b,n,:].qq[b,m,h,:]) + u[b,n,h]) + aq[m,h]*tq[b,m,h] + z[h]
 extern "C" int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, const float* sx, float gscale_x,
@@ -2736,9 +2754,8 @@ extern "C" int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, f
   a.lda = C; a.ldb = H * C; a.ldc = ldS;
   a.sA0 = N * C; a.sA1 = 0; a.sB0 = N * H * C; a.sB1 = C; a.sC0 = H * N * ldS; a.sC1 = N * ldS;
   a.M = (int)N; a.N = (int)N; a.K = (int)C; a.S = (int)N; a.nb1 = (int)H; a.s2s0 = (int)H; a.s2s1 = 1;
-  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale_x; a.gscale2 = gscale_q;
-  hipLaunchKernelGGL((qgemm_i8_nt_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  a.gscale = gscale_x; a.gscale2 = gscale_q;
+  i8_attn_launch<1>(a, N, N, B * H, (hipStream_t)stream);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -2756,9 +2773,8 @@ extern "C" int ofq_qattn_scores_plain_i8(const int8_t* qcodes, const int8_t* kco
   a.lda = C; a.ldb = C; a.ldc = ldS;
   a.sA0 = N * C; a.sA1 = d; a.sB0 = N * C; a.sB1 = d; a.sC0 = H * N * ldS; a.sC1 = N * ldS;
   a.M = (int)N; a.N = (int)N; a.K = (int)d; a.S = (int)N; a.nb1 = (int)H; a.s2s0 = 1; a.s2s1 = 0;
-  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale_q; a.gscale2 = gscale_k;
-  hipLaunchKernelGGL((qgemm_i8_nt_kernel<1>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  a.gscale = gscale_q; a.gscale2 = gscale_k;
+  i8_attn_launch<1>(a, N, N, B * H, (hipStream_t)stream);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -2773,9 +2789,8 @@ extern "C" int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, floa
   a.lda = Np; a.ldb = Np; a.ldc = C;
   a.sA0 = H * N * Np; a.sA1 = N * Np; a.sB0 = C * Np; a.sB1 = d * Np; a.sC0 = N * C; a.sC1 = d;
   a.M = (int)N; a.N = (int)d; a.K = (int)Np; a.S = (int)N; a.nb1 = (int)H;
-  a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(d, 128); a.gscale = gscale_p; a.gscale2 = gscale_v;
-  hipLaunchKernelGGL((qgemm_i8_nt_kernel<2>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  a.gscale = gscale_p; a.gscale2 = gscale_v;
+  i8_attn_launch<2>(a, N, d, B * H, (hipStream_t)stream);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -172,3 +172,49 @@ def test_plain_attention_full_size_code_path_equals_fp32_gemm_path(ops, cfg):
         if "move_" not in n and not n.endswith(".s"):          # (offset gradients that vanish in exact arithmetic are noise on both sides)
             visible = float(((a - b).abs() > 1e-3 * float(b.abs().max())).double().mean())
             assert visible < 1e-2, (name, n, visible)
+
+
+@pytest.mark.parametrize("qkr", [False, True])
+def test_swin_window_attention_full_size_code_path_equals_fp32_gemm_path(ops, qkr):
+    """BASELINE config 4 (Swin-T W3A3, 128 images) at its first stage: 56 x 56 tokens, 7 x 7 shifted windows (8192
+    windows of 49 tokens per step), C = 96, 3 heads (swin_attention_and_mlp.py:143-240 / :374-423).  The attention core
+    on integer codes -- 64 x 64 int8 tiles, one window per workgroup -- against the fp32-MFMA GEMMs on the fake-quant
+    values: the same function up to fp32 rounding and the rare level that sits on a rounding tie (norm-wise 1e-3)."""
+    import torch.nn as nn
+    from ofq_amd.quantization.modules import qlinear as ql
+    from ofq_amd.quantization.modules.swin_attention_and_mlp import QAttention_swin, QAttention_swin_qkreparam
+    from ofq_amd.swin import ShiftedWindowAttention
+    torch.manual_seed(23)
+    Bq, Hh, C, heads = 128, 56, 96, 3
+    m = ShiftedWindowAttention(C, [7, 7], [3, 3], heads)
+    cls = QAttention_swin_qkreparam if qkr else QAttention_swin
+    q = cls(m=m, weight_bits=3, input_bits=3, pretrained_initialized=True).cuda().train()
+    x = torch.randn(Bq, Hh, Hh, C, device="cuda")
+    with torch.no_grad():
+        q(x)
+        for n, p in q.named_parameters():
+            if "move_" in n:
+                p.uniform_(-0.05, 0.05)
+    w = torch.randn(Bq, Hh, Hh, C, device="cuda")
+
+    def run():
+        for p in q.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = q(xg)[0]
+        (y * w).sum().backward()
+        return {"y": y.detach().clone(), "dx": xg.grad.clone(), **{n: p.grad.clone() for n, p in q.named_parameters()
+                                                                  if p.grad is not None}}
+    codes = run()
+    ql.USE_CODE_GEMM = False
+    try:
+        fp32 = run()
+    finally:
+        ql.USE_CODE_GEMM = True
+    assert codes.keys() == fp32.keys() and len(codes) > 10
+    off_scale = max(float(v.double().norm()) for n, v in fp32.items() if "move_" in n)
+    for n in codes:
+        a, b = codes[n].double(), fp32[n].double()
+        den = off_scale if "move_" in n else float(b.norm())
+        e = float((a - b).norm()) / den
+        assert e < (5e-3 if n.endswith(".s") else 1e-3), (n, e)

@@ -313,3 +313,27 @@ def test_train_cli_two_steps_save_resume_and_validate(tmp_path):
     # on either side.  Tie-free parity of the eval forward is pinned at 1e-3 by tests/test_modules_gpu.py (g7 eval_logits).
     dev_logits = float((own.cpu().double() - logits.double()).norm() / logits.double().norm())
     assert dev_logits < 0.5 and got["loss"] == pytest.approx(want_loss, rel=2e-2), (dev_logits, got["loss"], want_loss)
+
+
+def test_fused_adamw_keeps_one_step_count_per_tensor():
+    """torch.optim.AdamW advances `step` per tensor: a parameter without a gradient in some step keeps its own count and
+    bias corrections (train.py:662 -> timm create_optimizer_v2 -> torch AdamW).  FusedAdamW must do the same -- it groups
+    the tensors of a param group by their count and launches each class with its own scalars."""
+    from ofq_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    a0, b0 = torch.randn(300, device="cuda"), torch.randn(17, 5, device="cuda")
+    pa, pb = [torch.nn.Parameter(a0.clone()) for _ in range(2)], [torch.nn.Parameter(b0.clone()) for _ in range(2)]
+    opts = [FusedAdamW([pa[0], pb[0]], lr=1e-2, weight_decay=0.05),
+            torch.optim.AdamW([pa[1], pb[1]], lr=1e-2, weight_decay=0.05)]
+    for step in range(5):
+        ga, gb = torch.randn_like(a0), torch.randn_like(b0)
+        for k, opt in enumerate(opts):
+            pa[k].grad = ga.clone()
+            pb[k].grad = None if step in (1, 2) else gb.clone()       # b sits out two steps
+            opt.step()
+    assert float(opts[0].state[pa[0]]["step"]) == 5 and float(opts[0].state[pb[0]]["step"]) == 3
+    assert float(opts[1].state[pb[1]]["step"]) == 3
+    for x, y in ((pa[0], pa[1]), (pb[0], pb[1])):
+        assert float((x - y).abs().max()) < 2e-6 * float(y.abs().max())
+    for key in ("exp_avg", "exp_avg_sq"):
+        assert torch.allclose(opts[0].state[pb[0]][key], opts[1].state[pb[1]][key], rtol=1e-5, atol=1e-8)
