@@ -203,6 +203,18 @@ int ofq_qattn_scores_i8(const int8_t* xcodes, const int8_t* qcodes, float* S, co
 int ofq_qattn_scores_plain_i8(const int8_t* qcodes, const int8_t* kcodes, float* S, const float* sq, float gscale_q,
                               const float* sk, float gscale_k, const float* u, const float* tq, const float* z,
                               int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream);
+
+/*  Scores GEMM + softmax + unsigned LSQ of the probabilities in one kernel (attention.py:96-99 / :207-216): the score
+ *  matrix never goes to HBM.  acodes / bcodes and the epilogue terms as in ofq_qattn_scores_i8 (plain = 0: x codes [B][N][CK],
+ *  qkx codes [B][N][H][CK], sb one step per (token, head)) or ofq_qattn_scores_plain_i8 (plain = 1: q / k codes [B][N][H*CK],
+ *  CK = head dim, sb per token); softmax arguments as in ofq_softmax_lsq_fwd.  Outputs: prob fp32 [B][H][N][ld] (kept for
+ *  the backward), codes uint8 [B][H][N][ld], rowsum [B][H][N] (row sums of the codes).  N <= 256, ld <= 256, ld % 4 == 0. */
+int ofq_qattn_scores_softmax_i8(const int8_t* acodes, const int8_t* bcodes, const float* sa, float gscale_a, const float* sb,
+                                float gscale_b, const float* u, const float* tq, const float* z, int plain, const float* sm_s,
+                                float sm_gscale, float alpha, int hi, const float* addend, int64_t add_period, float* prob,
+                                uint8_t* codes, float* rowsum, int64_t B, int64_t H, int64_t N, int64_t CK, int64_t ld,
+                                ofq_stream_t stream);
+
 int ofq_qattn_dq_plain_bf16s(const float* dS, const int8_t* kcodes, float* dq, const float* sk, float gscale_k,
                              int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldS, ofq_stream_t stream);
 int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, float* dk, const float* sq, float gscale_q,

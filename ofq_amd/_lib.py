@@ -56,6 +56,8 @@ SIGNATURES = {
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_scores_plain_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_scores_softmax_i8": (i32, [vp, vp, vp, f32, vp, f32, vp, vp, vp, i32, vp, f32, f32, i32, vp, i64, vp, vp, vp,
+                                          i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dq_plain_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dk_plain_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_pv_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, i64, i64, i64, i64, i64, vp]),

@@ -55,6 +55,16 @@ __device__ __forceinline__ float ofq_lsq_level_exact(float x, float a, float lo,
   return rintf(fminf(fmaxf(ofq_div(x, a), lo), hi));
 }
 
+// Correctly rounded x / d from the correctly rounded reciprocal rd = fl(1 / d): q0 = fl(x * rd), then two residual
+// corrections q <- fma(fma(-d, q, x), rd, q) -- the tail of the hardware's own division expansion with an exact reciprocal
+// in place of its refined estimate.  Valid while nothing under- or overflows (callers' operands are O(1e-30 .. 1e30)).
+__device__ __forceinline__ float ofq_div_by_rcp(float x, float d, float rd) {
+  float q = __fmul_rn(x, rd);
+  q = __fmaf_rn(__fmaf_rn(-d, q, x), rd, q);
+  q = __fmaf_rn(__fmaf_rn(-d, q, x), rd, q);
+  return q;
+}
+
 // One element of the LSQ backward (lsq.py:593-601 under autograd): v = xin / a, q = rint(clamp(v)),
 // dq = in_range ? (g * a) / a : 0 (the reference's own operation order), dsc = g * (in_range ? q - v : q).
 __device__ __forceinline__ void ofq_lsq_bwd_exact(float xin, float g, float a, float lo, float hi, float& dq, float& dsc) {

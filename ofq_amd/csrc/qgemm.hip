@@ -201,93 +201,96 @@ __device__ unsigned long long g_i8_dbg[8];          // phase timestamps of one m
 // Shared by the forward kernel and by the backward kernel that recomputes a layer output from the codes.
 // T = 2: 128 x 128 tile (each of the 2 x 2 waves owns 64 x 64 = 2 x 2 MFMA blocks); T = 1: 64 x 64 tile (one 32 x 32 block per
 // wave) for the 49-token Swin windows, where a 128 x 128 tile is 85 % padding.
-template <int T>
-__device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned char* A, const unsigned char* B, int m0, int n0,
-                                            unsigned char (*smem)[(128 * T) * QI8_LD], i32x16 (&acc)[T][T]) {
-  constexpr int BM = 64 * T, BN = 64 * T;
+// General form: the workgroup tile is (64 CA) x (64 CB) (CA / CB = 16-byte chunks per thread and k-step of the A / B operand),
+// its four waves are arranged WGM x (4 / WGM), each owning MI x NJ MFMA blocks of 32 x 32.
+template <int CA, int CB, int WGM, int MI, int NJ>
+__device__ __forceinline__ void i8_mainloop_g(const QGemmArgs& p, const unsigned char* A, const unsigned char* B, int m0, int n0,
+                                              unsigned char (*smem)[(64 * CA + 64 * CB) * QI8_LD], i32x16 (&acc)[MI][NJ]) {
+  constexpr int BM = 64 * CA, BN = 64 * CB, WGN = 4 / WGM;
+  static_assert(WGM * 32 * MI == BM && WGN * 32 * NJ == BN, "wave layout does not tile the workgroup tile");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int K = p.K;
   const int nkt = (K + QI8_BK - 1) / QI8_BK;
 
-  // staging: BM rows x 64 B per operand = 4 * BM x 16 B -> T chunks per thread per operand
-  int64_t offA[T], offB[T];
-  bool okA[T], okB[T];
-  int kq[T];
+  // staging: rows x 64 B per operand = 4 * rows x 16 B -> CA / CB chunks per thread (chunk i of a thread: row (tid + 256 i) / 4,
+  // the same 16-byte column kq for every i)
+  int64_t offA[CA], offB[CB];
+  bool okA[CA], okB[CB];
+  const int kq = (tid & 3) * 16;
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int f = tid + 256 * i;
-    const int row = f >> 2;
-    kq[i] = (f & 3) * 16;
+  for (int i = 0; i < CA; ++i) {
+    const int row = (tid + 256 * i) >> 2;
     okA[i] = (m0 + row) < p.M;
+    offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + kq;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int row = (tid + 256 * i) >> 2;
     okB[i] = (n0 + row) < p.N;
-    offA[i] = (int64_t)min(m0 + row, p.M - 1) * p.lda + kq[i];
-    offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + kq[i];
+    offB[i] = (int64_t)min(n0 + row, p.N - 1) * p.ldb + kq;
   }
   // Two register slots: the loads of tile kt+3 are issued behind the staging of tile kt+1 and are first touched (masked)
   // two k-steps later, so a k-step never waits for the HBM / L2 latency of its own loads (k-steps are only 8 MFMAs
   // long here).  The loop body is branch-free (tiles past the end repeat the last one into a stage nobody reads): guards
   // around the loads make the compiler's wait-count pass wait for every outstanding load at each k-step.
-  i32x4 ra[2][T], rb[2][T];
+  i32x4 ra[2][CA], rb[2][CB];
   const int klast = nkt - 1;
   const bool nomask = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (K % QI8_BK) == 0;
   auto gload = [&](int kt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
     const int k0 = kt * QI8_BK;
+    const bool kin = (k0 + kq) < K;                      // K % 16 == 0 (host check): a chunk is all in or all out
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
-      const bool kin = (k0 + kq[i]) < K;                 // K % 16 == 0 (host check): a chunk is all in or all out
-      ra[sl][i] = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq[i]));
-      rb[sl][i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq[i]));
-    }
+    for (int i = 0; i < CA; ++i) ra[sl][i] = *reinterpret_cast<const i32x4*>(A + offA[i] + (kin ? k0 : -kq));
+#pragma unroll
+    for (int i = 0; i < CB; ++i) rb[sl][i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kin ? k0 : -kq));
   };
   auto lstore = [&](unsigned char* sb, int kt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
 #pragma unroll
-    for (int i = 0; i < T; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rb[sl][i]));
+    for (int i = 0; i < CA; ++i) asm volatile("" : "+v"(ra[sl][i]));
+#pragma unroll
+    for (int i = 0; i < CB; ++i) asm volatile("" : "+v"(rb[sl][i]));
     const int k0 = kt * QI8_BK;
     if (nomask) {      // interior tile, no k tail (every tile of the DeiT-S shapes): 16 v_and + the mask selects per k-step gone
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        const int row = (tid + 256 * i) >> 2;
-        *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i];
-        *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i];
-      }
-    } else {
+      for (int i = 0; i < CA; ++i) *reinterpret_cast<i32x4*>(&sb[((tid + 256 * i) >> 2) * QI8_LD + kq]) = ra[sl][i];
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        const int f = tid + 256 * i;
-        const int row = f >> 2;
-        const bool kin = (k0 + kq[i]) < K;
-        const int ma = (okA[i] && kin) ? -1 : 0, mb = (okB[i] && kin) ? -1 : 0;
-        *reinterpret_cast<i32x4*>(&sb[row * QI8_LD + kq[i]]) = ra[sl][i] & ma;
-        *reinterpret_cast<i32x4*>(&sb[(BM + row) * QI8_LD + kq[i]]) = rb[sl][i] & mb;
-      }
+      for (int i = 0; i < CB; ++i) *reinterpret_cast<i32x4*>(&sb[(BM + ((tid + 256 * i) >> 2)) * QI8_LD + kq]) = rb[sl][i];
+    } else {
+      const bool kin = (k0 + kq) < K;
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        *reinterpret_cast<i32x4*>(&sb[((tid + 256 * i) >> 2) * QI8_LD + kq]) = ra[sl][i] & ((okA[i] && kin) ? -1 : 0);
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        *reinterpret_cast<i32x4*>(&sb[(BM + ((tid + 256 * i) >> 2)) * QI8_LD + kq]) = rb[sl][i] & ((okB[i] && kin) ? -1 : 0);
     }
   };
 
 #pragma unroll
-  for (int i = 0; i < T; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < T; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
   auto compute = [&](const unsigned char* sb) {
-    const unsigned char* a = &sb[(wm * 32 * T + l31) * QI8_LD + lh * 16];
-    const unsigned char* b = &sb[(BM + wn * 32 * T + l31) * QI8_LD + lh * 16];
+    const unsigned char* a = &sb[(wm * 32 * MI + l31) * QI8_LD + lh * 16];
+    const unsigned char* b = &sb[(BM + wn * 32 * NJ + l31) * QI8_LD + lh * 16];
 #pragma unroll
     for (int ks = 0; ks < QI8_BK / 32; ++ks) {
-      i32x4 av[T], bv[T];
+      i32x4 av[MI], bv[NJ];
 #pragma unroll
-      for (int i = 0; i < T; ++i) av[i] = *reinterpret_cast<const i32x4*>(a + i * 32 * QI8_LD + ks * 32);
+      for (int i = 0; i < MI; ++i) av[i] = *reinterpret_cast<const i32x4*>(a + i * 32 * QI8_LD + ks * 32);
 #pragma unroll
-      for (int j = 0; j < T; ++j) bv[j] = *reinterpret_cast<const i32x4*>(b + j * 32 * QI8_LD + ks * 32);
+      for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const i32x4*>(b + j * 32 * QI8_LD + ks * 32);
 #pragma unroll
-      for (int i = 0; i < T; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -316,6 +319,13 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
     if (kt < nkt) step(kt, smem[0], smem[1], Slot1());
   }
 #endif
+}
+
+// square form used by the GEMM kernels: 64 T x 64 T tile, 2 x 2 waves of T x T blocks
+template <int T>
+__device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned char* A, const unsigned char* B, int m0, int n0,
+                                            unsigned char (*smem)[(128 * T) * QI8_LD], i32x16 (&acc)[T][T]) {
+  i8_mainloop_g<T, T, 2, T, T>(p, A, B, m0, n0, smem, acc);
 }
 
 // EPI 0: linear layer   1: QKR attention scores   2: P*V

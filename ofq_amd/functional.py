@@ -569,6 +569,78 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
         return dS, ds, None, None, None, None, dadd
 
 
+FUSE_SCORES_SOFTMAX = os.environ.get("OFQ_NO_SCORES_SOFTMAX_FUSE") is None
+
+
+class ScoresSoftmaxCodesFn(torch.autograd.Function):
+    """QKRScoresCodesFn / QKScoresCodesFn followed by SoftmaxLsqCodesFn as ONE forward kernel (ofq_qattn_scores_softmax_i8):
+    the score matrix stays in LDS between the int8 GEMM and the softmax, only prob (for the backward), the P codes and their
+    row sums are written.  The backward is the unfused pair's: softmax-LSQ backward on the saved prob, then the two
+    bf16-split GEMMs of the scores.  aux["plain"]: plain attention (q / k codes per head) instead of QKR (x / qkx codes)."""
+
+    @staticmethod
+    def forward(ctx, a_carrier, b_carrier, s, aux, addend=None):
+        plain = aux["plain"]
+        H = aux["H"]
+        if plain:
+            B, N, C = a_carrier.shape
+            CK = C // H
+            eye = torch.eye(H, device=a_carrier.device, dtype=torch.float32).repeat_interleave(CK, dim=1)
+            u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), eye * aux["bk"])
+            tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), eye * aux["bq"])
+            z = (aux["bq"] * aux["bk"]).view(H, CK).sum(1)
+            ac, bc, sa, ga, sb, gb = aux["qcodes"], aux["kcodes"], aux["sq"], aux["gq"], aux["sk"], aux["gk"]
+        else:
+            B, N, C = a_carrier.shape
+            CK = C
+            baq2 = aux["baq"].view(H, C)
+            u = ops.rowdot_i8_multi(aux["xcodes"].view(B * N, C), baq2)
+            tq = ops.rowdot_i8(aux["qcodes"].view(B * N * H, C), aux["bax"])
+            z = torch.mv(baq2, aux["bax"])
+            ac, bc, sa, ga, sb, gb = aux["xcodes"], aux["qcodes"], aux["sx"], aux["gx"], aux["sq"], aux["gq"]
+        Np = pad16(N)
+        prob, codes, rsum = ops.qattn_scores_softmax(ac, bc, sa, ga, sb, gb, u, tq, z, plain, s, aux["alpha"], aux["hi"],
+                                                     B, H, N, CK, Np, addend=addend)
+        ctx.save_for_backward(prob, s)
+        ctx.addend = addend
+        ctx.aux = aux
+        ctx.dims = (B, H, N, C, Np)
+        ctx.mark_non_differentiable(codes, rsum)
+        ctx.set_materialize_grads(False)
+        return ops.placeholder((B, H, N, Np), prob.device), codes, rsum
+
+    @staticmethod
+    def backward(ctx, g, _gc, _gr):
+        if g is None:
+            return None, None, None, None, None
+        prob, s = ctx.saved_tensors
+        aux = ctx.aux
+        B, H, N, C, Np = ctx.dims
+        rows, alpha, hi = B * H * N, aux["alpha"], aux["hi"]
+        g = g.contiguous()
+        dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, rows, inplace=True, want_rowsum=True)
+        dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[4]) else None
+        if aux["plain"]:
+            d = C // H
+            da = ops.qattn_dq_plain(dS, aux["kcodes"], aux["sk"], aux["gk"], B, H, N, d, Np)
+            db = ops.qattn_dk_plain(dS, aux["qcodes"], aux["sq"], aux["gq"], aux["bq"], B, H, N, d, Np)
+            if KEEP_ZERO_ROWSUM_TERM:
+                da.view(B, N, H, d).add_(rs.view(B, H, N, 1).permute(0, 2, 1, 3) * aux["bk"].view(1, 1, H, d))
+            return da, db, ds, None, dadd
+        db = ops.qattn_dqkx(dS, aux["xcodes"], aux["sx"], aux["gx"], aux["bax"], B, H, N, C, Np)
+        dxq, accumulate, ret = _shared_grad(aux.get("xgrad_acc"), (B, N, C), dS.device)
+        ops.qattn_dxq(dS, aux["qcodes"], aux["sq"], aux["gq"], B, H, N, C, Np, out=dxq, accumulate=accumulate)
+        if KEEP_ZERO_ROWSUM_TERM:
+            dxq.view(B * N, C).addmm_(rs.view(B, H, N).permute(0, 2, 1).reshape(B * N, H), aux["baq"].view(H, C))
+        return ret, db, ds, None, dadd
+
+
+def scores_softmax_fusable(N):
+    """The fused kernel holds a 64 x 256 score panel: every key of a row must fit (N <= 256); for the 49-token Swin windows
+    three quarters of that panel would be padding, so they keep the separate 64 x 64 kernels."""
+    return FUSE_SCORES_SOFTMAX and 64 < N <= 256 and pad16(N) <= 256
+
+
 class PVCodesFn(torch.autograd.Function):
     """O = P_hat @ V_hat per head on the codes: P_hat = ap*qp, V_hat = av*qv + bav."""
 

@@ -488,6 +488,22 @@ def qattn_scores_plain(qcodes, kcodes, sq, gq, sk, gk, u, tq, z, B, H, N, d, ldS
     return S
 
 
+def qattn_scores_softmax(acodes, bcodes, sa, ga, sb, gb, u, tq, z, plain, sm_s, alpha, hi, B, H, N, CK, ld, addend=None):
+    """Scores GEMM + softmax + LSQ of the probabilities in one kernel; returns (prob fp32, codes uint8, code row sums)."""
+    dev = acodes.device
+    prob = torch.empty((B, H, N, ld), dtype=torch.float32, device=dev)
+    codes = torch.empty((B, H, N, ld), dtype=torch.uint8, device=dev)
+    rsum = torch.empty(B * H * N, dtype=torch.float32, device=dev)
+    gscale = 1.0 / math.sqrt(hi * (B * H * N))
+    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * CK):
+        _chk(lib().ofq_qattn_scores_softmax_i8(acodes.data_ptr(), bcodes.data_ptr(), sa.data_ptr(), ga, sb.data_ptr(), gb,
+                                               u.data_ptr(), tq.data_ptr(), z.data_ptr(), int(plain), sm_s.data_ptr(), gscale,
+                                               alpha, int(hi), _p(addend), addend.shape[0] if addend is not None else 1,
+                                               prob.data_ptr(), codes.data_ptr(), rsum.data_ptr(), B, H, N, CK, ld, _stream()),
+             "ofq_qattn_scores_softmax_i8")
+    return prob, codes, rsum
+
+
 def qattn_dq_plain(dS, kcodes, sk, gk, B, H, N, d, ldS):
     dq = torch.empty((B, N, H * d), dtype=torch.float32, device=dS.device)
     with _Timed('qgemm_bf16s_nn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):

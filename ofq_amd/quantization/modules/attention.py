@@ -16,7 +16,7 @@ from ...deit_vision_transformer import Attention as deit_attention
 from ... import ops
 from ...functional import (LinearFn, WqkFn, QKRScoresFn, QKScoresFn, SoftmaxLsqFn, PVFn, QKVSplitLsqFn, codes_linear,
                            codes_linear_ok, QKRScoresCodesFn, SoftmaxLsqCodesFn, PVCodesFn, QKVSplitLsqCodesFn,
-                           QKScoresCodesFn)
+                           QKScoresCodesFn, ScoresSoftmaxCodesFn, scores_softmax_fusable)
 from . import qlinear as _ql
 
 
@@ -45,6 +45,16 @@ def _fit_addend(addend, S):
     if addend is not None and addend.shape[-1] != S.shape[-1]:
         addend = torch.nn.functional.pad(addend, (0, S.shape[-1] - addend.shape[-1]))
     return None if addend is None else addend.contiguous()
+
+
+def _pad_addend(addend, N):
+    """the (P, N, N) additive term padded to the score row stride the code kernels use (N rounded up to 16)"""
+    if addend is None:
+        return None
+    Np = (N + 15) // 16 * 16
+    if addend.shape[-1] != Np:
+        addend = torch.nn.functional.pad(addend, (0, Np - addend.shape[-1]))
+    return addend.contiguous()
 
 
 def _softmax_lsq(quant, S, N, alpha, addend=None):
@@ -120,13 +130,17 @@ def plain_attention_core(self, x, scale, addend=None):
                                                            self.quan_a_k_fn.s, self.quan_a_v_fn.s, self.move_q_aft.bias,
                                                            self.move_k_aft.bias, self.move_v_aft.bias, gq, gq, gv)   # :71-90
             link = {}
-            S = QKScoresCodesFn.apply(q, k, {
-                "qcodes": qc, "kcodes": kc, "sq": self.quan_a_q_fn.s.detach(), "gq": gq.gscale,
-                "sk": self.quan_a_k_fn.s.detach(), "gk": gq.gscale, "bq": self.move_q_aft.bias.detach(),
-                "bk": self.move_k_aft.bias.detach(), "H": H, "link": link})                                           # :96
-            addend = _fit_addend(addend, S)
-            _softmax_init(sm, S, N, scale, addend)
-            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)                      # :97-99
+            saux = {"qcodes": qc, "kcodes": kc, "sq": self.quan_a_q_fn.s.detach(), "gq": gq.gscale,
+                    "sk": self.quan_a_k_fn.s.detach(), "gk": gq.gscale, "bq": self.move_q_aft.bias.detach(),
+                    "bk": self.move_k_aft.bias.detach(), "H": H, "link": link}
+            if scores_softmax_fusable(N) and sm.initialized_alpha and sm.s is not None:
+                saux.update(plain=True, alpha=scale, hi=sm.thd_pos)
+                P, pcodes, rp = ScoresSoftmaxCodesFn.apply(q, k, sm.s, saux, _pad_addend(addend, N))                 # :96-99
+            else:
+                S = QKScoresCodesFn.apply(q, k, saux)                                                                 # :96
+                addend = _fit_addend(addend, S)
+                _softmax_init(sm, S, N, scale, addend)
+                P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)                  # :97-99
             gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
             return PVCodesFn.apply(P, v, {
                 "pcodes": pcodes, "rp": rp, "vcodes": vc, "sp": sm.s.detach(), "gp": gp,
@@ -268,14 +282,18 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
                                                           pre_codes=None if qspec is None else qspec.get("codes_out"),
                                                           fused=qspec)
             link = {}
-            S = QKRScoresCodesFn.apply(xq, qkx, {
-                "xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,
-                "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
-                "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link, "xgrad_acc": xacc})   # :210
+            saux = {"xcodes": xcodes, "qcodes": qcodes, "sx": xin.input_quant_fn.s.detach(), "gx": xgeom.gscale,
+                    "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
+                    "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link, "xgrad_acc": xacc}
             sm = self.quan_a_softmax_fn
-            addend = _fit_addend(addend, S)
-            _softmax_init(sm, S, N, scale, addend)
-            P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)   # :213-216
+            if scores_softmax_fusable(N) and sm.initialized_alpha and sm.s is not None:
+                saux.update(plain=False, alpha=scale, hi=sm.thd_pos)
+                P, pcodes, rp = ScoresSoftmaxCodesFn.apply(xq, qkx, sm.s, saux, _pad_addend(addend, N))   # :210-216
+            else:
+                S = QKRScoresCodesFn.apply(xq, qkx, saux)                                                  # :210
+                addend = _fit_addend(addend, S)
+                _softmax_init(sm, S, N, scale, addend)
+                P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)       # :213-216
             gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
             out = PVCodesFn.apply(P, v, {
                 "pcodes": pcodes, "rp": rp, "vcodes": vcodes, "sp": sm.s.detach(), "gp": gp,

@@ -220,7 +220,8 @@ def test_swin_window_attention_full_size_code_path_equals_fp32_gemm_path(ops, qk
         # (here ALL GEMMs of the module switch between integer codes and fp32 -- the qkv / W_qk projections included -- so
         # every one of the module's quantisers sees inputs that differ in the last bits; among 2.5e7 three-bit activations
         # per tensor a few dozen sit on a rounding tie.  Norm-wise bound plus: the differences are confined to few elements.)
-        assert e < 5e-3, (n, e)
+        # (step gradients: sums of g * (q - v) over 2.5e7 elements, where a flipped level moves one term by a whole g)
+        assert e < (2e-2 if n.endswith(".s") else 5e-3), (n, e)
         if "move_" not in n and not n.endswith(".s"):
             visible = float(((a - b).abs() > 1e-2 * float(b.abs().max())).double().mean())
             assert visible < 2e-3, (n, visible)

@@ -785,3 +785,52 @@ def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
     assert rel_err(ds, ds_ref) < 1e-5 and rel_err(db4, db4_ref) < 1e-5 and rel_err(dba, dba_ref) < 1e-5
     # not everything was clipped (the pass-through branch of the straight-through estimator ran)
     assert float((dy == 0).float().mean()) < 0.98
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [("qkr", 3, 6, 198, 384, 2), ("qkr_small", 2, 3, 70, 96, 4), ("plain", 3, 3, 198, 64, 4),
+                                 ("plain_256", 1, 2, 256, 32, 3)])
+def test_fused_scores_softmax_equals_the_two_kernels(ops, cfg):
+    """ofq_qattn_scores_softmax_i8 (score panel kept in LDS) against ofq_qattn_scores(_plain)_i8 followed by
+    ofq_softmax_lsq_fwd (attention.py:96-99 / :207-216): same expressions element for element -- the probabilities agree to
+    the last bits (only the order of the row sum differs), the uint8 codes are identical except where a probability sits on a
+    rounding tie, the code row sums follow the codes."""
+    from ofq_amd.functional import pad16
+    name, B, H, N, CK, bits = cfg
+    plain = name.startswith("plain")
+    g = torch.Generator(device="cuda").manual_seed(N + CK)
+    lo, hi_c = -(2 ** (bits - 1)), 2 ** (bits - 1) - 1
+    Np = pad16(N)
+    if plain:
+        C = H * CK
+        ac = torch.randint(lo, hi_c + 1, (B, N, C), dtype=torch.int8, device="cuda", generator=g)
+        bc = torch.randint(lo, hi_c + 1, (B, N, C), dtype=torch.int8, device="cuda", generator=g)
+        sb = torch.rand(N, device="cuda", generator=g) * 0.2 + 0.05
+        u = torch.randn(B * N, H, device="cuda", generator=g) * 0.1
+        tq = torch.randn(B * N, H, device="cuda", generator=g) * 0.1
+    else:
+        C = CK
+        ac = torch.randint(lo, hi_c + 1, (B, N, C), dtype=torch.int8, device="cuda", generator=g)
+        bc = torch.randint(lo, hi_c + 1, (B, N, H, C), dtype=torch.int8, device="cuda", generator=g)
+        sb = torch.rand(N * H, device="cuda", generator=g) * 0.2 + 0.05
+        u = torch.randn(B * N, H, device="cuda", generator=g) * 0.1
+        tq = torch.randn(B * N * H, device="cuda", generator=g) * 0.1
+    sa = torch.rand(N, device="cuda", generator=g) * 0.2 + 0.05
+    z = torch.randn(H, device="cuda", generator=g) * 0.1
+    sm_s = torch.rand(N, device="cuda", generator=g) * 0.02 + 0.01
+    alpha, hi = CK ** -0.5 if plain else (C // H) ** -0.5, 2 ** bits - 1
+    addend = torch.randn(2, N, Np, device="cuda", generator=g) if name == "qkr_small" else None      # B*H % 2 == 0
+    if plain:
+        S = ops.qattn_scores_plain(ac, bc, sa, 0.01, sb, 0.02, u, tq, z, B, H, N, CK, Np)
+    else:
+        S = ops.qattn_scores(ac, bc, sa, 0.01, sb, 0.02, u, tq, z, B, H, N, C, Np)
+    prob_ref, _, codes_ref, rs_ref = ops.softmax_lsq_fwd(S, sm_s, B * H * N, N, Np, N, alpha, hi, B * H * N, want_codes=True,
+                                                         need_values=False, addend=addend)
+    prob, codes, rs = ops.qattn_scores_softmax(ac, bc, sa, 0.01, sb, 0.02, u, tq, z, plain, sm_s, alpha, hi, B, H, N,
+                                               CK, Np, addend=addend)
+    assert float((prob[..., :N] - prob_ref[..., :N]).abs().max()) < 2e-7
+    assert float(prob[..., N:].abs().max()) == 0.0 if Np > N else True
+    differ = float((codes[..., :N] != codes_ref[..., :N]).float().mean())
+    assert differ < 1e-5, differ
+    assert torch.equal(rs, codes[..., :N].float().sum(-1).reshape(-1))
+    assert float((prob[..., :N].sum(-1) - 1).abs().max()) < 1e-5
