@@ -240,6 +240,13 @@ int ofq_rowdot_f32_seg(const float* x, const float* vec, float* out, int64_t row
 int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t batches, int64_t rows, int64_t cols, int64_t rows_padded,
                            ofq_stream_t stream);
 
+/*  The three operand-preparation jobs of the QKR attention core (attention.py:207-219 on the codes) in one launch:
+ *  u[b][n][h] = xcodes[b][n][:] . baq[h][:], tq[b][m][h] = qcodes[b][m][h][:] . bax[:], vT[b][c][Np] = transpose of
+ *  vcodes[b][N][c] (zero-padded to Np).  Same values as ofq_rowdot_i8_multi / ofq_rowdot_i8 / ofq_codes_transpose_i8. */
+int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, const int8_t* qcodes, const float* bax, float* tq,
+                   const int8_t* vcodes, int8_t* vT, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np, ofq_stream_t stream);
+
+
 /* ---- column sum (bias gradients of F.linear: autograd of qlinear.py:71):  out[c] = sum_r x[r][c] */
 size_t ofq_colsum_ws_bytes(int64_t rows, int64_t cols);
 int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* ws, size_t ws_bytes,

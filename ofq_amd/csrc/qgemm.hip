@@ -2002,10 +2002,10 @@ __global__ __launch_bounds__(256) void rowdot_i8_kernel(const int8_t* __restrict
 }
 
 // same, 16 codes per load: a row is owned by 16 lanes (K % 16 == 0, 16-byte aligned rows)
-__global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vec,
-                                                            float* __restrict__ out, int N, int K) {
+__device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restrict__ codes, const float* __restrict__ vec,
+                                                   float* __restrict__ out, int N, int K) {
   const int l16 = threadIdx.x & 15;
-  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int n = bx * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   if (n < N) {
     const int8_t* row = codes + (int64_t)n * K;
@@ -2023,6 +2023,10 @@ __global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __rest
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (n < N && l16 == 0) out[n] = acc;
+}
+__global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vec,
+                                                            float* __restrict__ out, int N, int K) {
+  rowdot_i8_v16_body(blockIdx.x, codes, vec, out, N, K);
 }
 
 extern "C" int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream) {
@@ -2643,10 +2647,10 @@ __global__ __launch_bounds__(256) void rowdot_i8_multi_kernel(const int8_t* __re
 }
 
 // same, 16 lanes per row and 16 codes per load; the row's codes stay in registers for all V vectors (K <= 512)
-__global__ __launch_bounds__(256) void rowdot_i8_multi_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vecs,
-                                                                  float* __restrict__ out, int R, int K, int V) {
+__device__ __forceinline__ void rowdot_i8_multi_v16_body(int bx, const int8_t* __restrict__ codes, const float* __restrict__ vecs,
+                                                         float* __restrict__ out, int R, int K, int V) {
   const int l16 = threadIdx.x & 15;
-  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int r = bx * 16 + (threadIdx.x >> 4);
   const bool rok = r < R;
   i32x4 c[2];
   bool cok[2];
@@ -2675,6 +2679,10 @@ __global__ __launch_bounds__(256) void rowdot_i8_multi_v16_kernel(const int8_t* 
     if (rok && l16 == 0) out[(int64_t)r * V + v] = acc;
   }
 }
+__global__ __launch_bounds__(256) void rowdot_i8_multi_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vecs,
+                                                                  float* __restrict__ out, int R, int K, int V) {
+  rowdot_i8_multi_v16_body(blockIdx.x, codes, vecs, out, R, K, V);
+}
 
 // out[r][h] = sum_{c<d} x[r][h*d + c] * vec[h*d + c]      (per-head dot of an fp32 row with an offset vector)
 __global__ __launch_bounds__(256) void rowdot_f32_seg_kernel(const float* __restrict__ x, const float* __restrict__ vec,
@@ -2691,13 +2699,12 @@ __global__ __launch_bounds__(256) void rowdot_f32_seg_kernel(const float* __rest
 }
 
 // batched int8 transpose with zero padding: in [B][R][Cc] -> out [B][Cc][Rp]  (V codes for the P*V product)
-__global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out, int R,
-                                                                 int Cc, int Rp) {
-  __shared__ int8_t tile[32][33];
+__device__ __forceinline__ void codes_transpose_i8_body(int bx, int by, int bz, int8_t (*tile)[33], const int8_t* __restrict__ in,
+                                                        int8_t* __restrict__ out, int R, int Cc, int Rp) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int8_t* ib = in + (int64_t)blockIdx.z * R * Cc;
-  int8_t* ob = out + (int64_t)blockIdx.z * Cc * Rp;
+  const int r0 = by * 32, c0 = bx * 32;
+  const int8_t* ib = in + (int64_t)bz * R * Cc;
+  int8_t* ob = out + (int64_t)bz * Cc * Rp;
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
     tile[i][tx] = (r < R && c < Cc) ? ib[(int64_t)r * Cc + c] : (int8_t)0;
@@ -2707,6 +2714,47 @@ __global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* _
     const int c = c0 + i, r = r0 + tx;
     if (c < Cc && r < Rp) ob[(int64_t)c * Rp + r] = tile[tx][i];
   }
+}
+__global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out, int R,
+                                                                 int Cc, int Rp) {
+  __shared__ int8_t tile[32][33];
+  codes_transpose_i8_body(blockIdx.x, blockIdx.y, blockIdx.z, tile, in, out, R, Cc, Rp);
+}
+
+// The three operand-preparation jobs of the QKR attention core in ONE launch: u[b,n,h] = x codes . baq[h] (row dots with H
+// vectors), tq[b,m,h] = qkx codes . bax, and the per-image transpose of the v codes to [C][Np] (B operand of the int8 P.V
+// GEMM).  Each is a small, occupancy-bound kernel (~20 us for 10-60 MB); as ranges of one grid they run side by side.
+struct AttnPrepArgs {
+  const int8_t* xcodes; const float* baq; float* u;          // job 0: [R0 = B*N][C] . [H][C] -> [R0][H]
+  const int8_t* qcodes; const float* bax; float* tq;         // job 1: [R1 = B*N*H][C] . [C] -> [R1]
+  const int8_t* vcodes; int8_t* vT;                          // job 2: [B][N][C] -> [B][C][Np]
+  int R0, R1, C, H, N, Np, nb0, nb1, tx2, ty2;               // nb0 / nb1: blocks of job 0 / 1; job 2 grid: tx2 x ty2 x B
+};
+__global__ __launch_bounds__(256) void qattn_prep_kernel(AttnPrepArgs a) {
+  __shared__ int8_t tile[32][33];
+  int b = blockIdx.x;
+  if (b < a.nb0) { rowdot_i8_multi_v16_body(b, a.xcodes, a.baq, a.u, a.R0, a.C, a.H); return; }
+  b -= a.nb0;
+  if (b < a.nb1) { rowdot_i8_v16_body(b, a.qcodes, a.bax, a.tq, a.R1, a.C); return; }
+  b -= a.nb1;
+  const int bx = b % a.tx2, by = (b / a.tx2) % a.ty2, bz = b / (a.tx2 * a.ty2);
+  codes_transpose_i8_body(bx, by, bz, tile, a.vcodes, a.vT, a.N, a.C, a.Np);
+}
+extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, const int8_t* qcodes, const float* bax, float* tq,
+                              const int8_t* vcodes, int8_t* vT, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np,
+                              ofq_stream_t stream) {
+  if (!xcodes || !baq || !u || !qcodes || !bax || !tq || !vcodes || !vT || B <= 0 || H <= 0 || N <= 0 || Np < N) return OFQ_EINVAL;
+  if ((C & 15) || C > 512 || !al16(xcodes) || !al16(qcodes) || !al16(baq) || !al16(bax) || B * N * H >= (1ll << 31)) return OFQ_EINVAL;
+  AttnPrepArgs a = {};
+  a.xcodes = xcodes; a.baq = baq; a.u = u; a.qcodes = qcodes; a.bax = bax; a.tq = tq; a.vcodes = vcodes; a.vT = vT;
+  a.R0 = (int)(B * N); a.R1 = (int)(B * N * H); a.C = (int)C; a.H = (int)H; a.N = (int)N; a.Np = (int)Np;
+  a.nb0 = (int)ceil_div(B * N, 16); a.nb1 = (int)ceil_div(B * N * H, 16);
+  a.tx2 = (int)ceil_div(C, 32); a.ty2 = (int)ceil_div(Np, 32);
+  const int64_t total = (int64_t)a.nb0 + a.nb1 + (int64_t)a.tx2 * a.ty2 * B;
+  if (total >= (1ll << 31)) return OFQ_EINVAL;
+  hipLaunchKernelGGL(qattn_prep_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int ofq_rowdot_i8_multi(const int8_t* codes, const float* vecs, float* out, int64_t rows, int64_t cols, int nvec,

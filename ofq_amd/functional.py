@@ -103,6 +103,11 @@ class CodesLinearFn(torch.autograd.Function):
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         dx = None
+        fork = None
+        if (DW_SIDE_STREAM and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy2d.shape[1] % 4 == 0
+                and ctx.in_shape[-1] % 16 == 0):
+            fork = torch.cuda.Event()
+            fork.record()                                   # dY is ready here
         link = aux.get("lsq_link")
         if ctx.needs_input_grad[0] and link and "geom" in link and ctx.codes_only:
             # the input quantiser's backward runs in the dX GEMM's epilogue; its four gradients wait in the link for
@@ -124,12 +129,35 @@ class CodesLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and N_out % 4 == 0 and K_in % 16 == 0:
             # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
             # dY also yields the bias gradient (column sums)
-            dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
-                                        aux["act_gscale"], None, aux["baft"], compute_db=True)
+            if fork is not None:
+                cur, side = torch.cuda.current_stream(), _side_stream(dy2d.device)
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
+                                                aux["act_gscale"], None, aux["baft"], compute_db=True)
+                cur.wait_stream(side)
+            else:
+                dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
+                                            aux["act_gscale"], None, aux["baft"], compute_db=True)
         else:
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         return dx, dW, (db if ctx.has_bias else None), None
+
+
+# Experiment (OFQ_DW_SIDE_STREAM=1): the input-gradient GEMM of a linear layer fills 198 of the 256 CUs (25344 token rows =
+# 198 row tiles); the weight-gradient GEMM (255 workgroups) only feeds the optimizer.  dX is queued FIRST on the current
+# stream, dW right behind it on a side stream that waits only for dY (an event recorded before the dX launch), so the dW
+# workgroups can take the 58 idle CUs while dX runs.  (Queued the other way round dW fills the chip and nothing overlaps.)
+DW_SIDE_STREAM = os.environ.get("OFQ_DW_SIDE_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device.index)
+    if st is None:
+        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return st
 
 
 def codes_only_ok(in_features, out_features):
@@ -570,6 +598,7 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
 
 
 FUSE_SCORES_SOFTMAX = os.environ.get("OFQ_NO_SCORES_SOFTMAX_FUSE") is None
+ATTN_PREP = os.environ.get("OFQ_NO_ATTN_PREP") is None          # u, tq, v^T in one launch (A/B switch)
 
 
 class ScoresSoftmaxCodesFn(torch.autograd.Function):
@@ -594,8 +623,14 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
             B, N, C = a_carrier.shape
             CK = C
             baq2 = aux["baq"].view(H, C)
-            u = ops.rowdot_i8_multi(aux["xcodes"].view(B * N, C), baq2)
-            tq = ops.rowdot_i8(aux["qcodes"].view(B * N * H, C), aux["bax"])
+            vlink = aux.get("vlink")
+            if ATTN_PREP and vlink is not None and C <= 512 and baq2.is_contiguous() and aux["bax"].is_contiguous():
+                # u, tq and the transposed v codes (for the P.V GEMM that follows) in one launch
+                u, tq, vlink["vT"] = ops.qattn_prep(aux["xcodes"], baq2, aux["qcodes"], aux["bax"], vlink["vcodes"], B, H, N, C,
+                                                    pad16(N))
+            else:
+                u = ops.rowdot_i8_multi(aux["xcodes"].view(B * N, C), baq2)
+                tq = ops.rowdot_i8(aux["qcodes"].view(B * N * H, C), aux["bax"])
             z = torch.mv(baq2, aux["bax"])
             ac, bc, sa, ga, sb, gb = aux["xcodes"], aux["qcodes"], aux["sx"], aux["gx"], aux["sq"], aux["gq"]
         Np = pad16(N)
@@ -649,7 +684,9 @@ class PVCodesFn(torch.autograd.Function):
         B, H, N, Np = P.shape
         C = v.shape[2]
         d = C // H
-        vT = ops.codes_transpose_i8(aux["vcodes"].view(B, N, C), Np)
+        vT = aux.pop("vT", None)                    # prepared together with u / tq (ScoresSoftmaxCodesFn) ...
+        if vT is None:
+            vT = ops.codes_transpose_i8(aux["vcodes"].view(B, N, C), Np)
         O = ops.qattn_pv(aux["pcodes"], vT, aux["sp"], aux["gp"], aux["sv"], aux["gv"], aux["bav"], aux["rp"], B, H, N, d, Np)
         ctx.aux = aux
         ctx.dims = (B, H, N, d, Np)

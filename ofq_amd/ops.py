@@ -470,6 +470,18 @@ def codes_transpose_i8(codes3d, rows_padded):
     return out
 
 
+def qattn_prep(xcodes, baq2, qcodes, bax, vcodes, B, H, N, C, Np):
+    """u, tq and the transposed v codes of the QKR attention core in one launch (same values as rowdot_i8_multi /
+    rowdot_i8 / codes_transpose_i8)."""
+    dev = xcodes.device
+    u = torch.empty((B * N, H), dtype=torch.float32, device=dev)
+    tq = torch.empty(B * N * H, dtype=torch.float32, device=dev)
+    vT = torch.empty((B, C, Np), dtype=torch.int8, device=dev)
+    _chk(lib().ofq_qattn_prep(xcodes.data_ptr(), baq2.data_ptr(), u.data_ptr(), qcodes.data_ptr(), bax.data_ptr(), tq.data_ptr(),
+                              vcodes.data_ptr(), vT.data_ptr(), B, H, N, C, Np, _stream()), "ofq_qattn_prep")
+    return u, tq, vT
+
+
 def qattn_scores(xcodes, qcodes, sx, gx, sq, gq, u, tq, z, B, H, N, C, ldS):
     S = torch.empty((B, H, N, ldS), dtype=torch.float32, device=xcodes.device)
     with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * C):

@@ -286,8 +286,9 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
                     "sq": self.quan_a_qkx_fn.s.detach(), "gq": qgeom.gscale, "bax": xin.move_aft.bias.detach(),
                     "baq": self.move_qkx_aft.bias.detach(), "H": H, "link": link, "xgrad_acc": xacc}
             sm = self.quan_a_softmax_fn
+            pv_aux = {"vcodes": vcodes}
             if scores_softmax_fusable(N) and sm.initialized_alpha and sm.s is not None:
-                saux.update(plain=False, alpha=scale, hi=sm.thd_pos)
+                saux.update(plain=False, alpha=scale, hi=sm.thd_pos, vlink=pv_aux)
                 P, pcodes, rp = ScoresSoftmaxCodesFn.apply(xq, qkx, sm.s, saux, _pad_addend(addend, N))   # :210-216
             else:
                 S = QKRScoresCodesFn.apply(xq, qkx, saux)                                                  # :210
@@ -295,9 +296,9 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
                 _softmax_init(sm, S, N, scale, addend)
                 P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)       # :213-216
             gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
-            out = PVCodesFn.apply(P, v, {
-                "pcodes": pcodes, "rp": rp, "vcodes": vcodes, "sp": sm.s.detach(), "gp": gp,
-                "sv": self.quan_a_v_fn.s.detach(), "gv": vgeom.gscale, "bav": self.move_v_aft.bias.detach()})   # :219
+            pv_aux.update(pcodes=pcodes, rp=rp, sp=sm.s.detach(), gp=gp, sv=self.quan_a_v_fn.s.detach(), gv=vgeom.gscale,
+                          bav=self.move_v_aft.bias.detach())
+            out = PVCodesFn.apply(P, v, pv_aux)                                                              # :219
         return out
 
 

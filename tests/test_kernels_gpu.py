@@ -834,3 +834,23 @@ def test_fused_scores_softmax_equals_the_two_kernels(ops, cfg):
     assert differ < 1e-5, differ
     assert torch.equal(rs, codes[..., :N].float().sum(-1).reshape(-1))
     assert float((prob[..., :N].sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_attention_prep_launch_equals_the_three_kernels(ops):
+    """ofq_qattn_prep (u, tq and the transposed v codes as three block ranges of one launch) against ofq_rowdot_i8_multi,
+    ofq_rowdot_i8 and ofq_codes_transpose_i8: the same device code, so bit-identical outputs (attention.py:207-219 operands)."""
+    from ofq_amd.functional import pad16
+    B, H, N, C = 3, 6, 198, 384
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xc = torch.randint(-2, 2, (B, N, C), dtype=torch.int8, device="cuda", generator=g)
+    qc = torch.randint(-2, 2, (B, N, H, C), dtype=torch.int8, device="cuda", generator=g)
+    vc = torch.randint(-2, 2, (B, N, C), dtype=torch.int8, device="cuda", generator=g)
+    baq = torch.randn(H, C, device="cuda", generator=g)
+    bax = torch.randn(C, device="cuda", generator=g)
+    Np = pad16(N)
+    u, tq, vT = ops.qattn_prep(xc, baq, qc, bax, vc, B, H, N, C, Np)
+    assert torch.equal(u, ops.rowdot_i8_multi(xc.view(B * N, C), baq))
+    assert torch.equal(tq, ops.rowdot_i8(qc.view(B * N * H, C), bax))
+    assert torch.equal(vT, ops.codes_transpose_i8(vc, Np))
+    assert torch.equal(vT[:, :, :N], vc.transpose(1, 2)) and int(vT[:, :, N:].abs().max()) == 0

@@ -2,7 +2,7 @@
 set -u
 O=gpurun_out/r02k; mkdir -p $O
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "fused_scores" > $O/kernel_tests.txt 2>&1; echo "kernel tests rc=$?"
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "fused_scores or attention_prep" > $O/kernel_tests.txt 2>&1; echo "kernel tests rc=$?"
 tail -15 $O/kernel_tests.txt | cut -c1-300
 timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1; echo "gpu tests rc=$?"
 tail -12 $O/gpu_tests.txt | cut -c1-300
@@ -15,10 +15,10 @@ try:
 except Exception as e: print("$1 failed", e); print(open("$O/$1.err").read()[-1500:])
 PY
 }
-run fused "A=1" ""
-run unfused "OFQ_NO_SCORES_SOFTMAX_FUSE=1" ""
-run fused2 "A=1" ""
-run unfused2 "OFQ_NO_SCORES_SOFTMAX_FUSE=1" ""
+run prep "A=1" ""
+run noprep "OFQ_NO_ATTN_PREP=1" ""
+run prep2 "A=1" ""
+run noprep2 "OFQ_NO_ATTN_PREP=1" ""
 C2="--model deit_tiny_distilled_patch16_224 --wbits 4 --abits 4 --no-qkr --batch-per-gpu 256"
 run c2_fused "A=1" "$C2"
 run c2_unfused "OFQ_NO_SCORES_SOFTMAX_FUSE=1" "$C2"
