@@ -103,11 +103,6 @@ class CodesLinearFn(torch.autograd.Function):
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         dx = None
-        fork = None
-        if (DW_SIDE_STREAM and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy2d.shape[1] % 4 == 0
-                and ctx.in_shape[-1] % 16 == 0):
-            fork = torch.cuda.Event()
-            fork.record()                                   # dY is ready here
         link = aux.get("lsq_link")
         if ctx.needs_input_grad[0] and link and "geom" in link and ctx.codes_only:
             # the input quantiser's backward runs in the dX GEMM's epilogue; its four gradients wait in the link for
@@ -129,35 +124,12 @@ class CodesLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and N_out % 4 == 0 and K_in % 16 == 0:
             # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
             # dY also yields the bias gradient (column sums)
-            if fork is not None:
-                cur, side = torch.cuda.current_stream(), _side_stream(dy2d.device)
-                side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
-                                                aux["act_gscale"], None, aux["baft"], compute_db=True)
-                cur.wait_stream(side)
-            else:
-                dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
-                                            aux["act_gscale"], None, aux["baft"], compute_db=True)
+            dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
+                                        aux["act_gscale"], None, aux["baft"], compute_db=True)
         else:
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         return dx, dW, (db if ctx.has_bias else None), None
-
-
-# Experiment (OFQ_DW_SIDE_STREAM=1): the input-gradient GEMM of a linear layer fills 198 of the 256 CUs (25344 token rows =
-# 198 row tiles); the weight-gradient GEMM (255 workgroups) only feeds the optimizer.  dX is queued FIRST on the current
-# stream, dW right behind it on a side stream that waits only for dY (an event recorded before the dX launch), so the dW
-# workgroups can take the 58 idle CUs while dX runs.  (Queued the other way round dW fills the chip and nothing overlaps.)
-DW_SIDE_STREAM = os.environ.get("OFQ_DW_SIDE_STREAM", "0") == "1"
-_side_streams = {}
-
-
-def _side_stream(device):
-    st = _side_streams.get(device.index)
-    if st is None:
-        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
-    return st
 
 
 def codes_only_ok(in_features, out_features):
