@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured step with more than one rank as well (default there: eager launches; the capture "
                          "of RCCL collectives is validated with one rank only, tests/test_graph_gpu.py)")
+    ap.add_argument("--stock-teacher", action="store_true",
+                    help="with --with-teacher: run the teacher through stock PyTorch-ROCm (hipBLASLt) instead of the HIP kernels")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -243,6 +245,9 @@ def main():
         teacher = create_model(args.model, num_classes=1000).to(dev)
         for p_ in teacher.parameters():
             p_.requires_grad_(False)
+        if not args.stock_teacher:                  # the same forward on the HIP kernels (ofq_amd/teacher.py)
+            from ofq_amd.teacher import HipTeacher
+            teacher = HipTeacher(teacher)
 
     def soft_targets():
         if teacher is None:
@@ -354,7 +359,8 @@ def main():
                                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
                                          " + CGA hooks" if args.cga else "", B,
                                          "7x7 windows" if args.model.startswith("swin") else "198 tokens",
-                                         "fp32 teacher forward in the step" if args.with_teacher else "teacher logits synthetic"),
+                                         ("fp32 teacher forward in the step (%s)" % ("stock PyTorch-ROCm" if args.stock_teacher else "HIP kernels"))
+                                         if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
                           "launch": "hipGraph replay" if use_graph else "eager (one ctypes launch per kernel)",
                           "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},

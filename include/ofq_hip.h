@@ -313,6 +313,11 @@ int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, flo
 /*  W = W*(1-frozen) + saved               (after optimizer.step) */
 int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n, ofq_stream_t stream);
 
+/* ---- exact (erf) GELU, y = gelu(x) elementwise (x may alias y): activation of the fp32 KD teacher's MLP
+ *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
+ *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
+int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

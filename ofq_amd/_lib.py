@@ -88,6 +88,7 @@ SIGNATURES = {
     "ofq_cga_freeze_mask_multi": (i32, [vp, i64, i32, f32, vp]),
     "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
     "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),
+    "ofq_gelu_fwd": (i32, [vp, vp, i64, vp]),
 }
 
 _lib = None

@@ -220,3 +220,22 @@ extern "C" int ofq_cga_restore(float* W, const float* frozen, const float* saved
   OFQ_LAUNCH_CHECK();
   return 0;
 }
+
+
+// exact (erf) GELU, elementwise: the fp32 KD teacher's MLP activation (deit_vision_transformer.py:61, nn.GELU()); the
+// quantised student folds its GELU into fc2's quantiser kernels instead
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i4);
+    *reinterpret_cast<float4*>(y + i4) = make_float4(ofq_gelu(v.x), ofq_gelu(v.y), ofq_gelu(v.z), ofq_gelu(v.w));
+  } else {
+    for (int64_t i = i4; i < n && i < i4 + 4; ++i) y[i] = ofq_gelu(x[i]);
+  }
+}
+extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream) {
+  if (!x || !y || n <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

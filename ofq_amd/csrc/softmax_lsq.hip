@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
                                    int64_t ld, int64_t S, float alpha, int hi, float gscale, uint8_t* codes,
                                    float* code_rowsum, const float* addend, int64_t add_period, ofq_stream_t stream) {
-  if (!scores || !s || !prob || (!y && !codes) || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
+  // (y and codes may both be NULL: the probabilities alone -- the fp32 teacher's softmax, ofq_amd/teacher.py)
+  if (!scores || !s || !prob || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE || S <= 0)
     return OFQ_EINVAL;
   const bool v4 = (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0 && ((uintptr_t)prob & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0) &&
                   (!codes || ((uintptr_t)codes & 3) == 0) && (!addend || ((uintptr_t)addend & 15) == 0);

@@ -688,3 +688,11 @@ def cga_mask_grad_save(grad, W, frozen):
 def cga_restore(W, frozen, saved):
     _chk(lib().ofq_cga_restore(W.data_ptr(), frozen.data_ptr(), saved.data_ptr(), W.numel(), _stream()),
          "ofq_cga_restore")
+
+
+# ------------------------------------------------------------------------------------------------ fp32 teacher helpers
+def gelu_(x):
+    """exact GELU in place"""
+    _dev(x, "x")
+    _chk(lib().ofq_gelu_fwd(x.data_ptr(), x.data_ptr(), x.numel(), _stream()), "ofq_gelu_fwd")
+    return x

@@ -459,6 +459,35 @@ def deit_forward(img, sd, cfg, training=True):
     return (cls_x + dist_x) / 2                                          # deit.py:64
 
 
+def deit_fp32_forward(img, sd, depth, num_heads, patch=16, training=True, ln_eps=1e-6):
+    """The fp32 (un-quantised) distilled DeiT the KD recipes use as teacher: PatchEmbed conv, cls / dist tokens, pos_embed
+    (deit.py:27-40), `depth` blocks x + attn(norm1(x)), x + mlp(norm2(x)) (deit_vision_transformer.py:85-164: qkv linear,
+    softmax((q k^T) * scale), (attn @ v), proj; fc1, exact GELU, fc2), final norm, the two heads (deit.py:56-67).
+    sd: state dict with the reference's key names.  Training mode returns (cls, dist), eval mode their mean."""
+    x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
+    x = x.flatten(2).transpose(1, 2)
+    B = x.shape[0]
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), sd["dist_token"].expand(B, -1, -1), x), dim=1) + sd["pos_embed"]
+    C = x.shape[-1]
+    d = C // num_heads
+    for i in range(depth):
+        p = _sub(sd, "blocks.%d." % i)
+        h = F.layer_norm(x, (C,), p["norm1.weight"], p["norm1.bias"], ln_eps)
+        N = h.shape[1]
+        qkv = F.linear(h, p["attn.qkv.weight"], p["attn.qkv.bias"]).reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = ((q @ k.transpose(-2, -1)) * (d ** -0.5)).softmax(dim=-1)                 # :81-83
+        a = (attn @ v).transpose(1, 2).reshape(B, N, C)
+        x = x + F.linear(a, p["attn.proj.weight"], p["attn.proj.bias"])
+        h = F.layer_norm(x, (C,), p["norm2.weight"], p["norm2.bias"], ln_eps)
+        h = F.linear(F.gelu(F.linear(h, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
+        x = x + h
+    x = F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], ln_eps)
+    cls = F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])
+    dist = F.linear(x[:, 1], sd["head_dist.weight"], sd["head_dist.bias"])
+    return (cls, dist) if training else (cls + dist) / 2
+
+
 def kd_loss_soft_and_hard(cls_out, dist_out, hard_target, soft_target):
     """KDLossSoftandHard.forward (quantization/utils.py:59-77) with KLLossSoft (:44-57), T = 1."""
     tp = F.softmax(soft_target, dim=1)

@@ -337,3 +337,37 @@ def test_fused_adamw_keeps_one_step_count_per_tensor():
         assert float((x - y).abs().max()) < 2e-6 * float(y.abs().max())
     for key in ("exp_avg", "exp_avg_sq"):
         assert torch.allclose(opts[0].state[pb[0]][key], opts[1].state[pb[1]][key], rtol=1e-5, atol=1e-8)
+
+
+def test_hip_teacher_forward_equals_the_fp32_deit():
+    """The KD teacher's forward through the HIP kernels (ofq_amd.teacher.HipTeacher: fp32 MFMA GEMMs, fused add + LayerNorm,
+    softmax kernel, erf-GELU) against (a) the oracle's restatement of the reference's fp32 distilled DeiT
+    (deit_vision_transformer.py:85-164, deit.py:27-67) and (b) the stock PyTorch-ROCm forward of the same module, in the
+    mode the reference runs its teacher in (training mode: cls logits distilled) and in eval mode.  fp32 against fp32 with
+    different summation orders: 1e-5 of the logits' scale."""
+    import ofq_oracle as O
+    from ofq_amd.deit import create_model
+    from ofq_amd.teacher import HipTeacher
+    torch.manual_seed(0)
+    model = create_model("deit_tiny_distilled_patch16_224", num_classes=1000).cuda()
+    with torch.no_grad():
+        for p in model.parameters():                       # random-init logits are ~0: give the comparison some scale
+            if p.dim() >= 2:
+                p.mul_(3.0)
+        model.blocks[3].mlp.fc1.bias.normal_(0, 0.3)
+    x = torch.randn(3, 3, 224, 224, device="cuda")
+    teacher = HipTeacher(model)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for training in (True, False):
+        model.train(training)
+        with torch.no_grad():
+            stock, _ = model(x)
+            got, _ = teacher(x)
+            want = O.deit_fp32_forward(x.cpu(), sd, 12, 3, training=training)
+        pairs = list(zip(got, stock, want)) if training else [(got, stock, want)]
+        for g, s, w in pairs:
+            scale = float(w.abs().max())
+            assert float((g.cpu() - w).abs().max()) < 1e-5 * scale
+            assert float((g - s).abs().max()) < 1e-5 * scale
+    with pytest.raises(RuntimeError):
+        teacher(x.cpu())
