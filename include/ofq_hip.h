@@ -318,6 +318,16 @@ int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
 int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
 
+/* ---- on-device input pipeline (train.py:579-629 -> timm 0.5.4 FastCollateMixup + PrefetchLoader + RandomErasing): one
+ *  pass over a decoded uint8 batch in [B][C][H][W]: mixup / cutmix with the mirrored sample B-1-b in uint8 space
+ *  (use_mix; use_cutmix selects the box copy, otherwise rint(lam * x + one_minus_lam * x'), both scalars as float32), per-channel normalisation
+ *  (x - mean255[c]) / std255[c] in fp32 (mean255 / std255: HOST arrays of C floats), and random erasing: rects = DEVICE
+ *  int32 [B][4] {top, left, h, w} (h = 0: sample not erased) or NULL, the rectangle is overwritten with noise[b][c][y][x]
+ *  (DEVICE fp32, same shape as out).  The random decisions are taken on the host (ofq_amd/data.py).  W % 4 == 0. */
+int ofq_input_pipeline_u8(const uint8_t* in, float* out, int64_t B, int64_t C, int64_t H, int64_t W, const float* mean255,
+                          const float* std255, int use_mix, int use_cutmix, float lam, float one_minus_lam, int yl, int yh, int xl,
+                          int xh, const int32_t* rects, const float* noise, ofq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

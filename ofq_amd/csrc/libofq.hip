@@ -16,3 +16,4 @@ extern "C" const char* ofq_source_hash(void) { return "OFQ_SOURCE_HASH=" OFQ_SOU
 #include "layernorm.hip"
 #include "misc.hip"
 #include "adamw.hip"
+#include "input_pipeline.hip"

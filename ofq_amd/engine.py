@@ -333,7 +333,8 @@ class GraphedTrainStep:
             before = q.latched()
             q._latch(q.latch_input(images, getattr(m, "move_b4").bias))
             flipped |= q.latched() != before
-        if self.graph is not None and (flipped or images.shape != self.static[0].shape):
+        if self.graph is not None and (flipped or any(a.shape != b.shape or a.dtype != b.dtype
+                                                      for a, b in zip((images, target, soft_target), self.static))):
             self.graph = None                              # clamp bounds / shapes are baked into the captured launches
         if self.graph is None:
             self._capture(images, target, soft_target)

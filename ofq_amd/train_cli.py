@@ -11,8 +11,11 @@ import argparse
 import json
 import math
 import os
+import random
 import sys
 import time
+
+import numpy as np
 
 import torch
 import torch.distributed as dist
@@ -45,8 +48,17 @@ def build_parser(cga=False):
     p.add_argument('--resume', default='')
     p.add_argument('--no-resume-opt', action='store_true')
     p.add_argument('--initial-checkpoint', default='', help='student weights loaded after the surgery, strict=False (train.py:515-516)')
+    # on-device input pipeline (train.py:199-220, :579-629; ofq_amd/data.py)
     p.add_argument('--mixup', type=float, default=0.0)
     p.add_argument('--cutmix', type=float, default=0.0)
+    p.add_argument('--mixup-prob', type=float, default=1.0)
+    p.add_argument('--mixup-switch-prob', type=float, default=0.5)
+    p.add_argument('--mixup-mode', default='batch')
+    p.add_argument('--mixup-off-epoch', type=int, default=0)
+    p.add_argument('--reprob', type=float, default=0.0)
+    p.add_argument('--remode', default='pixel')
+    p.add_argument('--recount', type=int, default=1)
+    p.add_argument('--aa', default=None, help='RandAugment runs in timm CPU workers on PIL images: not part of this path')
     p.add_argument('--no-graph', action='store_true',
                    help='launch every kernel from Python instead of replaying the captured hipGraph of the step')
     # quantisation flags (train.py:297-366)
@@ -100,20 +112,27 @@ def parse_args(argv, cga):
 
 
 class SyntheticLoader:
-    """Device-resident ImageNet-shaped batches (randn images, random labels), sharded by rank through the seed."""
+    """Device-resident ImageNet-shaped batches (randn images, random labels), sharded by rank through the seed.
+    With a `pipeline` (ofq_amd.data.DeviceInputPipeline) the pool holds decoded uint8 batches -- what timm's fast_collate
+    hands to the device -- and every batch goes through mixup / cutmix, normalisation and random erasing on the device."""
 
-    def __init__(self, steps, batch, num_classes, device, seed):
-        self.steps, self.batch, self.nc, self.device = steps, batch, num_classes, device
+    def __init__(self, steps, batch, num_classes, device, seed, pipeline=None):
+        self.steps, self.batch, self.nc, self.device, self.pipeline = steps, batch, num_classes, device, pipeline
         g = torch.Generator(device=device).manual_seed(seed)
-        self.pool = [(torch.randn(batch, 3, 224, 224, device=device, generator=g),
-                      torch.randint(0, num_classes, (batch,), device=device, generator=g)) for _ in range(2)]
+        if pipeline is None:
+            self.pool = [(torch.randn(batch, 3, 224, 224, device=device, generator=g),
+                          torch.randint(0, num_classes, (batch,), device=device, generator=g)) for _ in range(2)]
+        else:
+            self.pool = [(torch.randint(0, 256, (batch, 3, 224, 224), device=device, generator=g, dtype=torch.uint8),
+                          torch.randint(0, num_classes, (batch,), device=device, generator=g)) for _ in range(2)]
 
     def __len__(self):
         return self.steps
 
     def __iter__(self):
         for i in range(self.steps):
-            yield self.pool[i % len(self.pool)]
+            x, y = self.pool[i % len(self.pool)]
+            yield (x, y) if self.pipeline is None else self.pipeline(x, y)
 
 
 def cosine_lr(epoch, epochs, base, min_lr, warmup_epochs, warmup_lr):
@@ -148,8 +167,12 @@ def check_supported(args):
         bad.append("--opt %s (only adamw: train_scripts/*, configs/*.yml)" % args.opt)
     if args.sched != "cosine":
         bad.append("--sched %s (only cosine)" % args.sched)
-    if args.mixup > 0 or args.cutmix > 0:
-        bad.append("--mixup/--cutmix > 0 (the timm augmentation pipeline is SURVEY.md 8(f) rank 4, not built)")
+    if (args.mixup > 0 or args.cutmix > 0) and args.mixup_mode != "batch":
+        bad.append("--mixup-mode %s (only 'batch', the recipes' setting)" % args.mixup_mode)
+    if args.reprob > 0 and (args.remode != "pixel" or args.recount != 1):
+        bad.append("--remode %s --recount %d (only pixel / 1, the recipes' setting)" % (args.remode, args.recount))
+    if (args.mixup > 0 or args.cutmix > 0) and args.batch_size % 2:
+        bad.append("mixup / cutmix need an even batch size (timm: 'Batch size should be even when using this')")
     if args.use_kd and args.kd_hard_and_soft not in (0, 1):
         bad.append("--kd_hard_and_soft %d (0: soft only, 1: hard + soft)" % args.kd_hard_and_soft)
     if args.use_kd and not args.teacher_checkpoint and not args.teacher_random_init:
@@ -194,10 +217,25 @@ def main_worker(local_rank, args, cga, spawned):
                 args.qmodules = engine.default_qmodules(len(model.blocks))
         model = engine.get_qat_model(model, args)                                           # train.py:523
     model.to(dev)
-    loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, args.num_classes, dev, args.seed + rank)
+    mixup_active = args.mixup > 0 or args.cutmix > 0                                        # train.py:582
+    pipeline = mixup = None
+    if mixup_active or args.reprob > 0:
+        from . import data
+        np.random.seed(args.seed + rank)                                                    # timm.utils.random_seed
+        random.seed(args.seed + rank)
+        if mixup_active:
+            mixup = data.MixupParams(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, prob=args.mixup_prob,
+                                     switch_prob=args.mixup_switch_prob, label_smoothing=args.smoothing,
+                                     num_classes=args.num_classes)
+        erasing = data.RandomErasingParams(probability=args.reprob) if args.reprob > 0 else None
+        pipeline = data.DeviceInputPipeline(mixup=mixup, erasing=erasing)
+    loader = SyntheticLoader(args.steps_per_epoch, args.batch_size, args.num_classes, dev, args.seed + rank, pipeline)
     val_loader = SyntheticLoader(args.val_steps, args.batch_size, args.num_classes, dev, args.seed + 1000 + rank)
     if args.quantized:
-        engine.setup_alpha(model, loader.pool[0][0])                                        # train.py:656-657
+        first = loader.pool[0][0]
+        if pipeline is not None:                                                            # a normalised batch without augmentation
+            first = data.DeviceInputPipeline()(first, loader.pool[0][1])[0]
+        engine.setup_alpha(model, first)                                                    # train.py:656-657
     if args.initial_checkpoint:                                                              # train.py:515-516
         # (the lazily created LSQ steps exist by now, so a quantised checkpoint's `s` vectors have somewhere to go)
         load_checkpoint(model, args.initial_checkpoint, strict=False, map_location=dev)
@@ -222,7 +260,8 @@ def main_worker(local_rank, args, cga, spawned):
     dp = parallel.DataParallel(model) if world > 1 else None                                # train.py:727
     kd_both = KDLossSoftandHard()
     kd_soft = KLLossSoft()
-    hard = torch.nn.CrossEntropyLoss(label_smoothing=args.smoothing)                         # train.py:764-769 (mixup off)
+    # train.py:764-769: with mixup the smoothing is in the soft targets (SoftTargetCrossEntropy), else label smoothing
+    hard = torch.nn.CrossEntropyLoss(label_smoothing=0.0 if mixup_active else args.smoothing)
 
     def loss_fn(out, target, soft):                                                          # train.py:896-913
         if teacher is None:
@@ -246,6 +285,8 @@ def main_worker(local_rank, args, cga, spawned):
         lr = args.min_lr if cga else cosine_lr(epoch, args.epochs, args.lr, args.min_lr, args.warmup_epochs, args.warmup_lr)
         for gparam in optimizer.param_groups:
             gparam["lr"] = lr
+        if mixup is not None and args.mixup_off_epoch and epoch >= args.mixup_off_epoch:
+            mixup.mixup_enabled = False                                                     # train.py:865-869
         for bi, (x, y) in enumerate(loader):
             if teacher is not None:
                 with torch.no_grad():

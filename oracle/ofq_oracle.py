@@ -524,3 +524,54 @@ def cga_mask_grad(grad, frz):
 
 def cga_restore(W_new, W_old, frz):
     return W_new * (1 - frz) + (W_old * frz)                             # cga.py:964, :994-997
+
+
+# ----------------------------------------------------------------------------------------------
+# Input pipeline (train.py:579-629).  The arithmetic lives in timm==0.5.4 (README.md:19), which is not vendored under
+# /root/reference: restated here from its published source -- timm/data/mixup.py (FastCollateMixup._mix_batch_collate,
+# mixup_target, one_hot), timm/data/loader.py (PrefetchLoader.__iter__: float().sub_(mean).div_(std) with mean / std * 255)
+# and timm/data/random_erasing.py (RandomErasing._erase, mode 'pixel': the rectangle is filled with normal noise).  The
+# reference holds no tests or fixtures for this path (parity unpinned upstream); pinned here by hand-computed cases in
+# tests/test_host_logic.py.
+# ----------------------------------------------------------------------------------------------
+
+
+def input_pipeline(images_u8, lam, use_cutmix, box, rects, noise, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """images_u8: uint8 numpy [B][C][H][W]; lam: python float (1.0: no mixing); box: (yl, yh, xl, xh); rects: int [B][4]
+    {top, left, h, w} (h = 0: not erased) or None; noise: float32 [B][C][H][W].  Returns float32 [B][C][H][W]."""
+    import numpy as np
+    B = images_u8.shape[0]
+    mixed_all = np.zeros(images_u8.shape, dtype=np.uint8)
+    yl, yh, xl, xh = box
+    for i in range(B):                                                  # _mix_batch_collate
+        j = B - i - 1
+        mixed = images_u8[i]
+        if lam != 1.0:
+            if use_cutmix:
+                mixed = mixed.copy()
+                mixed[:, yl:yh, xl:xh] = images_u8[j][:, yl:yh, xl:xh]
+            else:
+                mixed = mixed.astype(np.float32) * np.float32(lam) + images_u8[j].astype(np.float32) * np.float32(1 - lam)
+                np.rint(mixed, out=mixed)
+        mixed_all[i] += mixed.astype(np.uint8)
+    x = torch.from_numpy(mixed_all).float()                             # PrefetchLoader
+    m = torch.tensor([v * 255 for v in mean]).view(1, -1, 1, 1)
+    sd = torch.tensor([v * 255 for v in std]).view(1, -1, 1, 1)
+    x = x.sub_(m).div_(sd)
+    if rects is not None:                                               # RandomErasing._erase
+        nz = torch.as_tensor(noise)
+        for i in range(B):
+            top, left, h, w = [int(v) for v in rects[i]]
+            if h > 0:
+                x[i, :, top:top + h, left:left + w] = nz[i, :, top:top + h, left:left + w]
+    return x
+
+
+def mixup_target(target, num_classes, lam, smoothing):
+    """timm.data.mixup.mixup_target (device='cpu')."""
+    off_value = smoothing / num_classes
+    on_value = 1.0 - smoothing + off_value
+    t = target.long().view(-1, 1)
+    y1 = torch.full((t.shape[0], num_classes), off_value).scatter_(1, t, on_value)
+    y2 = torch.full((t.shape[0], num_classes), off_value).scatter_(1, t.flip(0), on_value)
+    return y1 * lam + y2 * (1.0 - lam)

@@ -6,6 +6,7 @@ all-reduce of the data-parallel wrapper, and the stem quantiser's data-dependent
 import copy
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -286,7 +287,12 @@ def test_train_cli_two_steps_save_resume_and_validate(tmp_path):
     assert losses_b[0] == pytest.approx(losses_full[2], rel=1e-6) and losses_b[1] == pytest.approx(losses_full[3], rel=1e-6)
     # unsupported flags do not pass silently
     with pytest.raises(SystemExit):
-        train_cli.main(common + ["--epochs", "1", "--mixup", "0.8"])
+        train_cli.main(common + ["--epochs", "1", "--mixup", "0.8", "--mixup-mode", "elem"])
+    # the recipe's augmentation flags (configs/ours_imagenet_recipe.attn_q.yml:18-26) drive the on-device input pipeline:
+    # uint8 batches, mixup / cutmix with soft targets, normalisation, random erasing -- and the step still trains
+    _, losses_aug = run(["--epochs", "1", "--mixup", "0.8", "--cutmix", "1.0", "--reprob", "0.25", "--remode", "pixel",
+                         "--smoothing", "0.1"])
+    assert len(losses_aug) == 2 and all(np.isfinite(l) and 5.0 < l < 20.0 for l in losses_aug)
     with pytest.raises(SystemExit):
         train_cli.main([a for a in common if a not in ("--teacher-checkpoint", tpath)] + ["--epochs", "1"])
     # validate() against the oracle's eval forward on the same synthetic validation batch

@@ -176,3 +176,70 @@ def test_fp32_teacher_skeleton_runs_on_cpu_and_matches_shapes():
         y, attn = m(torch.randn(1, 3, 224, 224))
     assert y.shape == (1, 10) and len(attn) == 1
     assert m.pos_embed.shape == (1, 198, 192)                                    # cls + dist + 196 (deit.py:23-25)
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline (host side)
+def test_input_pipeline_oracle_on_hand_computed_cases():
+    """oracle.input_pipeline restates timm 0.5.4's FastCollateMixup / PrefetchLoader / RandomErasing arithmetic; the
+    reference holds no fixtures for it, so it is pinned on cases small enough to compute by hand."""
+    import ofq_oracle as O
+    x = np.zeros((2, 3, 2, 4), dtype=np.uint8)
+    x[0] = 10
+    x[1] = 201
+    mean, std = (0.5, 0.5, 0.5), (0.25, 0.5, 1.0)
+    # no mixing: (10 - 127.5) / 63.75, / 127.5, / 255
+    y = O.input_pipeline(x, 1.0, False, (0, 0, 0, 0), None, None, mean, std)
+    assert y.shape == (2, 3, 2, 4) and y.dtype == torch.float32
+    assert torch.equal(y[0, :, 0, 0], torch.tensor([(10 - 127.5) / 63.75, (10 - 127.5) / 127.5, (10 - 127.5) / 255.0]).float())
+    # mixup lam = 0.3: sample 0 <- rint(0.3 * 10 + 0.7 * 201) = rint(143.7) = 144, sample 1 <- rint(0.3 * 201 + 0.7 * 10) = 67
+    y = O.input_pipeline(x, 0.3, False, (0, 0, 0, 0), None, None, mean, std)
+    assert float(y[0, 2, 0, 0]) == pytest.approx((144 - 127.5) / 255.0) and float(y[1, 2, 1, 3]) == pytest.approx((67 - 127.5) / 255.0)
+    # cutmix: the box rows [0,1) x cols [1,3) comes from the mirrored sample, the rest stays
+    y = O.input_pipeline(x, 0.75, True, (0, 1, 1, 3), None, None, mean, std)
+    got = (y[0, 2] * 255.0 + 127.5).round().int()
+    assert got.tolist() == [[10, 201, 201, 10], [10, 10, 10, 10]]
+    # erasing: rectangle of sample 1 replaced by the noise values, everything else normalised as before
+    noise = np.full((2, 3, 2, 4), 7.0, dtype=np.float32)
+    rects = np.array([[0, 0, 0, 0], [1, 2, 1, 2]], dtype=np.int32)
+    y = O.input_pipeline(x, 1.0, False, (0, 0, 0, 0), rects, noise, mean, std)
+    assert torch.equal(y[1, :, 1, 2:4], torch.full((3, 2), 7.0)) and float(y[1, 0, 0, 0]) == pytest.approx((201 - 127.5) / 63.75)
+    assert not bool((y[0] == 7.0).any())
+    # soft targets: label smoothing 0.1 over 4 classes, lam 0.3
+    t = O.mixup_target(torch.tensor([1, 3]), 4, 0.3, 0.1)
+    assert t.shape == (2, 4) and torch.allclose(t.sum(1), torch.ones(2))
+    assert float(t[0, 1]) == pytest.approx(0.3 * 0.925 + 0.7 * 0.025) and float(t[0, 3]) == pytest.approx(0.3 * 0.025 + 0.7 * 0.925)
+
+
+def test_input_pipeline_host_draws_follow_timm_formulas():
+    """ofq_amd.data draws the augmentation parameters on the host in timm's order from timm's generators: a seeded run
+    gives the values the published formulas give (Mixup._params_per_batch, rand_bbox, RandomErasing._erase)."""
+    import random
+    from ofq_amd.data import MixupParams, RandomErasingParams
+    np.random.seed(7)
+    mp = MixupParams(mixup_alpha=0.8, cutmix_alpha=1.0, prob=1.0, switch_prob=0.5, label_smoothing=0.1, num_classes=10)
+    draws = [mp.draw(224, 224) for _ in range(8)]
+    np.random.seed(7)
+    for lam, use_cutmix, box in draws:                      # replay the generator by hand
+        assert np.random.rand() < 1.0
+        cm = np.random.rand() < 0.5
+        lam_mix = np.random.beta(1.0, 1.0) if cm else np.random.beta(0.8, 0.8)
+        assert cm == use_cutmix
+        if cm:
+            ratio = np.sqrt(1 - lam_mix)
+            ch, cw = int(224 * ratio), int(224 * ratio)
+            cy, cx = np.random.randint(0, 224), np.random.randint(0, 224)
+            b = (int(np.clip(cy - ch // 2, 0, 224)), int(np.clip(cy + ch // 2, 0, 224)),
+                 int(np.clip(cx - cw // 2, 0, 224)), int(np.clip(cx + cw // 2, 0, 224)))
+            assert b == box and lam == pytest.approx(1.0 - (b[1] - b[0]) * (b[3] - b[2]) / (224.0 * 224.0))
+        else:
+            assert lam == float(lam_mix) and box == (0, 0, 0, 0)
+    assert any(d[1] for d in draws) and not all(d[1] for d in draws)
+    random.seed(11)
+    rects = RandomErasingParams(probability=0.25).draw(256, 224, 224)
+    erased = rects[rects[:, 2] > 0]
+    assert 0.15 < len(erased) / 256 < 0.35                                   # re_prob 0.25
+    area = erased[:, 2] * erased[:, 3] / (224.0 * 224.0)
+    assert area.min() > 0.015 and area.max() < 0.36                          # min_area 0.02 .. max_area 1/3 (after rounding)
+    assert (erased[:, 0] + erased[:, 2] <= 224).all() and (erased[:, 1] + erased[:, 3] <= 224).all()
+    mp.mixup_enabled = False                                                 # train.py:865-869 (mixup_off_epoch)
+    assert mp.draw(224, 224) == (1.0, False, (0, 0, 0, 0))

@@ -854,3 +854,38 @@ def test_attention_prep_launch_equals_the_three_kernels(ops):
     assert torch.equal(tq, ops.rowdot_i8(qc.view(B * N * H, C), bax))
     assert torch.equal(vT, ops.codes_transpose_i8(vc, Np))
     assert torch.equal(vT[:, :, :N], vc.transpose(1, 2)) and int(vT[:, :, N:].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "mixup", "cutmix", "mixup_erase", "erase"])
+def test_input_pipeline_kernel_is_bit_exact_vs_oracle(ops, mode):
+    """ofq_input_pipeline_u8 (uint8-space mixup / cutmix with the mirrored sample, normalisation, random-erasing noise in one
+    pass) against the oracle's restatement of timm 0.5.4's FastCollateMixup + PrefetchLoader + RandomErasing
+    (train.py:579-629): byte and elementwise fp32 work, so bit for bit; the soft targets too."""
+    import random
+    from ofq_amd.data import DeviceInputPipeline, MixupParams, RandomErasingParams
+    B, C, H, W = 8, 3, 224, 224
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (B, C, H, W), dtype=torch.uint8, generator=g)
+    tgt = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, C, H, W, generator=g)
+    np_seed = {"plain": 0, "mixup": 1, "cutmix": 2, "mixup_erase": 1, "erase": 0}[mode]
+    for trial in range(4):
+        np.random.seed(100 * np_seed + trial)
+        random.seed(trial + 5)
+        mix = None
+        if "mix" in mode:
+            mix = MixupParams(mixup_alpha=0.8 if mode != "cutmix" else 0.0, cutmix_alpha=1.0 if mode == "cutmix" else 0.0)
+        er = RandomErasingParams(probability=0.6) if "erase" in mode else None
+        pipe = DeviceInputPipeline(mixup=mix, erasing=er)
+        out, t = pipe(x.cuda(), tgt.cuda(), noise=noise.cuda())
+        last = pipe.last
+        want = O.input_pipeline(x.numpy(), last["lam"], last["use_cutmix"], last["box"], last["rects"], noise.numpy())
+        assert torch.equal(out.cpu(), want), (mode, trial, last)
+        if mix is not None:
+            assert last["lam"] != 1.0 and last["use_cutmix"] == (mode == "cutmix")
+            assert torch.equal(t.cpu(), O.mixup_target(tgt, 1000, last["lam"], 0.1))
+        else:
+            assert torch.equal(t.cpu(), tgt)
+        if er is not None and trial == 0:
+            assert last["rects"] is not None and int((last["rects"][:, 2] > 0).sum()) >= 2
