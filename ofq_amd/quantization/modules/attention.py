@@ -95,8 +95,13 @@ class QAttention(deit_attention):
         self.move_v_aft = LearnableBias(C)
         self.quan_a_softmax_fn = LsqQuantizer(bit=input_bits, all_positive=True, per_channel=True, learnable=aq_learnable)
 
-    def forward(self, x):
-        return self.proj_drop(self.proj(plain_attention_core(self, x, self.scale))), None   # attention.py:103-105
+    def fused_input_quant(self, in_shape):
+        """The qkv projection's input quantiser, for a producer that can apply it itself (LayerNorm + LSQ in one kernel,
+        deit_vision_transformer.Block.forward_fused); None when qkv needs the fp32 values."""
+        return self.qkv.fused_input_quant(in_shape)
+
+    def forward(self, x, pre_quant=None):
+        return self.proj_drop(self.proj(plain_attention_core(self, x, self.scale, pre_quant=pre_quant))), None   # :103-105
 
 
 def _plain_lazy_init(self, qkv):
@@ -109,13 +114,13 @@ def _plain_lazy_init(self, qkv):
                 qz.init_from(t[..., i * C:(i + 1) * C])
 
 
-def plain_attention_core(self, x, scale, addend=None):
+def plain_attention_core(self, x, scale, addend=None, pre_quant=None):
     """qkv projection -> offsets/LSQ on q,k,v -> scores -> softmax+LSQ -> P.V, everything before `proj`
     (attention.py:69-102; shared with the Swin window attention, swin_attention_and_mlp.py:173-228)."""
     if True:
         B, N, C = x.shape
         H = self.num_heads
-        qkv = self.qkv(x)                                                        # attention.py:69
+        qkv = self.qkv(x, pre_quant=pre_quant)                                   # attention.py:69
         _plain_lazy_init(self, qkv)
         lo, hi = self.quan_a_q_fn.thd_neg, self.quan_a_q_fn.thd_pos
         gq = ops.LsqGeom(B, N, C, C, 0, lo, hi, B * C, ldx=3 * C, ldy=C)         # s per token, M = B*H*d
