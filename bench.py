@@ -261,7 +261,7 @@ def main():
 
     eager_step = step
     # one rank: graph replay.  Several ranks: the step is GPU-bound at 128 img/GPU either way (the launch queue never runs dry,
-    # profiles/r02_graph_gaps_*), and RCCL collectives inside a hipGraph could only be exercised with one rank on the
+    # profiles/r02_graph_gaps_graph_vs_eager.txt), and RCCL collectives inside a hipGraph could only be exercised with one rank on the
     # one-GPU development boxes, so the multi-rank default is the eager path; --graph turns the replay on there too.
     use_graph = not args.no_graph and (world == 1 or args.graph)
     n_warm = args.warmup

@@ -8,7 +8,7 @@ O=gpurun_out/evidence_$TAG; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/kt.log 2>&1; echo "kernel-trace rc=$?"
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-events > $R/$O/kt.log 2>&1; echo "kernel-trace rc=$?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$O/pf -o pf -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline-events > $R/$O/pf.log 2>&1; echo "fetch rc=$?"
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/pw -o pw -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline-events > $R/$O/pw.log 2>&1; echo "write rc=$?"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $R/$O/pm -o pm -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline-events > $R/$O/pm.log 2>&1; echo "mfma rc=$?"
