@@ -77,6 +77,25 @@ def shift_attention_mask(pad_H, pad_W, window_size, shift_size, device):
     return m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
 
 
+class _PermuteTokensFn(torch.autograd.Function):
+    """y[b, i] = x[b, idx[i]] for a PERMUTATION idx of the token axis (inv its inverse): one gather each way instead of the
+    roll + view + permute + reshape copy chain of the shifted-window partition; the backward of a permutation is the
+    gather with the inverse permutation (no scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv):
+        ctx.save_for_backward(idx, inv)
+        return x.index_select(1, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, inv = ctx.saved_tensors
+        return g.index_select(1, inv), None, None
+
+
+_PERM_CACHE = {}
+
+
 class WindowGeometry:
     """pad -> cyclic shift -> window partition of a (B, H, W, C) map and the inverse (swin.py:103-131, :160-170)."""
 
@@ -97,14 +116,39 @@ class WindowGeometry:
         self.nW = (self.pH // self.ws[0]) * (self.pW // self.ws[1])
         self.N = self.ws[0] * self.ws[1]
 
+    def _perm(self, device):
+        """token permutation of partition() (and its inverse) when nothing is padded: built by pushing the token indices
+        through the very same pad / roll / view / permute code path, cached per geometry"""
+        key = (self.H, self.W, tuple(self.ws), tuple(self.ss), str(device))
+        hit = _PERM_CACHE.get(key)
+        if hit is None:
+            grid = torch.arange(self.H * self.W, device=device, dtype=torch.float32).view(1, self.H, self.W, 1)
+            idx = self._partition_copy(grid, 1).reshape(-1).long()
+            inv = torch.empty_like(idx)
+            inv[idx] = torch.arange(idx.numel(), device=device)
+            hit = _PERM_CACHE[key] = (idx, inv)
+        return hit
+
     def partition(self, x):
+        if self.pad == (0, 0) and x.is_cuda:
+            idx, inv = self._perm(x.device)
+            y = _PermuteTokensFn.apply(x.reshape(self.B, self.H * self.W, self.C), idx, inv)
+            return y.view(self.B * self.nW, self.N, self.C)
+        return self._partition_copy(x, self.B)
+
+    def _partition_copy(self, x, B):
         x = F.pad(x, (0, 0, 0, self.pad[0], 0, self.pad[1]))
         if sum(self.ss) > 0:
             x = torch.roll(x, shifts=(-self.ss[0], -self.ss[1]), dims=(1, 2))
-        x = x.view(self.B, self.pH // self.ws[0], self.ws[0], self.pW // self.ws[1], self.ws[1], self.C)
-        return x.permute(0, 1, 3, 2, 4, 5).reshape(self.B * self.nW, self.N, self.C)
+        C = x.shape[-1]
+        x = x.view(B, self.pH // self.ws[0], self.ws[0], self.pW // self.ws[1], self.ws[1], C)
+        return x.permute(0, 1, 3, 2, 4, 5).reshape(B * self.nW, self.N, C)
 
     def reverse(self, x):
+        if self.pad == (0, 0) and x.is_cuda:
+            idx, inv = self._perm(x.device)
+            y = _PermuteTokensFn.apply(x.reshape(self.B, self.nW * self.N, self.C), inv, idx)
+            return y.view(self.B, self.H, self.W, self.C)
         x = x.view(self.B, self.pH // self.ws[0], self.pW // self.ws[1], self.ws[0], self.ws[1], self.C)
         x = x.permute(0, 1, 3, 2, 4, 5).reshape(self.B, self.pH, self.pW, self.C)
         if sum(self.ss) > 0:
@@ -181,6 +225,18 @@ class SwinTransformerBlock(nn.Module):
         x = x + self.mlp(n2)
         return x, info
 
+    def forward_fused(self, x, pending):
+        """forward() with the residual add of the PREVIOUS block's MLP output (`pending`, not yet added to x) folded into
+        norm1's pass; this block's own MLP output is returned un-added.  Returns (x after the attention residual, info,
+        mlp output)."""
+        if pending is None:
+            xin, n1 = x, F_ofq.layer_norm(self.norm1, x)
+        else:
+            xin, n1 = F_ofq.add_layer_norm(self.norm1, x, pending)
+        y, info = self.attn(n1)
+        x, n2 = F_ofq.add_layer_norm(self.norm2, xin, y)
+        return x, info, self.mlp(n2)
+
 
 class SwinTransformer(nn.Module):
     def __init__(self, patch_size, embed_dim, depths, num_heads, window_size, mlp_ratio=4.0, dropout=0.0, qqkkvv=False,
@@ -217,11 +273,17 @@ class SwinTransformer(nn.Module):
         infos = []
         for blk in self.features[1:]:
             if isinstance(blk, nn.Sequential):
-                info = None
+                info, pending, cur = None, None, x[0]
                 for b in blk:
-                    x = b(x)
-                    info = x[1]
-                    x = (x[0], None)
+                    if hasattr(b, "forward_fused"):     # residual adds ride in the next block's norm1 (same values)
+                        cur, info, pending = b.forward_fused(cur, pending)
+                    else:
+                        if pending is not None:
+                            cur, pending = cur + pending, None
+                        cur, info = b((cur, None))
+                if pending is not None:
+                    cur = cur + pending
+                x = (cur, None)
             else:
                 x = blk(x)
                 info = x[1]
