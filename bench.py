@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured step with more than one rank as well (default there: eager launches; the capture "
                          "of RCCL collectives is validated with one rank only, tests/test_graph_gpu.py)")
+    ap.add_argument("--teacher-gemm", default="bf16x9", choices=["f32", "bf16x9", "bf16x6"],
+                    help="with --with-teacher: fp32-MFMA GEMMs, or the weights pre-split into bf16 planes (9 / 6 plane products)")
     ap.add_argument("--stock-teacher", action="store_true",
                     help="with --with-teacher: run the teacher through stock PyTorch-ROCm (hipBLASLt) instead of the HIP kernels")
     ap.add_argument("--force-dp", action="store_true",
@@ -247,7 +249,7 @@ def main():
             p_.requires_grad_(False)
         if not args.stock_teacher:                  # the same forward on the HIP kernels (ofq_amd/teacher.py)
             from ofq_amd.teacher import HipTeacher
-            teacher = HipTeacher(teacher)
+            teacher = HipTeacher(teacher, gemm=args.teacher_gemm)
 
     def soft_targets():
         if teacher is None:
@@ -359,7 +361,7 @@ def main():
                                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
                                          " + CGA hooks" if args.cga else "", B,
                                          "7x7 windows" if args.model.startswith("swin") else "198 tokens",
-                                         ("fp32 teacher forward in the step (%s)" % ("stock PyTorch-ROCm" if args.stock_teacher else "HIP kernels"))
+                                         ("fp32 teacher forward in the step (%s)" % ("stock PyTorch-ROCm" if args.stock_teacher else "HIP kernels, GEMMs " + args.teacher_gemm))
                                          if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
                           "launch": "hipGraph replay" if use_graph else "eager (one ctypes launch per kernel)",

@@ -317,6 +317,13 @@ int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n
  *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
 int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
+/*  GEMM of the frozen fp32 teacher on the bf16 matrix cores: C[M][N] = A[M][K] . B[N][K]^T + bias[N], A fp32 (split into
+ *  three bf16 planes inside the kernel), B pre-split by ofq_split_f32_bf16x3 into planes[3][plane_stride] (bf16, B = sum of
+ *  the planes exactly).  products = 9: every plane pair, i.e. the exact product of the fp32 values up to fp32 accumulation;
+ *  6: the six leading pairs (dropped terms <= 2^-24 of a product).  K % 8 == 0. */
+int ofq_split_f32_bf16x3(const float* x, void* planes, int64_t n, int64_t plane_stride, ofq_stream_t stream);
+int ofq_gemm_bf16x3x3_nt(const float* A, const void* B_planes, float* C, const float* bias, int products, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t plane_stride, ofq_stream_t stream);
 
 /* ---- on-device input pipeline (train.py:579-629 -> timm 0.5.4 FastCollateMixup + PrefetchLoader + RandomErasing): one
  *  pass over a decoded uint8 batch in [B][C][H][W]: mixup / cutmix with the mirrored sample B-1-b in uint8 space

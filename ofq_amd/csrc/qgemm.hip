@@ -42,6 +42,7 @@ struct QGemmArgs {
   int64_t lda, ldb, ldc;
   int64_t sA0, sA1, sB0, sB1, sC0, sC1;   // batch strides (elements)
   int64_t sK1;           // bf16s: offset of the k-scale vector per inner batch index b1
+  int64_t sBp;           // bf16s with a plane-split fp32 B operand: elements between consecutive bf16 planes
   int M, N, K, S, nb1;
   int s2s0, s2s1;        // scores: the column step is s2[n * s2s0 + b1 * s2s1] (QKR: one per (token, head); plain: per token)
   int tiles_m, tiles_n, accumulate, b_is_i8;
@@ -774,11 +775,18 @@ __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
   return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
 }
 
-template <int NSPLIT, bool B_I8>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
+// NB > 1 (B_I8 = false): B is an fp32 matrix given as NB bf16 planes B = B_0 + B_1 + B_2 (plane r at B + r * sBp); the
+// products A_q . B_r with q + r < PMAX are accumulated: PMAX = 5 keeps all nine (the exact product of the two fp32 values
+// up to fp32 accumulation), PMAX = 3 the six leading ones (the dropped terms are <= 2^-24 of the product).  This is the
+// GEMM of the frozen fp32 KD teacher, whose weights are split once: 6 / 9 bf16 MFMAs per k-step amortise the split of the
+// activations that bounds the three-product kernels, at 16x the fp32-MFMA rate per instruction.
+template <int NSPLIT, bool B_I8, int NB = 1, int PMAX = 5>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2, NB == 1 ? 3 : 2))) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
+  static_assert(NB == 1 || !B_I8, "plane-split B is an fp32 operand");
   constexpr int BM = 128, BN = 128;
   constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NSPLIT * PLANE + BN * QBS_LD];
+  constexpr int PLANE_B = BN * QBS_LD;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSPLIT * PLANE + NB * PLANE_B];
   int tm, tn, gby;
   qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // gload only issues the loads; scaling, masking, the int8 -> bf16 conversion and the split happen at the LDS store of
   // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
   f32x4v ra[4], rks;
-  i32x4 rb[2];
+  i32x4 rb[NB][2];
   bool rkina = false, rkinb = false;
   auto gload = [&](int kt) {
     const int k0 = kt * QBS_BK;
@@ -827,11 +835,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (!B_I8) {
-        rb[i] = *reinterpret_cast<const i32x4*>(B + offB[i] + (kinb ? k0 : -kqb));
+#pragma unroll
+        for (int r = 0; r < NB; ++r) rb[r][i] = *reinterpret_cast<const i32x4*>(B + r * p.sBp + offB[i] + (kinb ? k0 : -kqb));
       } else {
         const u32x2v v = *reinterpret_cast<const u32x2v*>(B8 + offB[i] + (kinb ? k0 : -kqb));
-        rb[i].x = (int)v[0];
-        rb[i].y = (int)v[1];
+        rb[0][i].x = (int)v[0];
+        rb[0][i].y = (int)v[1];
       }
     }
     rkina = kina;
@@ -873,10 +882,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int m = (okB[i] && rkinb) ? -1 : 0;
       i32x4 w;
       if (!B_I8) {
-        asm volatile("" : "+v"(rb[i]));
-        w = rb[i] & m;
+#pragma unroll
+        for (int r = 1; r < NB; ++r) {
+          asm volatile("" : "+v"(rb[r][i]));
+          *reinterpret_cast<i32x4*>(&smem[NSPLIT * PLANE + r * PLANE_B + row * QBS_LD + kqb * 2]) = rb[r][i] & m;
+        }
+        asm volatile("" : "+v"(rb[0][i]));
+        w = rb[0][i] & m;
       } else {   // 8 int8 codes -> 8 bf16
-        int w0 = rb[i].x, w1 = rb[i].y;
+        int w0 = rb[0][i].x, w1 = rb[0][i].y;
         asm volatile("" : "+v"(w0), "+v"(w1));
         w0 &= m;
         w1 &= m;
@@ -907,9 +921,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const unsigned char* b = &smem[NSPLIT * PLANE + (wn * 64 + l31) * QBS_LD + lh * 16];
 #pragma unroll
     for (int ks = 0; ks < QBS_BK / 16; ++ks) {
-      bf16x8 bv[2];
+      bf16x8 bv[NB][2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD + ks * 32);
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[r][j] = *reinterpret_cast<const bf16x8*>(b + r * PLANE_B + j * 32 * QBS_LD + ks * 32);
 #pragma unroll
       for (int sidx = 0; sidx < NSPLIT; ++sidx) {
         bf16x8 av[2];
@@ -917,10 +933,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int i = 0; i < 2; ++i)
           av[i] = *reinterpret_cast<const bf16x8*>(a + sidx * PLANE + i * 32 * QBS_LD + ks * 32);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < NB; ++r) {
+          if (sidx + r >= PMAX) continue;
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[r][j], acc[i][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -937,11 +957,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
   int ncc[2];
   bool nok[2];
+  float cbias[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
     nok[j] = n < p.N;
     ncc[j] = min(n, p.N - 1);
+    cbias[j] = (NB > 1 && p.bias) ? p.bias[ncc[j]] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -965,6 +987,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < 2; ++j)
           if (m < p.M && nok[j]) {
             float v = acc[i][j][eb * 4 + ee] * p.alpha + uu;
+            if (NB > 1) v += cbias[j];
             if (p.accumulate) v += old[ee][j];
             Cb[(int64_t)m * p.ldc + ncc[j]] = v;
           }
@@ -2577,6 +2600,48 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// C[m][n] = sum_k A[m][k] * B[n][k] + bias[n] with BOTH operands fp32: A is split into three bf16 planes in the kernel, B is
+// given pre-split (three bf16 planes [3][N][ldb], B = B_0 + B_1 + B_2 exactly: ofq_split_f32_bf16x3).  products = 9: all
+// plane pairs (the exact product up to fp32 accumulation); 6: the leading ones (dropped terms <= 2^-24 relative).
+extern "C" int ofq_gemm_bf16x3x3_nt(const float* A, const void* B_planes, float* C, const float* bias, int products, int64_t M,
+                                    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t plane_stride,
+                                    ofq_stream_t stream) {
+  if (!A || !B_planes || !C || M <= 0 || N <= 0 || K <= 0 || (products != 6 && products != 9)) return OFQ_EINVAL;
+  if ((K & 7) || (lda & 3) || (ldb & 7) || (plane_stride & 7) || !al16(A) || !al16(B_planes) || M >= (1ll << 30) || N >= (1ll << 30))
+    return OFQ_EINVAL;
+  QGemmArgs a = {};
+  a.A = A; a.B = B_planes; a.C = C; a.bias = bias; a.sBp = plane_stride;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = 1.f; a.nb1 = 1;
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  if (products == 9) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false, 3, 5>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// x (fp32, n elements) -> three bf16 planes p0, p1, p2 with x = p0 + p1 + p2 exactly (each plane the round-to-nearest bf16
+// of what is left): the one-off split of a frozen fp32 weight matrix
+__global__ __launch_bounds__(256) void split_f32_bf16x3_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes,
+                                                               int64_t n, int64_t plane_stride) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = x[i];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const __bf16 h = (__bf16)r;                              // RNE
+    planes[q * plane_stride + i] = __builtin_bit_cast(unsigned short, h);
+    r = __fsub_rn(r, (float)h);                              // exact: the residual fits in fp32
+  }
+}
+extern "C" int ofq_split_f32_bf16x3(const float* x, void* planes, int64_t n, int64_t plane_stride, ofq_stream_t stream) {
+  if (!x || !planes || n <= 0 || plane_stride < n) return OFQ_EINVAL;
+  hipLaunchKernelGGL(split_f32_bf16x3_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)planes, n, plane_stride);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

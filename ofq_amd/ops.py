@@ -696,3 +696,25 @@ def gelu_(x):
     _dev(x, "x")
     _chk(lib().ofq_gelu_fwd(x.data_ptr(), x.data_ptr(), x.numel(), _stream()), "ofq_gelu_fwd")
     return x
+
+
+def split_f32_bf16x3(W):
+    """fp32 matrix -> (3, rows, cols) bf16 planes with W = p0 + p1 + p2 exactly (one-off split of a frozen weight)."""
+    _dev(W, "weight")
+    W = W.contiguous()
+    planes = torch.empty((3,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
+    _chk(lib().ofq_split_f32_bf16x3(W.data_ptr(), planes.data_ptr(), W.numel(), W.numel(), _stream()), "ofq_split_f32_bf16x3")
+    return planes
+
+
+def gemm_bf16x3x3_nt(x2d, planes, bias=None, products=9):
+    """y[M,N] = x2d[M,K] @ W[N,K]^T + bias with W given as its three bf16 planes (split_f32_bf16x3): fp32-grade product on
+    the bf16 matrix cores (products = 9: exact plane pairs; 6: the leading ones)."""
+    _dev(x2d, "x")
+    M, K = x2d.shape
+    N = planes.shape[1]
+    y = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+        _chk(lib().ofq_gemm_bf16x3x3_nt(x2d.data_ptr(), planes.data_ptr(), y.data_ptr(), _p(bias), int(products), M, N, K,
+                                        x2d.stride(0), planes.stride(1), N, planes.stride(0), _stream()), "ofq_gemm_bf16x3x3_nt")
+    return y

@@ -15,13 +15,36 @@ from .functional import pad4
 
 
 class HipTeacher:
-    def __init__(self, model):
+    """gemm: "f32" -- the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak); "bf16x9" / "bf16x6" -- the four
+    linear layers of every block on the bf16 matrix cores: the frozen weights are split ONCE into three bf16 planes
+    (W = W0 + W1 + W2 exactly), the activations are split per tile inside the kernel, and all nine (six leading) plane
+    products are accumulated in fp32 -- the exact product of the fp32 values (up to 2^-24), at 16x the fp32-MFMA
+    instruction rate.  Call refresh() after loading new teacher weights."""
+
+    def __init__(self, model, gemm="bf16x9"):
         self.m = model
         for p in model.parameters():
             p.requires_grad_(False)
         if getattr(model, "dist_token", None) is None:
             raise ValueError("HipTeacher: the KD recipes use the distilled DeiT (deit.py:19)")
+        if gemm not in ("f32", "bf16x9", "bf16x6"):
+            raise ValueError("HipTeacher: gemm must be 'f32', 'bf16x9' or 'bf16x6'")
+        self.gemm = gemm
         self._ones = None
+        self._planes = {}
+
+    def refresh(self):
+        self._planes.clear()
+
+    def _linear(self, x2d, lin):
+        """x2d @ lin.weight^T + lin.bias"""
+        K = lin.weight.shape[1]
+        if self.gemm == "f32" or K % 8 or not lin.weight.is_cuda:
+            return ops.linear_fwd(x2d, lin.weight, lin.bias)
+        pl = self._planes.get(id(lin))
+        if pl is None:
+            pl = self._planes[id(lin)] = ops.split_f32_bf16x3(lin.weight.detach())
+        return ops.gemm_bf16x3x3_nt(x2d, pl, lin.bias, products=9 if self.gemm == "bf16x9" else 6)
 
     def parameters(self):
         return self.m.parameters()
@@ -35,7 +58,7 @@ class HipTeacher:
         H = attn.num_heads
         d = C // H
         Np = pad4(N)
-        qkv = ops.linear_fwd(n1, attn.qkv.weight, attn.qkv.bias)                     # (B*N, 3C): q | k | v column thirds
+        qkv = self._linear(n1, attn.qkv)                                             # (B*N, 3C): q | k | v column thirds
         S = torch.empty((B, H, N, Np), dtype=torch.float32, device=n1.device)
         ops.gemm(qkv, qkv, S, N, N, d, 3 * C, 3 * C, Np, transB=True, nb0=B, nb1=H, sA=(N * 3 * C, d), sB=(N * 3 * C, d),
                  sC=(H * N * Np, N * Np), offB=C)                                     # q k^T per (image, head)
@@ -45,12 +68,12 @@ class HipTeacher:
         O = torch.empty((B * N, C), dtype=torch.float32, device=n1.device)
         ops.gemm(P, qkv, O, N, d, N, Np, 3 * C, C, nb0=B, nb1=H, sA=(H * N * Np, N * Np), sB=(N * 3 * C, d), sC=(N * C, d),
                  offB=2 * C)                                                          # P v, written head-interleaved
-        return ops.linear_fwd(O, attn.proj.weight, attn.proj.bias)
+        return self._linear(O, attn.proj)
 
     def _mlp(self, mlp, n2):
-        h = ops.linear_fwd(n2, mlp.fc1.weight, mlp.fc1.bias)
+        h = self._linear(n2, mlp.fc1)
         ops.gelu_(h)
-        return ops.linear_fwd(h, mlp.fc2.weight, mlp.fc2.bias)
+        return self._linear(h, mlp.fc2)
 
     @torch.no_grad()
     def __call__(self, images):

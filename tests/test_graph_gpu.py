@@ -362,18 +362,39 @@ def test_hip_teacher_forward_equals_the_fp32_deit():
                 p.mul_(3.0)
         model.blocks[3].mlp.fc1.bias.normal_(0, 0.3)
     x = torch.randn(3, 3, 224, 224, device="cuda")
-    teacher = HipTeacher(model)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    for training in (True, False):
-        model.train(training)
-        with torch.no_grad():
-            stock, _ = model(x)
-            got, _ = teacher(x)
-            want = O.deit_fp32_forward(x.cpu(), sd, 12, 3, training=training)
-        pairs = list(zip(got, stock, want)) if training else [(got, stock, want)]
-        for g, s, w in pairs:
-            scale = float(w.abs().max())
-            assert float((g.cpu() - w).abs().max()) < 1e-5 * scale
-            assert float((g - s).abs().max()) < 1e-5 * scale
+    for gemm in ("f32", "bf16x9", "bf16x6"):              # exact-fp32 MFMA; weights pre-split into bf16 planes (9 / 6 products)
+        teacher = HipTeacher(model, gemm=gemm)
+        for training in (True, False):
+            model.train(training)
+            with torch.no_grad():
+                stock, _ = model(x)
+                got, _ = teacher(x)
+                want = O.deit_fp32_forward(x.cpu(), sd, 12, 3, training=training)
+            pairs = list(zip(got, stock, want)) if training else [(got, stock, want)]
+            for g, s, w in pairs:
+                scale = float(w.abs().max())
+                assert float((g.cpu() - w).abs().max()) < 1e-5 * scale, gemm
+                assert float((g - s).abs().max()) < 1e-5 * scale, gemm
     with pytest.raises(RuntimeError):
         teacher(x.cpu())
+
+
+def test_bf16_plane_gemm_is_fp32_grade():
+    """ofq_gemm_bf16x3x3_nt: both operands fp32, A split into bf16 planes in the kernel, B pre-split by ofq_split_f32_bf16x3.
+    The planes reproduce the weights exactly; with all nine plane products the result is as close to the fp64 product as a
+    true fp32 GEMM (torch / hipBLASLt) is, with the six leading ones within 2x of it."""
+    from ofq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M, N, K = 1000, 392, 1536
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.pow(10.0, torch.randint(-3, 3, (M, 1), device="cuda", generator=g).float())
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g)
+    planes = ops.split_f32_bf16x3(W)
+    assert torch.equal(planes[0].float() + planes[1].float() + planes[2].float(), W)          # exact split
+    ref = x.double() @ W.double().t() + b.double()
+    den = (x.double().abs() @ W.double().abs().t()) + 1e-30                                    # the GEMM error scale
+    e_f32 = float(((torch.nn.functional.linear(x, W, b).double() - ref).abs() / den).max())
+    e9 = float(((ops.gemm_bf16x3x3_nt(x, planes, b, products=9).double() - ref).abs() / den).max())
+    e6 = float(((ops.gemm_bf16x3x3_nt(x, planes, b, products=6).double() - ref).abs() / den).max())
+    assert e9 <= 1.5 * e_f32 + 1e-8 and e6 <= 3.0 * e_f32 + 1e-7, (e_f32, e9, e6)
