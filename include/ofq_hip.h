@@ -317,6 +317,12 @@ int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n
  *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
 int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
+
+/* ---- token permutation y[b][i][:] = x[b][idx[i]][:] (x, y: [B][N][C] fp32, C % 4 == 0, x != y; idx: int32[N], a
+ *  permutation of 0..N-1).  Swin's shifted-window partition and its inverse when nothing is padded
+ *  (src/swin.py:103-131 pad -> roll -> view -> permute -> reshape, :160-170 the way back): ONE row gather each way; the
+ *  backward of either is the same call with the inverse permutation. */
+int ofq_permute_tokens(const float* x, const int32_t* idx, float* y, int64_t B, int64_t N, int64_t C, ofq_stream_t stream);
 /*  GEMM of the frozen fp32 teacher on the bf16 matrix cores: C[M][N] = A[M][K] . B[N][K]^T + bias[N], A fp32 (split into
  *  three bf16 planes inside the kernel), B pre-split by ofq_split_f32_bf16x3 into planes[3][plane_stride] (bf16, B = sum of
  *  the planes exactly).  products = 9: every plane pair, i.e. the exact product of the fp32 values up to fp32 accumulation;

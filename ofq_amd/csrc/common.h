@@ -148,11 +148,18 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
   __shared__ float part[RL][CPB + 1];
   const int cx = threadIdx.x % CPB, py = threadIdx.x / CPB;
   const int64_t c = (int64_t)blockIdx.x * CPB + cx;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (jb.dst && c < jb.ncols) {
     const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
     const float* base = jb.src + co;
     int64_t r = py;
+    for (; r + 7 * RL < jb.nrows; r += 8 * RL) {         // thousands of partial rows (Swin windows): eight loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* p = base + (r + RL * u) * jb.row_stride;
+        for (int t = 0; t < jb.cnt; ++t) acc[u] += p[t];
+      }
+    }
     for (; r + 3 * RL < jb.nrows; r += 4 * RL) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
       for (int t = 0; t < jb.cnt; ++t) acc[0] += p[t];
     }
   }
-  part[py][cx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  part[py][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (py == 0 && jb.dst && c < jb.ncols) {
     float s = 0.f;
@@ -176,9 +183,24 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
 }
 
 static inline void strided_sum_launch(const SumJobs& jobs, int64_t maxcols, int njobs, hipStream_t st) {
-  if (maxcols > 2048)
-    hipLaunchKernelGGL(strided_sum_kernel_t<64>, dim3((unsigned)ceil_div(maxcols, 64), njobs), dim3(1024), 0, st, jobs);
+  // jobs with a handful of columns over thousands of partial rows (Swin: 49 window-token scales over every window of
+  // the batch) get their own launch with 256 row lanes per column; the rest go together as before
+  SumJobs deep = jobs, rest = jobs;
+  int64_t deep_cols = 0, rest_cols = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!jobs.j[i].dst) continue;
+    const bool d = jobs.j[i].ncols <= 64 && jobs.j[i].nrows >= 2048;
+    (d ? rest : deep).j[i].dst = nullptr;
+    int64_t& mc = d ? deep_cols : rest_cols;
+    if (jobs.j[i].ncols > mc) mc = jobs.j[i].ncols;
+  }
+  if (deep_cols > 0)
+    hipLaunchKernelGGL(strided_sum_kernel_t<4>, dim3((unsigned)ceil_div(deep_cols, 4), njobs), dim3(1024), 0, st, deep);
+  if (rest_cols <= 0) return;
+  (void)maxcols;
+  if (rest_cols > 2048)
+    hipLaunchKernelGGL(strided_sum_kernel_t<64>, dim3((unsigned)ceil_div(rest_cols, 64), njobs), dim3(1024), 0, st, rest);
   else
-    hipLaunchKernelGGL(strided_sum_kernel_t<16>, dim3((unsigned)ceil_div(maxcols, 16), njobs), dim3(1024), 0, st, jobs);
+    hipLaunchKernelGGL(strided_sum_kernel_t<16>, dim3((unsigned)ceil_div(rest_cols, 16), njobs), dim3(1024), 0, st, rest);
 }
 

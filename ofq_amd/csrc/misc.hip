@@ -239,3 +239,30 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t st
   OFQ_LAUNCH_CHECK();
   return 0;
 }
+
+// y[b][i][:] = x[b][idx[i]][:]: the token permutation of Swin's shifted-window partition / reverse (swin.py:103-131
+// pad-free case: roll + view + permute + reshape collapse into one row gather; the backward is the gather with the inverse
+// permutation).  HBM-bound, 8 B/elt; one float4 per thread, C % 4 == 0.
+__global__ __launch_bounds__(256) void permute_tokens_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                             float* __restrict__ y, int64_t total4, int N, int C4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t row = i / C4;
+  const int c = (int)(i - row * C4);
+  const int64_t b = row / N;
+  const int t = (int)(row - b * N);
+  const float4 v = *reinterpret_cast<const float4*>(x + ((b * N + idx[t]) * C4 + c) * 4);
+  *reinterpret_cast<float4*>(y + i * 4) = v;
+}
+extern "C" int ofq_permute_tokens(const float* x, const int32_t* idx, float* y, int64_t B, int64_t N, int64_t C,
+                                  ofq_stream_t stream) {
+  if (!x || !idx || !y || x == y || B <= 0 || N <= 0 || C <= 0 || (C & 3) || N >= (1ll << 31) || C >= (1ll << 31) ||
+      !al16(x) || !al16(y))
+    return OFQ_EINVAL;
+  const int64_t total4 = B * N * (C / 4);
+  if (ceil_div(total4, 256) >= (1ll << 31)) return OFQ_EINVAL;
+  hipLaunchKernelGGL(permute_tokens_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                     y, total4, (int)N, (int)(C / 4));
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

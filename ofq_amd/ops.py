@@ -690,6 +690,18 @@ def cga_restore(W, frozen, saved):
          "ofq_cga_restore")
 
 
+def permute_tokens(x, idx32):
+    """y[b, i, :] = x[b, idx32[i], :] for x (B, N, C) fp32 contiguous, idx32 an int32 permutation of range(N)."""
+    _dev(x, "x")
+    if x.dim() != 3 or not x.is_contiguous() or x.dtype != torch.float32 or idx32.dtype != torch.int32 \
+            or idx32.numel() != x.shape[1]:
+        raise ValueError("permute_tokens: (B, N, C) contiguous fp32 and an int32 index of length N")
+    y = torch.empty_like(x)
+    _chk(lib().ofq_permute_tokens(x.data_ptr(), idx32.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
+                                  _stream()), "ofq_permute_tokens")
+    return y
+
+
 # ------------------------------------------------------------------------------------------------ fp32 teacher helpers
 def gelu_(x):
     """exact GELU in place"""

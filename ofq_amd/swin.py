@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as F_ofq
+from . import ops
 
 
 class MLP(nn.Sequential):
@@ -85,12 +86,18 @@ class _PermuteTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, inv):
         ctx.save_for_backward(idx, inv)
-        return x.index_select(1, idx)
+        return _permute(x, idx)
 
     @staticmethod
     def backward(ctx, g):
         idx, inv = ctx.saved_tensors
-        return g.index_select(1, inv), None, None
+        return _permute(g, inv), None, None
+
+
+def _permute(x, idx32):
+    if x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+        return ops.permute_tokens(x.contiguous(), idx32)         # csrc/misc.hip, HBM-bound row gather
+    return x.index_select(1, idx32.long())
 
 
 _PERM_CACHE = {}
@@ -126,7 +133,7 @@ class WindowGeometry:
             idx = self._partition_copy(grid, 1).reshape(-1).long()
             inv = torch.empty_like(idx)
             inv[idx] = torch.arange(idx.numel(), device=device)
-            hit = _PERM_CACHE[key] = (idx, inv)
+            hit = _PERM_CACHE[key] = (idx.int(), inv.int())
         return hit
 
     def partition(self, x):
@@ -269,7 +276,9 @@ class SwinTransformer(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def forward_features(self, x):
-        x = (self.features[0](x), None)
+        stem = self.features[0]
+        x = stem[1](stem[0](x))
+        x = (F_ofq.layer_norm(stem[2], x), None)               # the HIP LayerNorm (nn.Sequential would call the stock one)
         infos = []
         for blk in self.features[1:]:
             if isinstance(blk, nn.Sequential):

@@ -127,6 +127,7 @@ def _oracle_lsq_sandwich(x, s, b4, baft, mode, bits, unsigned, gelu, H=1):
     dict(B=3, N=50, C=24, H=1, mode="channel", bits=3, unsigned=False, gelu=False),
     dict(B=3, N=49, C=4608, H=12, mode="token", bits=3, unsigned=False, gelu=False),     # Swin stage 3 qkx: 12 phases > 8 row-groups
     dict(B=2, N=49, C=18432, H=24, mode="token", bits=3, unsigned=False, gelu=False),    # Swin stage 4 qkx
+    dict(B=2304, N=49, C=96, H=1, mode="token", bits=3, unsigned=False, gelu=False),     # Swin stage 1: 49 scales over thousands of windows (deep second-stage sum)
 ])
 def test_lsq_sandwich_vs_oracle(ops, case):
     B, N, C, H = case["B"], case["N"], case["C"], case["H"]
@@ -889,3 +890,19 @@ def test_input_pipeline_kernel_is_bit_exact_vs_oracle(ops, mode):
             assert torch.equal(t.cpu(), tgt)
         if er is not None and trial == 0:
             assert last["rects"] is not None and int((last["rects"][:, 2] > 0).sum()) >= 2
+
+
+def test_permute_tokens_is_the_row_gather(ops):
+    """ofq_permute_tokens (Swin window partition / reverse, swin.py:103-131) == index_select, and the inverse undoes it."""
+    g = torch.Generator().manual_seed(5)
+    for B, N, C in ((3, 3136, 96), (2, 784, 192), (5, 49, 768), (1, 7, 4)):
+        x = torch.randn(B, N, C, generator=g).cuda()
+        idx = torch.randperm(N, generator=g)
+        inv = torch.empty_like(idx)
+        inv[idx] = torch.arange(N)
+        y = ops.permute_tokens(x, idx.int().cuda())
+        assert torch.equal(y.cpu(), x.cpu().index_select(1, idx))
+        assert torch.equal(ops.permute_tokens(y, inv.int().cuda()), x)
+    with pytest.raises(ValueError):
+        ops.permute_tokens(x, idx.cuda())                      # int64 index
+
