@@ -1247,6 +1247,192 @@ __device__ __forceinline__ bf16x8 tr_frag_ld(const unsigned char* base) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- window-sized direct GEMM: one WAVE per (batch, column chunk) ------------------------------------------------------
+// Swin's 49-token windows give C[m][n] = sum_k (sc[k] * A[k][m]) * B[k][n] with M <= 64 and K <= 64 per (window, head):
+// on the 128 x 128 (x 384) tiles above a workgroup lives for one load round trip + one short k-loop, three (one) of them
+// per CU, and the launch is bound by that latency chain, not by HBM or the MFMAs.  Here every wave is its own tile: the
+// fp32 operand goes from global memory straight into MFMA fragment layout (lane = column m, eight consecutive k: dword
+// loads, 128 B per row and half-wave), is split into its three bf16 planes once, in registers, and reused for every 64
+// columns of the int8 operand, which is staged through a wave-private LDS slice ([k][64] bf16, transpose reads).  No
+// workgroup barrier: the four waves of a workgroup are independent, eight waves per CU stay in flight.
+// TRANS = trans_out: the operands swap MFMA roles so that the lanes run along the contiguous output dimension.
+#define QTW_LDB 192                     // bytes per LDS row: 64 bf16 + 64 B pad (4 consecutive k rows on disjoint bank slots)
+#define QTW_SLICE (64 * QTW_LDB + 2 * 64 * 4)
+template <int MB, bool TRANS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB == 2 ? 2 : 3, MB == 2 ? 2 : 3)))
+void qgemm_bf16s_tn_win_kernel(QTnArgs p, int chunks, int cpc, int ntasks) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * QTW_SLICE];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int bx, by_unused;
+  xcd_remap_grid(bx, by_unused);                       // heads of one window share B: keep them on one XCD
+  const int task = bx * 4 + wid;
+  if (task >= ntasks) return;                          // wave-uniform
+  const int pair = task / chunks, chunk = task - pair * chunks;
+  const int b0 = pair / p.nb1, b1 = pair - b0 * p.nb1;
+  unsigned char* sb = smem + wid * QTW_SLICE;
+  float* ssc = reinterpret_cast<float*>(sb + 64 * QTW_LDB);
+  float* scs = ssc + 64;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  ssc[lane] = lane < p.Ktok ? ofq_lsq_eff_scale(p.s[lane % p.S], p.gscale) : 0.f;
+  asm volatile("" ::: "memory");
+
+  // A: fragments straight from global memory, split once
+  const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1;
+  unsigned av[3][4][MB][4];
+  float csum[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int m = 32 * i + l31;
+    const bool mok = m < p.M;
+    const float* Am = Ap + (mok ? m : 0);
+    float cs = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float raw[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * ks + 8 * lh + e;
+        raw[e] = Am[(unsigned)(min(k, p.Ktok - 1) * (int)p.lda)];
+      }
+      const float4 s0 = *reinterpret_cast<const float4*>(ssc + 16 * ks + 8 * lh);
+      const float4 s1 = *reinterpret_cast<const float4*>(ssc + 16 * ks + 8 * lh + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int k = 16 * ks + 8 * lh + e;
+        const float v0 = (mok && k < p.Ktok) ? raw[e] : 0.f;
+        const float v1 = (mok && k + 1 < p.Ktok) ? raw[e + 1] : 0.f;
+        cs += v0;
+        cs += v1;
+        const f32x2v x = {v0 * sc[e], v1 * sc[e + 1]};
+        unsigned pl[3];
+        split_pair_bf16<3>(x, pl);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) av[q][ks][i][e >> 1] = pl[q];
+      }
+    }
+    csum[i] = cs + __shfl_xor(cs, 32, 64);
+  }
+  if (p.baft) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+      if (lh == 0) scs[32 * i + l31] = csum[i];
+    asm volatile("" ::: "memory");
+  }
+
+  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1;
+  float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
+  const int n_end = min(p.N, (chunk + 1) * cpc);
+  const int st_row = lane >> 2, st_col = (lane & 3) * 16;
+  const int p16 = lane & 15;
+  const unsigned char* frb = sb + (8 * lh + (p16 >> 2)) * QTW_LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  auto bload = [&](int n0, i32x4 (&rb)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + st_row, col = n0 + st_col;
+      const bool ok = row < p.Ktok && col < p.N;
+      const i32x4 v = *reinterpret_cast<const i32x4*>(Bp + (unsigned)(min(row, p.Ktok - 1) * (int)p.ldb) + (col < p.N ? col : 0));
+      rb[it] = v & (ok ? -1 : 0);
+    }
+  };
+  i32x4 rb[4];
+  bload(chunk * cpc, rb);
+  for (int n0 = chunk * cpc; n0 < n_end; n0 += 64) {
+    // stage: 16 codes -> 16 bf16 per lane and row group
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      unsigned w[8];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int word = rb[it][d];
+        w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
+        w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
+      }
+      unsigned char* dst = sb + (it * 16 + st_row) * QTW_LDB + st_col * 2;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    asm volatile("" ::: "memory");                     // one wave: its LDS operations execute in program order
+    if (n0 + 64 < n_end) bload(n0 + 64, rb);           // next block's codes fly behind the MFMAs
+    const bool two = n0 + 32 < n_end;                  // a 32-column tail needs one column block only
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      if (j == 1 && !two) break;
+      f32x16q acc[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 bv = tr_frag_ld<QTW_LDB>(frb + ks * 16 * QTW_LDB + j * 64);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) {
+            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v au = {av[q][ks][i][0], av[q][ks][i][1], av[q][ks][i][2], av[q][ks][i][3]};
+            const bf16x8 a = __builtin_bit_cast(bf16x8, au);
+            if (TRANS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, a, acc[i], 0, 0, 0);
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[i], 0, 0, 0);
+          }
+      }
+      // epilogue of the 32-column block
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        if (!TRANS) {
+          const int n = n0 + 32 * j + l31;
+          const bool nok = n < p.Nstore;
+          const float bf = (p.baft && nok) ? p.baft[n + b1 * p.sBf1] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = acc[i][e];
+            if (p.baft) v += scs[m] * bf;
+            if (nok && m < p.Mstore) Cb[(int64_t)m * p.ldc + n] = v;
+          }
+        } else {
+          const int m = 32 * i + l31;
+          const bool mok = m < p.Mstore;
+          const float cm = p.baft ? scs[m] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int n = n0 + 32 * j + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = acc[i][e];
+            if (p.baft && n < p.Nstore) v += cm * p.baft[n + b1 * p.sBf1];
+            if (mok && n < p.Nstore) Cb[(int64_t)n * p.ldc + m] = v;
+          }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");                     // the next block's LDS stores stay behind these fragment reads
+  }
+}
+
+// direct-mode launch of the window kernel when the shape fits one wave tile; returns false when it does not apply
+static bool tn_win_launch(const QTnArgs& a, int64_t batches, hipStream_t st) {
+  static const bool off = getenv("OFQ_NO_WIN_TN") != nullptr;
+  if (off || !a.C || a.split != 1 || a.Ktok > 64 || a.M > 64 || a.S < a.Ktok || (a.N & 15) || (a.ldb & 15) ||
+      a.Ktok * a.lda >= (1ll << 31) || a.Ktok * a.ldb >= (1ll << 31))
+    return false;
+  // one wave walks up to 384 columns with the split planes of its A operand in registers
+  const int cpc = a.N <= 384 ? (int)ceil_div(a.N, 64) * 64 : 384;
+  const int chunks = (int)ceil_div(a.N, cpc);
+  const int64_t ntasks = batches * chunks;
+  if (ntasks >= (1ll << 31)) return false;
+  const dim3 grid((unsigned)ceil_div(ntasks, 4)), block(256);
+  const bool two = a.M > 32;
+  if (a.trans_out) {
+    if (two) hipLaunchKernelGGL((qgemm_bf16s_tn_win_kernel<2, true>), grid, block, 0, st, a, chunks, cpc, (int)ntasks);
+    else hipLaunchKernelGGL((qgemm_bf16s_tn_win_kernel<1, true>), grid, block, 0, st, a, chunks, cpc, (int)ntasks);
+  } else {
+    if (two) hipLaunchKernelGGL((qgemm_bf16s_tn_win_kernel<2, false>), grid, block, 0, st, a, chunks, cpc, (int)ntasks);
+    else hipLaunchKernelGGL((qgemm_bf16s_tn_win_kernel<1, false>), grid, block, 0, st, a, chunks, cpc, (int)ntasks);
+  }
+  return true;
+}
+
 #ifdef TNW_TIMING
 __device__ unsigned long long g_tnw_dbg[8][8];     // [wave][phase] cycles of block 0 (tools/probe/tn_probe.hip)
 #define TNW_T(slot) do { const unsigned long long t_ = clock64(); tacc[slot] += t_ - tlast; tlast = t_; } while (0)
@@ -2944,8 +3130,9 @@ extern "C" int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* 
   a.M = (int)d; a.N = (int)Np; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
   a.Mstore = (int)d; a.Nstore = (int)N; a.trans_out = 1; a.gscale = gscale_p;
   a.tiles_m = (int)ceil_div(d, 128); a.tiles_n = (int)ceil_div(Np, 128);
-  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (!tn_win_launch(a, B * H, (hipStream_t)stream))     // Swin windows: one wave per (window, head)
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                       (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -2959,6 +3146,10 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
   a.M = (int)ldS; a.N = (int)C; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
   a.Mstore = (int)N; a.Nstore = (int)C; a.trans_out = 0; a.gscale = gscale_x;
   a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(C, 128);
+  if (tn_win_launch(a, B * H, (hipStream_t)stream)) {
+    OFQ_LAUNCH_CHECK();
+    return 0;
+  }
   static const bool narrow_only = getenv("OFQ_TN_NARROW") != nullptr;
   if (C % 384 == 0 && N >= QTN_BK && !narrow_only && N * ldS < (1ll << 31) && N * C < (1ll << 31)) {
     a.tiles_n = (int)(C / 384);       // one split of a dS panel feeds all 384 columns
@@ -3001,8 +3192,9 @@ extern "C" int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, f
   a.M = (int)ldS; a.N = (int)d; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
   a.Mstore = (int)N; a.Nstore = (int)d; a.trans_out = 0; a.gscale = gscale_q;
   a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(d, 128);
-  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (!tn_win_launch(a, B * H, (hipStream_t)stream))
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+                       (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -906,3 +906,42 @@ def test_permute_tokens_is_the_row_gather(ops):
     with pytest.raises(ValueError):
         ops.permute_tokens(x, idx.cuda())                      # int64 index
 
+
+@pytest.mark.parametrize("shape", [(37, 3, 49, 32, 64), (5, 12, 49, 32, 64), (3, 24, 49, 32, 64), (6, 2, 64, 16, 64),
+                                   (9, 4, 33, 64, 48), (7, 1, 16, 16, 16)])
+def test_window_sized_attention_backward_kernels_vs_fp64(ops, shape):
+    """Swin-sized (window, head) batches run on the one-wave-per-tile kernel (qgemm_bf16s_tn_win_kernel): dV, dqkx
+    (several 64-column blocks, chunked past 384 columns) and the plain-attention dk, against fp64; the pad columns of dS
+    hold NaN (they only ever meet output rows that are not stored)."""
+    B, H, N, d, Np = shape
+    C = H * d
+    rs = np.random.RandomState(11)
+    gx, gp, gq = 0.011, 0.017, 0.013
+    cu = lambda t: t.cuda()
+    xcodes = torch.from_numpy(rs.randint(-4, 4, (B, N, C)).astype(np.int8))
+    pcodes = torch.zeros(B, H, N, Np, dtype=torch.uint8)
+    pcodes[..., :N] = torch.from_numpy(rs.randint(0, 8, (B, H, N, N)).astype(np.uint8))
+    sx, sp = T(det_uniform((N,), 201, 0.2, 1.0)), T(det_uniform((N,), 203, 0.05, 0.3))
+    bax = T(det_uniform((C,), 205, -0.1, 0.1))
+    ax, ap = O.lsq_effective_scale(sx, gx).double(), O.lsq_effective_scale(sp, gp).double()
+    dO = T(det_normalish((B, N, C), 208, 1.0))
+    ph = ap[None, None, :, None] * pcodes[..., :N].double()
+    dV = ops.qattn_dv(cu(dO), cu(pcodes).view(torch.int8), cu(sp), gp, B, H, N, d, Np)
+    dV_ref = torch.einsum("bhnm,bnhj->bmhj", ph, dO.double().view(B, N, H, d)).reshape(B, N, C)
+    assert rel_err(dV.cpu(), dV_ref.float()) < 2e-6
+    dS = torch.full((B, H, N, Np), float("nan"))
+    dS[..., :N] = T(det_normalish((B, H, N, N), 209, 1.0))
+    xh = ax[None, :, None] * xcodes.double() + bax.double()
+    dq = ops.qattn_dqkx(cu(dS), cu(xcodes), cu(sx), gx, cu(bax), B, H, N, C, Np)
+    dq_ref = torch.einsum("bhnm,bnc->bmhc", dS[..., :N].double(), xh)
+    assert rel_err(dq.cpu(), dq_ref.float()) < 2e-6
+    dq0 = ops.qattn_dqkx(cu(dS), cu(xcodes), cu(sx), gx, None, B, H, N, C, Np)            # no offset term
+    assert rel_err(dq0.cpu(), torch.einsum("bhnm,bnc->bmhc", dS[..., :N].double(), ax[None, :, None] * xcodes.double()).float()) < 2e-6
+    if d % 16 == 0:
+        sq, bq = T(det_uniform((N,), 211, 0.2, 1.0)), T(det_uniform((C,), 212, -0.1, 0.1))
+        aq = O.lsq_effective_scale(sq, gq).double()
+        qh = (aq[None, :, None] * xcodes.double() + bq.double()).view(B, N, H, d)
+        dk = ops.qattn_dk_plain(cu(dS), cu(xcodes), cu(sq), gq, cu(bq), B, H, N, d, Np)
+        dk_ref = torch.einsum("bhnm,bnhj->bmhj", dS[..., :N].double(), qh).reshape(B, N, C)
+        assert rel_err(dk.cpu(), dk_ref.float()) < 2e-6
+
