@@ -1145,6 +1145,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int p16 = lane & 15;
   const int fr_off = (8 * lh + (p16 >> 2)) * QTN_LD + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
 
+  // a wave whose 64 x 64 quarter lies outside the matrix (dV: 64 rows; plain dk / dq: 64 columns) only helps with staging
+  const bool wave_on = (m0 + wm * 64 < p.M) && (n0 + wn * 64 < p.N);
   if (t_begin < t_end) {
     gload(t_begin);
     for (int kt = t_begin; kt < t_end; ++kt) {
@@ -1152,6 +1154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       __syncthreads();
       gload(kt + 1);                       // unconditional (clamped, masked past the end), pinned ahead of the MFMAs
       __builtin_amdgcn_sched_barrier(0);
+      if (wave_on)
 #pragma unroll
       for (int ks = 0; ks < QTN_BK / 16; ++ks) {
         bf16x8 bv[2];
@@ -2108,6 +2111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   const int p16 = lane & 15;
   const int fr_off = (8 * lh + (p16 >> 2)) * QTN_LD + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  const bool wave_on = (m0 + wm * 64 < p.M) && (n0 + wn * 64 < p.N);     // plain dq: 64 columns, half the waves only stage
   gload(0);
   for (int t = 0; t < T; ++t) {
     lstore();
@@ -2115,6 +2119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     gload(min(t + 1, T - 1));          // unconditional (the last one is never stored): no guard, no merged wait state
     __builtin_amdgcn_sched_barrier(0);  // ... and ahead of the MFMAs (the scheduler otherwise sinks the loads below them)
     const unsigned char* a = &smem[(wm * 64 + l31) * QBS_LD + lh * 16];
+    if (wave_on)
 #pragma unroll
     for (int ks = 0; ks < QBS_BK / 16; ++ks) {
       bf16x8 bv[2];
