@@ -1416,9 +1416,12 @@ void qgemm_bf16s_tn_win_kernel(QTnArgs p, int chunks, int cpc, int ntasks) {
 // direct-mode launch of the window kernel when the shape fits one wave tile; returns false when it does not apply
 static bool tn_win_launch(const QTnArgs& a, int64_t batches, hipStream_t st) {
   static const bool off = getenv("OFQ_NO_WIN_TN") != nullptr;
-  if (off || !a.C || a.split != 1 || a.Ktok > 64 || a.M > 64 || a.S < a.Ktok || (a.N & 15) || (a.ldb & 15) ||
-      a.Ktok * a.lda >= (1ll << 31) || a.Ktok * a.ldb >= (1ll << 31))
+  if (off || !a.C || a.split != 1 || (a.N & 15) || (a.ldb & 15) || (int64_t)a.Ktok * a.lda >= (1ll << 31) ||
+      (int64_t)a.Ktok * a.ldb >= (1ll << 31))
     return false;
+  // (a k-chunked form of this tile for the 198-token dV / plain dk was measured and dropped: every wave re-splits its A rows
+  // per 64-column block and stalls on each chunk's loads -- 27.61 vs 27.58 ms/step, no gain over the workgroup tile)
+  if (a.Ktok > 64 || a.M > 64 || a.S < a.Ktok) return false;
   // one wave walks up to 384 columns with the split planes of its A operand in registers
   const int cpc = a.N <= 384 ? (int)ceil_div(a.N, 64) * 64 : 384;
   const int chunks = (int)ceil_div(a.N, cpc);

@@ -908,11 +908,12 @@ def test_permute_tokens_is_the_row_gather(ops):
 
 
 @pytest.mark.parametrize("shape", [(37, 3, 49, 32, 64), (5, 12, 49, 32, 64), (3, 24, 49, 32, 64), (6, 2, 64, 16, 64),
-                                   (9, 4, 33, 64, 48), (7, 1, 16, 16, 16)])
+                                   (9, 4, 33, 64, 48), (7, 1, 16, 16, 16),
+                                   (2, 6, 198, 64, 208), (3, 3, 198, 64, 208), (2, 2, 100, 32, 112), (2, 1, 65, 16, 80)])
 def test_window_sized_attention_backward_kernels_vs_fp64(ops, shape):
     """Swin-sized (window, head) batches run on the one-wave-per-tile kernel (qgemm_bf16s_tn_win_kernel): dV, dqkx
     (several 64-column blocks, chunked past 384 columns) and the plain-attention dk, against fp64; the pad columns of dS
-    hold NaN (they only ever meet output rows that are not stored)."""
+    hold NaN (they only ever meet output rows that are not stored).  The 198-token shapes take the workgroup-tile kernels (same entry points)."""
     B, H, N, d, Np = shape
     C = H * d
     rs = np.random.RandomState(11)
