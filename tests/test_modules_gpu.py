@@ -570,7 +570,8 @@ def test_zero_rowsum_term_of_dxhat_is_rounding_residue():
     """The product drops `rowsum(dS) * move_qkx_aft` from dx_hat (functional.QKRScoresCodesFn.backward): dS is a softmax
     backward, its rows sum to zero, so the term the reference's autograd adds (attention.py:207-210) is fp32 rounding
     residue.  With functional.KEEP_ZERO_ROWSUM_TERM the term is computed as the reference does; every gradient of a full
-    QKR model must agree with the default path to 1e-6 of its scale (1e-3 is the parity tolerance)."""
+    QKR model must agree with the default path to 1e-6 of its scale (5e-6 for the scalar step sizes; 1e-3 is the parity
+    tolerance)."""
     import copy
     from ofq_amd import engine, functional as F_ofq
     from ofq_amd.quantization.utils import KDLossSoftandHard
@@ -603,5 +604,6 @@ def test_zero_rowsum_term_of_dxhat_is_rounding_residue():
         a, b = grads[0][n], grads[1][n]
         differs |= not torch.equal(a, b)
         e = float((a - b).abs().max()) / off_scale if "move_" in n else rel_err(a, b)
-        assert e < 1e-6, (n, e)
+        # scalar step sizes are sums of ~10^5-10^6 signed terms (the image quantiser's: 600k): their residue sits at 1e-6
+        assert e < (5e-6 if n.endswith(".s") else 1e-6), (n, e)
     assert differs          # the switch really changes the computation (it adds the residue)

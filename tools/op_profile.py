@@ -21,6 +21,9 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     engine.train_step(model, opt, x, y, s, lf)
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.device_time_total > 0]
+if os.environ.get("ATEN_ONLY"):
+    rows = [e for e in rows if e.key.startswith("aten::")]
+    print("aten:: total device us: %.1f" % sum(e.self_device_time_total for e in rows))
 rows.sort(key=lambda e: -e.device_time_total)
 print("%-42s %6s %10s  %s" % ("op", "calls", "device_us", "shapes"))
 for e in rows[:28]:
