@@ -183,11 +183,35 @@ def self_launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # rank 0's stdout is read by a thread (its pipe must drain) while the parent watches every child: a rank that dies
+    # would leave the others waiting in a collective for ever, so the first failure ends the rest (exact PIDs only)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0):
+                failed = (r, rc)
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print("bench.py: rank %d exited with code %d; the other ranks were stopped" % failed, file=sys.stderr)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    raise SystemExit(max(abs(c) for c in codes))
+    codes = [p.wait() for p in procs]
+    raise SystemExit(max(abs(c) for c in codes) if failed is None else (abs(failed[1]) or 1))
 
 
 def main():

@@ -243,3 +243,20 @@ def test_input_pipeline_host_draws_follow_timm_formulas():
     assert (erased[:, 0] + erased[:, 2] <= 224).all() and (erased[:, 1] + erased[:, 3] <= 224).all()
     mp.mixup_enabled = False                                                 # train.py:865-869 (mixup_off_epoch)
     assert mp.draw(224, 224) == (1.0, False, (0, 0, 0, 0))
+
+
+def test_bench_self_launch_ends_every_rank_when_one_fails():
+    """`bench.py --gpus N` starts N child ranks itself.  Without a HIP device every child exits with an
+    error: the parent must come back promptly with a non-zero code instead of waiting on a rank that will never answer."""
+    import subprocess, sys, os, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.argv=['bench.py','--gpus','2','--steps','1','--warmup','0'];"
+            "torch.cuda.device_count=lambda: 2; sys.path.insert(0, %r); import bench; bench.main()" % root)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, timeout=300,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert r.returncode != 0
+    assert b"HIP device" in r.stderr
+    assert b'"metric"' not in r.stdout
+    assert time.time() - t0 < 240
+
