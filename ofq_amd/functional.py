@@ -455,6 +455,18 @@ class QKVSplitLsqCodesFn(torch.autograd.Function):
                 res[2][1], None, None, None)
 
 
+_HEAD_MASKS = {}
+
+
+def _head_mask(H, d, dev):
+    """(H, H*d) 0/1 matrix, row h selects the channels of head h (a constant: built once per geometry and device)."""
+    key = (H, d, str(dev))
+    m = _HEAD_MASKS.get(key)
+    if m is None:
+        m = _HEAD_MASKS[key] = torch.eye(H, device=dev, dtype=torch.float32).repeat_interleave(d, dim=1)
+    return m
+
+
 class QKScoresCodesFn(torch.autograd.Function):
     """Plain attention scores on the codes: S[b,h,n,m] = q_hat[b,n,hd:hd+d] . k_hat[b,m,hd:hd+d], one exact int8 GEMM
     per (b, h) plus the offset terms in its epilogue; backward = two bf16-split GEMMs per (b, h)."""
@@ -468,7 +480,7 @@ class QKScoresCodesFn(torch.autograd.Function):
         dev = q.device
         # per-head offset vectors as H rows of length C with zeros outside the head's channels: the per-head dot products
         # of the codes with the other operand's offsets are plain row dots against them
-        eye = torch.eye(H, device=dev, dtype=torch.float32).repeat_interleave(d, dim=1)       # (H, C)
+        eye = _head_mask(H, d, dev)                                                           # (H, C), cached
         u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), eye * aux["bk"])                 # [B*N, H]: qq . bk|head
         tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), eye * aux["bq"])                # [B*N, H]: bq|head . qk
         z = (aux["bq"] * aux["bk"]).view(H, d).sum(1)
@@ -586,7 +598,7 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         if plain:
             B, N, C = a_carrier.shape
             CK = C // H
-            eye = torch.eye(H, device=a_carrier.device, dtype=torch.float32).repeat_interleave(CK, dim=1)
+            eye = _head_mask(H, CK, a_carrier.device)
             u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), eye * aux["bk"])
             tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), eye * aux["bq"])
             z = (aux["bq"] * aux["bk"]).view(H, CK).sum(1)

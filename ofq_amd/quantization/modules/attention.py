@@ -107,11 +107,14 @@ class QAttention(deit_attention):
 def _plain_lazy_init(self, qkv):
     B, N, C3 = qkv.shape
     C = C3 // 3
+    todo = [(i, qz) for i, qz in enumerate((self.quan_a_q_fn, self.quan_a_k_fn, self.quan_a_v_fn))
+            if not qz.initialized_alpha or qz.s is None]
+    if not todo:
+        return                                          # every later step: nothing to do (and no qkv-sized add)
     with torch.no_grad():
         t = qkv.detach() + self.move_qkv_b4.bias.detach()
-        for i, qz in enumerate((self.quan_a_q_fn, self.quan_a_k_fn, self.quan_a_v_fn)):
-            if not qz.initialized_alpha or qz.s is None:
-                qz.init_from(t[..., i * C:(i + 1) * C])
+        for i, qz in todo:
+            qz.init_from(t[..., i * C:(i + 1) * C])
 
 
 def plain_attention_core(self, x, scale, addend=None, pre_quant=None):

@@ -35,6 +35,9 @@ class Permute(nn.Module):
         return torch.permute(x, self.dims)
 
 
+_MERGE_PERM = {}
+
+
 class PatchMerging(nn.Module):
     def __init__(self, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -42,11 +45,30 @@ class PatchMerging(nn.Module):
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
+    @staticmethod
+    def _gather4(fx):
+        return torch.cat([fx[..., 0::2, 0::2, :], fx[..., 1::2, 0::2, :], fx[..., 0::2, 1::2, :], fx[..., 1::2, 1::2, :]], -1)
+
     def forward(self, x):
         fx, info = x
-        H, W, _ = fx.shape[-3:]
-        fx = F.pad(fx, (0, 0, 0, W % 2, 0, H % 2))
-        fx = torch.cat([fx[..., 0::2, 0::2, :], fx[..., 1::2, 0::2, :], fx[..., 0::2, 1::2, :], fx[..., 1::2, 1::2, :]], -1)
+        H, W, C = fx.shape[-3:]
+        if H % 2 == 0 and W % 2 == 0 and fx.is_cuda and fx.dim() == 4 and fx.dtype == torch.float32 and C % 4 == 0:
+            # even maps (every stage of the 224-px recipes): the 2x2 neighbourhood gather is a permutation of the tokens --
+            # one row-gather kernel each way instead of pad + four strided slices + cat (and four slice_backward + three
+            # adds on the way back); the index is built by pushing the token numbers through the very same slicing code
+            key = (H, W, str(fx.device))
+            hit = _MERGE_PERM.get(key)
+            if hit is None:
+                grid = torch.arange(H * W, device=fx.device, dtype=torch.float32).view(1, H, W, 1)
+                idx = self._gather4(grid).reshape(-1).long()
+                inv = torch.empty_like(idx)
+                inv[idx] = torch.arange(idx.numel(), device=fx.device)
+                hit = _MERGE_PERM[key] = (idx.int(), inv.int())
+            B = fx.shape[0]
+            fx = _PermuteTokensFn.apply(fx.reshape(B, H * W, C), hit[0], hit[1]).view(B, H // 2, W // 2, 4 * C)
+        else:
+            fx = F.pad(fx, (0, 0, 0, W % 2, 0, H % 2))
+            fx = self._gather4(fx)
         return self.reduction(F_ofq.layer_norm(self.norm, fx)), info
 
 
@@ -61,8 +83,21 @@ def relative_position_index(window_size):
     return rel.sum(-1).view(-1)
 
 
+_MASK_CACHE = {}
+
+
 def shift_attention_mask(pad_H, pad_W, window_size, shift_size, device):
-    """(num_windows, N, N) additive mask of the shifted-window scheme: 0 inside a region, -100 across (swin.py:134-151)"""
+    """(num_windows, N, N) additive mask of the shifted-window scheme: 0 inside a region, -100 across (swin.py:134-151).
+    A constant of the geometry: built once per (map size, window, shift, device) instead of ~25 small kernels per block and
+    step."""
+    key = (pad_H, pad_W, tuple(window_size), tuple(shift_size), str(device))
+    m = _MASK_CACHE.get(key)
+    if m is None:
+        m = _MASK_CACHE[key] = _shift_attention_mask(pad_H, pad_W, window_size, shift_size, device)
+    return m
+
+
+def _shift_attention_mask(pad_H, pad_W, window_size, shift_size, device):
     m = torch.zeros((pad_H, pad_W), device=device)
     hs = ((0, -window_size[0]), (-window_size[0], -shift_size[0]), (-shift_size[0], None))
     ws = ((0, -window_size[1]), (-window_size[1], -shift_size[1]), (-shift_size[1], None))
@@ -76,6 +111,36 @@ def shift_attention_mask(pad_H, pad_W, window_size, shift_size, device):
     m = m.permute(0, 2, 1, 3).reshape(nw, window_size[0] * window_size[1])
     m = m.unsqueeze(1) - m.unsqueeze(2)
     return m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
+
+
+class _RelPosBiasFn(torch.autograd.Function):
+    """table[index] (swin.py:232-238, (2*ws-1)^2 x heads -> N*N x heads).  Autograd's backward of the gather is an
+    index_put_ with accumulate (60 us per block on sorted keys); here it is one small matmul with the constant 0/1 matrix
+    of the index, deterministic."""
+
+    @staticmethod
+    def forward(ctx, table, index, onehot_t):
+        ctx.save_for_backward(onehot_t)
+        return table.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (onehot_t,) = ctx.saved_tensors
+        return onehot_t @ g.reshape(onehot_t.shape[1], -1), None, None
+
+
+_ONEHOT_CACHE = {}
+
+
+def _rel_bias(table, index):
+    key = (index.data_ptr(), index.numel(), table.shape[0], str(table.device))
+    hit = _ONEHOT_CACHE.get(key)
+    if hit is None or hit[0] is not index:
+        idx = index.to(table.device).long()
+        oh = torch.zeros(table.shape[0], idx.numel(), device=table.device, dtype=table.dtype)
+        oh[idx, torch.arange(idx.numel(), device=table.device)] = 1.0
+        hit = _ONEHOT_CACHE[key] = (index, idx, oh)
+    return _RelPosBiasFn.apply(table, hit[1], hit[2])
 
 
 class _PermuteTokensFn(torch.autograd.Function):
@@ -165,7 +230,8 @@ class WindowGeometry:
     def addend(self, table, index, num_heads):
         """(P, N, N) additive term of the softmax: relative-position bias per head (+ shift mask per window);
         slab index = window * heads + head, P = heads (no shift) or windows * heads."""
-        bias = table[index].view(self.N, self.N, -1).permute(2, 0, 1)               # (heads, N, N)
+        gather = _rel_bias(table, index) if table.is_cuda else table[index]
+        bias = gather.view(self.N, self.N, -1).permute(2, 0, 1)                     # (heads, N, N)
         if sum(self.ss) == 0:
             return bias.contiguous()
         mask = shift_attention_mask(self.pH, self.pW, self.ws, self.ss, table.device)  # (nW, N, N)

@@ -26,5 +26,7 @@ if os.environ.get("ATEN_ONLY"):
     print("aten:: total device us: %.1f" % sum(e.self_device_time_total for e in rows))
 rows.sort(key=lambda e: -e.device_time_total)
 print("%-42s %6s %10s  %s" % ("op", "calls", "device_us", "shapes"))
-for e in rows[:28]:
+if os.environ.get("ATEN_FILTER"):
+    rows = [e for e in rows if os.environ["ATEN_FILTER"] in e.key]
+for e in rows[:int(os.environ.get("TOP", "28"))]:
     print("%-42s %6d %10.1f  %s" % (e.key[:42], e.count, e.device_time_total, str(e.input_shapes)[:110]))
