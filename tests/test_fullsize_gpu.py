@@ -225,3 +225,54 @@ def test_swin_window_attention_full_size_code_path_equals_fp32_gemm_path(ops, qk
         if "move_" not in n and not n.endswith(".s"):
             visible = float(((a - b).abs() > 1e-2 * float(b.abs().max())).double().mean())
             assert visible < 2e-3, (n, visible)
+
+
+@pytest.mark.parametrize("hw", [(56, 56, 96), (28, 28, 192), (14, 14, 384), (6, 10, 8)])
+def test_swin_patch_merging_permutation_equals_the_slicing_path(ops, hw):
+    """PatchMerging gathers the 2x2 neighbourhoods with ONE token permutation each way on even maps (swin.py); forward and
+    input gradient must equal the reference formulation (pad + four strided slices + cat, src/swin.py:45-60) bit for bit
+    at the sizes of Swin-T's three mergings."""
+    from ofq_amd import swin
+    H, W, C = hw
+    B = 8 if H > 20 else 16
+    g = torch.Generator().manual_seed(H + C)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    gy = torch.randn(B, H // 2, W // 2, 4 * C, generator=g).cuda()
+    pm = swin.PatchMerging(C).cuda()
+    xa = x.clone().requires_grad_(True)
+    ya, _ = pm((xa, None))
+    xb = x.clone().requires_grad_(True)
+    fx = torch.nn.functional.pad(xb, (0, 0, 0, W % 2, 0, H % 2))
+    yb = pm.reduction(swin.F_ofq.layer_norm(pm.norm, swin.PatchMerging._gather4(fx)))
+    assert torch.equal(ya, yb)
+    gout = torch.randn_like(ya)
+    ya.backward(gout)
+    yb.backward(gout)
+    assert torch.equal(xa.grad, xb.grad)
+    del gy
+
+
+def test_swin_relative_position_bias_backward_equals_autograd(ops):
+    """table[index] with the one-hot-matmul backward (swin._RelPosBiasFn) against autograd's index_put_ backward."""
+    from ofq_amd import swin
+    idx = swin.relative_position_index([7, 7]).cuda()
+    for H in (3, 6, 12, 24):
+        t1 = torch.randn(169, H, device="cuda", requires_grad=True)
+        t2 = t1.detach().clone().requires_grad_(True)
+        a = swin._rel_bias(t1, idx)
+        b = t2[idx]
+        assert torch.equal(a, b)
+        g = torch.randn_like(a)
+        a.backward(g)
+        b.backward(g)
+        assert rel_err(t1.grad, t2.grad) < 1e-6
+
+
+def test_swin_shift_mask_is_cached_and_correct(ops):
+    from ofq_amd import swin
+    m1 = swin.shift_attention_mask(56, 56, [7, 7], [3, 3], torch.device("cuda"))
+    m2 = swin.shift_attention_mask(56, 56, [7, 7], [3, 3], torch.device("cuda"))
+    assert m1 is m2 and m1.shape == (64, 49, 49)
+    assert torch.equal(m1, swin._shift_attention_mask(56, 56, [7, 7], [3, 3], torch.device("cuda")))
+    assert set(m1.unique().tolist()) == {-100.0, 0.0}
+
