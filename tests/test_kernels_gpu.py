@@ -930,6 +930,16 @@ def test_window_sized_attention_backward_kernels_vs_fp64(ops, shape):
     dV = ops.qattn_dv(cu(dO), cu(pcodes).view(torch.int8), cu(sp), gp, B, H, N, d, Np)
     dV_ref = torch.einsum("bhnm,bnhj->bmhj", ph, dO.double().view(B, N, H, d)).reshape(B, N, C)
     assert rel_err(dV.cpu(), dV_ref.float()) < 2e-6
+    # dP on wave tiles (qgemm_bf16s_nt_win_kernel): per-channel step of v, per-row addend w
+    gv = 0.019
+    vcodes = torch.from_numpy(rs.randint(-8, 8, (B, N, C)).astype(np.int8))
+    sv, bav = T(det_uniform((C,), 204, 0.2, 1.0)), T(det_uniform((C,), 207, -0.1, 0.1))
+    av = O.lsq_effective_scale(sv, gv).double()
+    w = ops.rowdot_f32_seg(cu(dO).view(B * N, C), cu(bav), H, d)
+    dP = ops.qattn_dp(cu(dO), cu(vcodes), cu(sv), gv, w, B, H, N, d, Np)
+    vh = av * vcodes.double() + bav.double()
+    dP_ref = torch.einsum("bnhj,bmhj->bhnm", dO.double().view(B, N, H, d), vh.view(B, N, H, d))
+    assert rel_err(dP.cpu()[..., :N], dP_ref.float()) < 2e-6
     dS = torch.full((B, H, N, Np), float("nan"))
     dS[..., :N] = T(det_normalish((B, H, N, N), 209, 1.0))
     xh = ax[None, :, None] * xcodes.double() + bax.double()
