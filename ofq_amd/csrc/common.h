@@ -141,6 +141,19 @@ struct SumJobs { SumJob j[5]; };
 // hundred rows deep, so the kernel is a chain of dependent L2 round trips unless many loads are in flight.  CPB = 64
 // (one 256-B line per row) for wide jobs, 16 when the job has few columns, so that enough workgroups exist.
 #define OFQ_SUM_COLS 64
+// sum of `cnt` consecutive partials of one (row, column): eight loads in flight (the image quantiser's step gradient has
+// 98 of them per row: as a chain of dependent loads that one job took 131 - 250 us per step)
+__device__ __forceinline__ float ofq_sum_run(const float* __restrict__ p, int cnt) {
+  if (cnt == 1) return p[0];
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int t = 0;
+  for (; t + 7 < cnt; t += 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += p[t + e];
+  }
+  for (; t < cnt; ++t) s[0] += p[t];
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
 template <int CPB>
 __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
   constexpr int RL = 1024 / CPB;
@@ -155,22 +168,13 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
     int64_t r = py;
     for (; r + 7 * RL < jb.nrows; r += 8 * RL) {         // thousands of partial rows (Swin windows): eight loads in flight
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* p = base + (r + RL * u) * jb.row_stride;
-        for (int t = 0; t < jb.cnt; ++t) acc[u] += p[t];
-      }
+      for (int u = 0; u < 8; ++u) acc[u] += ofq_sum_run(base + (r + RL * u) * jb.row_stride, jb.cnt);
     }
     for (; r + 3 * RL < jb.nrows; r += 4 * RL) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* p = base + (r + RL * u) * jb.row_stride;
-        for (int t = 0; t < jb.cnt; ++t) acc[u] += p[t];
-      }
+      for (int u = 0; u < 4; ++u) acc[u] += ofq_sum_run(base + (r + RL * u) * jb.row_stride, jb.cnt);
     }
-    for (; r < jb.nrows; r += RL) {
-      const float* p = base + r * jb.row_stride;
-      for (int t = 0; t < jb.cnt; ++t) acc[0] += p[t];
-    }
+    for (; r < jb.nrows; r += RL) acc[0] += ofq_sum_run(base + r * jb.row_stride, jb.cnt);
   }
   part[py][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
