@@ -2226,8 +2226,7 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
   float acc = 0.f;
   if (n < N) {
     const int8_t* row = codes + (int64_t)n * K;
-    for (int k = l16 * 16; k < K; k += 256) {
-      const i32x4 c = *reinterpret_cast<const i32x4*>(row + k);
+    auto chunk = [&](int k, const i32x4& c) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const float4 v = *reinterpret_cast<const float4*>(vec + k + 4 * w);
@@ -2235,6 +2234,16 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
         acc += v.x * (float)(signed char)(word & 0xff) + v.y * (float)(signed char)((word >> 8) & 0xff) +
                v.z * (float)(signed char)((word >> 16) & 0xff) + v.w * (float)(word >> 24);
       }
+    };
+    const int k0 = l16 * 16;
+    if (K <= 512) {                      // both 256-byte halves of the row are in flight together (K = 384: the attention prep)
+      const bool in0 = k0 < K, in1 = k0 + 256 < K;
+      const i32x4 c0 = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
+      const i32x4 c1 = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
+      if (in0) chunk(k0, c0);
+      if (in1) chunk(k0 + 256, c1);
+    } else {
+      for (int k = k0; k < K; k += 256) chunk(k, *reinterpret_cast<const i32x4*>(row + k));
     }
   }
 #pragma unroll
@@ -2958,12 +2967,36 @@ __global__ __launch_bounds__(256) void rowdot_f32_seg_kernel(const float* __rest
 }
 
 // batched int8 transpose with zero padding: in [B][R][Cc] -> out [B][Cc][Rp]  (V codes for the P*V product)
-__device__ __forceinline__ void codes_transpose_i8_body(int bx, int by, int bz, int8_t (*tile)[33], const int8_t* __restrict__ in,
+__device__ __forceinline__ void codes_transpose_i8_body(int bx, int by, int bz, int8_t (*tile)[36], const int8_t* __restrict__ in,
                                                         int8_t* __restrict__ out, int R, int Cc, int Rp) {
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // 32 x 32 bytes per tile: one dword load per thread (four consecutive columns of one row), its bytes scattered into the
+  // transposed LDS tile, one dword store per thread (four consecutive rows of one column).  Cc % 4 == 0 and Rp % 4 == 0
+  // (host check), so a dword is all inside or all outside the matrices.
   const int r0 = by * 32, c0 = bx * 32;
   const int8_t* ib = in + (int64_t)bz * R * Cc;
   int8_t* ob = out + (int64_t)bz * Cc * Rp;
+  {
+    const int r = r0 + (threadIdx.x >> 3), cq = (threadIdx.x & 7) * 4, c = c0 + cq;
+    int word = 0;
+    if (r < R && c < Cc) word = *reinterpret_cast<const int*>(ib + (int64_t)r * Cc + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[cq + j][threadIdx.x >> 3] = (int8_t)((word >> (8 * j)) & 0xff);
+  }
+  __syncthreads();
+  {
+    const int cc = threadIdx.x >> 3, rq = (threadIdx.x & 7) * 4;
+    const int c = c0 + cc, r = r0 + rq;
+    if (c < Cc && r < Rp) *reinterpret_cast<int*>(ob + (int64_t)c * Rp + r) = *reinterpret_cast<const int*>(&tile[cc][rq]);
+  }
+}
+// any size / alignment, one byte per access
+__global__ __launch_bounds__(256) void codes_transpose_i8_bytes_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out,
+                                                                       int R, int Cc, int Rp) {
+  __shared__ int8_t tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int8_t* ib = in + (int64_t)blockIdx.z * R * Cc;
+  int8_t* ob = out + (int64_t)blockIdx.z * Cc * Rp;
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
     tile[i][tx] = (r < R && c < Cc) ? ib[(int64_t)r * Cc + c] : (int8_t)0;
@@ -2976,7 +3009,7 @@ __device__ __forceinline__ void codes_transpose_i8_body(int bx, int by, int bz, 
 }
 __global__ __launch_bounds__(256) void codes_transpose_i8_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out, int R,
                                                                  int Cc, int Rp) {
-  __shared__ int8_t tile[32][33];
+  __shared__ __attribute__((aligned(16))) int8_t tile[32][36];
   codes_transpose_i8_body(blockIdx.x, blockIdx.y, blockIdx.z, tile, in, out, R, Cc, Rp);
 }
 
@@ -2990,7 +3023,7 @@ struct AttnPrepArgs {
   int R0, R1, C, H, N, Np, nb0, nb1, tx2, ty2;               // nb0 / nb1: blocks of job 0 / 1; job 2 grid: tx2 x ty2 x B
 };
 __global__ __launch_bounds__(256) void qattn_prep_kernel(AttnPrepArgs a) {
-  __shared__ int8_t tile[32][33];
+  __shared__ __attribute__((aligned(16))) int8_t tile[32][36];
   int b = blockIdx.x;
   if (b < a.nb0) { rowdot_i8_multi_v16_body(b, a.xcodes, a.baq, a.u, a.R0, a.C, a.H); return; }
   b -= a.nb0;
@@ -3003,7 +3036,9 @@ extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, 
                               const int8_t* vcodes, int8_t* vT, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np,
                               ofq_stream_t stream) {
   if (!xcodes || !baq || !u || !qcodes || !bax || !tq || !vcodes || !vT || B <= 0 || H <= 0 || N <= 0 || Np < N) return OFQ_EINVAL;
-  if ((C & 15) || C > 512 || !al16(xcodes) || !al16(qcodes) || !al16(baq) || !al16(bax) || B * N * H >= (1ll << 31)) return OFQ_EINVAL;
+  if ((C & 15) || (Np & 3) || C > 512 || !al16(xcodes) || !al16(qcodes) || !al16(baq) || !al16(bax) || !al16(vcodes) || !al16(vT) ||
+      B * N * H >= (1ll << 31))
+    return OFQ_EINVAL;
   AttnPrepArgs a = {};
   a.xcodes = xcodes; a.baq = baq; a.u = u; a.qcodes = qcodes; a.bax = bax; a.tq = tq; a.vcodes = vcodes; a.vT = vT;
   a.R0 = (int)(B * N); a.R1 = (int)(B * N * H); a.C = (int)C; a.H = (int)H; a.N = (int)N; a.Np = (int)Np;
@@ -3039,8 +3074,13 @@ extern "C" int ofq_rowdot_f32_seg(const float* x, const float* vec, float* out, 
 extern "C" int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t batches, int64_t rows, int64_t cols, int64_t rows_padded,
                                       ofq_stream_t stream) {
   if (!in || !out || batches <= 0 || rows <= 0 || cols <= 0 || rows_padded < rows) return OFQ_EINVAL;
-  hipLaunchKernelGGL(codes_transpose_i8_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows_padded, 32), (unsigned)batches),
-                     dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols, (int)rows_padded);
+  const dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows_padded, 32), (unsigned)batches);
+  if ((cols & 3) == 0 && (rows_padded & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0)
+    hipLaunchKernelGGL(codes_transpose_i8_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols,
+                       (int)rows_padded);
+  else
+    hipLaunchKernelGGL(codes_transpose_i8_bytes_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols,
+                       (int)rows_padded);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

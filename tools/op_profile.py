@@ -24,7 +24,7 @@ rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.device_time
 if os.environ.get("ATEN_ONLY"):
     rows = [e for e in rows if e.key.startswith("aten::")]
     print("aten:: total device us: %.1f" % sum(e.self_device_time_total for e in rows))
-rows.sort(key=lambda e: -e.device_time_total)
+rows.sort(key=lambda e: -(e.count if os.environ.get("BY_COUNT") else e.device_time_total))
 print("%-42s %6s %10s  %s" % ("op", "calls", "device_us", "shapes"))
 if os.environ.get("ATEN_FILTER"):
     rows = [e for e in rows if os.environ["ATEN_FILTER"] in e.key]
