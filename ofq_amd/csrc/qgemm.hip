@@ -2219,36 +2219,71 @@ __global__ __launch_bounds__(256) void rowdot_i8_kernel(const int8_t* __restrict
 }
 
 // same, 16 codes per load: a row is owned by 16 lanes (K % 16 == 0, 16-byte aligned rows)
+#define RD16_RPG 4                        // rows per 16-lane group: 64 rows per workgroup, six 16-byte loads in flight per lane
 __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restrict__ codes, const float* __restrict__ vec,
                                                    float* __restrict__ out, int N, int K) {
   const int l16 = threadIdx.x & 15;
-  const int n = bx * 16 + (threadIdx.x >> 4);
-  float acc = 0.f;
-  if (n < N) {
-    const int8_t* row = codes + (int64_t)n * K;
-    auto chunk = [&](int k, const i32x4& c) {
+  const int nb = bx * (16 * RD16_RPG) + (threadIdx.x >> 4);
+  const int k0 = l16 * 16;
+  float acc[RD16_RPG];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float4 v = *reinterpret_cast<const float4*>(vec + k + 4 * w);
-        const int word = c[w];
-        acc += v.x * (float)(signed char)(word & 0xff) + v.y * (float)(signed char)((word >> 8) & 0xff) +
-               v.z * (float)(signed char)((word >> 16) & 0xff) + v.w * (float)(word >> 24);
+  for (int j = 0; j < RD16_RPG; ++j) acc[j] = 0.f;
+  auto fma16 = [&](float& a, int k, const i32x4& c, const float4 (&v)[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int word = c[w];
+      a += v[w].x * (float)(signed char)(word & 0xff) + v[w].y * (float)(signed char)((word >> 8) & 0xff) +
+           v[w].z * (float)(signed char)((word >> 16) & 0xff) + v[w].w * (float)(word >> 24);
+    }
+  };
+  if (K <= 512) {
+    // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
+    // for the four rows of the group
+    const bool in0 = k0 < K, in1 = k0 + 256 < K;
+    i32x4 c0[RD16_RPG], c1[RD16_RPG];
+#pragma unroll
+    for (int j = 0; j < RD16_RPG; ++j) {
+      const int n = min(nb + 16 * j, N - 1);
+      const int8_t* row = codes + (int64_t)n * K;
+      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
+      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
+    }
+    if (in0) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
+    }
+    if (in1) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < RD16_RPG; ++j) {
+      const int n = nb + 16 * j;
+      if (n >= N) continue;
+      const int8_t* row = codes + (int64_t)n * K;
+      for (int k = k0; k < K; k += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k + 4 * w);
+        fma16(acc[j], k, *reinterpret_cast<const i32x4*>(row + k), v);
       }
-    };
-    const int k0 = l16 * 16;
-    if (K <= 512) {                      // both 256-byte halves of the row are in flight together (K = 384: the attention prep)
-      const bool in0 = k0 < K, in1 = k0 + 256 < K;
-      const i32x4 c0 = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
-      const i32x4 c1 = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
-      if (in0) chunk(k0, c0);
-      if (in1) chunk(k0 + 256, c1);
-    } else {
-      for (int k = k0; k < K; k += 256) chunk(k, *reinterpret_cast<const i32x4*>(row + k));
     }
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (n < N && l16 == 0) out[n] = acc;
+  for (int j = 0; j < RD16_RPG; ++j) {
+    float a = acc[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    const int n = nb + 16 * j;
+    if (n < N && l16 == 0) out[n] = a;
+  }
 }
 __global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vec,
                                                             float* __restrict__ out, int N, int K) {
@@ -2267,7 +2302,7 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
                              ofq_stream_t stream) {
   if (!codes || !vec || !out || rows <= 0 || cols <= 0) return OFQ_EINVAL;
   if ((cols & 15) == 0 && al16(codes) && al16(vec))
-    hipLaunchKernelGGL(rowdot_i8_v16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, codes, vec,
+    hipLaunchKernelGGL(rowdot_i8_v16_kernel, dim3((unsigned)ceil_div(rows, 16 * RD16_RPG)), dim3(256), 0, (hipStream_t)stream, codes, vec,
                        out, (int)rows, (int)cols);
   else
     hipLaunchKernelGGL(rowdot_i8_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, codes, vec, out,
@@ -2915,8 +2950,16 @@ __global__ __launch_bounds__(256) void rowdot_i8_multi_kernel(const int8_t* __re
 }
 
 // same, 16 lanes per row and 16 codes per load; the row's codes stay in registers for all V vectors (K <= 512)
+#define RDM_LDS_FLOATS 6144              // the V vectors staged in LDS when they fit (24 KB: 12 heads x 512)
 __device__ __forceinline__ void rowdot_i8_multi_v16_body(int bx, const int8_t* __restrict__ codes, const float* __restrict__ vecs,
-                                                         float* __restrict__ out, int R, int K, int V) {
+                                                         float* __restrict__ out, int R, int K, int V, float* vlds) {
+  // every 16-lane row group reads all V vectors: from LDS (one cooperative copy per workgroup) instead of 8 * V float4
+  // loads per lane through the texture path (which bounded this kernel: 21 us for 10 MB of codes)
+  if (V * K <= RDM_LDS_FLOATS) {
+    for (int i = threadIdx.x * 4; i < V * K; i += 1024) *reinterpret_cast<float4*>(vlds + i) = *reinterpret_cast<const float4*>(vecs + i);
+    __syncthreads();
+    vecs = vlds;
+  }
   const int l16 = threadIdx.x & 15;
   const int r = bx * 16 + (threadIdx.x >> 4);
   const bool rok = r < R;
@@ -2949,7 +2992,8 @@ __device__ __forceinline__ void rowdot_i8_multi_v16_body(int bx, const int8_t* _
 }
 __global__ __launch_bounds__(256) void rowdot_i8_multi_v16_kernel(const int8_t* __restrict__ codes, const float* __restrict__ vecs,
                                                                   float* __restrict__ out, int R, int K, int V) {
-  rowdot_i8_multi_v16_body(blockIdx.x, codes, vecs, out, R, K, V);
+  __shared__ __attribute__((aligned(16))) float vlds[RDM_LDS_FLOATS];
+  rowdot_i8_multi_v16_body(blockIdx.x, codes, vecs, out, R, K, V, vlds);
 }
 
 // out[r][h] = sum_{c<d} x[r][h*d + c] * vec[h*d + c]      (per-head dot of an fp32 row with an offset vector)
@@ -3024,8 +3068,9 @@ struct AttnPrepArgs {
 };
 __global__ __launch_bounds__(256) void qattn_prep_kernel(AttnPrepArgs a) {
   __shared__ __attribute__((aligned(16))) int8_t tile[32][36];
+  __shared__ __attribute__((aligned(16))) float vlds[RDM_LDS_FLOATS];
   int b = blockIdx.x;
-  if (b < a.nb0) { rowdot_i8_multi_v16_body(b, a.xcodes, a.baq, a.u, a.R0, a.C, a.H); return; }
+  if (b < a.nb0) { rowdot_i8_multi_v16_body(b, a.xcodes, a.baq, a.u, a.R0, a.C, a.H, vlds); return; }
   b -= a.nb0;
   if (b < a.nb1) { rowdot_i8_v16_body(b, a.qcodes, a.bax, a.tq, a.R1, a.C); return; }
   b -= a.nb1;
@@ -3042,7 +3087,7 @@ extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, 
   AttnPrepArgs a = {};
   a.xcodes = xcodes; a.baq = baq; a.u = u; a.qcodes = qcodes; a.bax = bax; a.tq = tq; a.vcodes = vcodes; a.vT = vT;
   a.R0 = (int)(B * N); a.R1 = (int)(B * N * H); a.C = (int)C; a.H = (int)H; a.N = (int)N; a.Np = (int)Np;
-  a.nb0 = (int)ceil_div(B * N, 16); a.nb1 = (int)ceil_div(B * N * H, 16);
+  a.nb0 = (int)ceil_div(B * N, 16); a.nb1 = (int)ceil_div(B * N * H, 16 * RD16_RPG);
   a.tx2 = (int)ceil_div(C, 32); a.ty2 = (int)ceil_div(Np, 32);
   const int64_t total = (int64_t)a.nb0 + a.nb1 + (int64_t)a.tx2 * a.ty2 * B;
   if (total >= (1ll << 31)) return OFQ_EINVAL;
