@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
   const int64_t rstride = (int64_t)gridDim.x * TY;
   int64_t r = (int64_t)blockIdx.x * TY + ty;
+  const float q_tol = Q ? ofq_lsq_level_tol(a.qlo, a.qhi) : 0.f;
+  const float q_hmt = 0.5f - q_tol;
   float4 xn[J], sn[J];          // x (and res / dy) of the next row
   float4 dn[J];
   auto issue = [&](int64_t rr) {
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       }
       const float var = ln_row_sum<TXW>(s2) * invC;
       rs = 1.0f / sqrtf(var + a.eps);
+      float q_al = 1.f, q_ra = 1.f;
+      if (Q) {
+        q_al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+        q_ra = ofq_div(1.0f, q_al);                       // correctly rounded reciprocal of the row's step
+      }
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         if (!cok[j]) continue;
@@ -134,12 +141,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         if (!Q || a.y) *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
         if (a.res) *reinterpret_cast<float4*>(a.xs + r * a.ldx + col) = xv[j];
         if (Q) {
-          const float al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
-          float q0, q1, q2, q3, v;
-          ofq_lsq_quant(__fadd_rn(o.x, qb4v[j].x), al, a.qlo, a.qhi, q0, v);
-          ofq_lsq_quant(__fadd_rn(o.y, qb4v[j].y), al, a.qlo, a.qhi, q1, v);
-          ofq_lsq_quant(__fadd_rn(o.z, qb4v[j].z), al, a.qlo, a.qhi, q2, v);
-          ofq_lsq_quant(__fadd_rn(o.w, qb4v[j].w), al, a.qlo, a.qhi, q3, v);
+          // only the level leaves this kernel: x * fl(1/al) decides it unless the product sits within a few ulp of a
+          // rounding boundary (common.h: ofq_lsq_level_rcp) -- then the four elements are redone with the IEEE division,
+          // so the codes stay bit-identical at ~5 instead of ~16 VALU per element
+          const float xe[4] = {__fadd_rn(o.x, qb4v[j].x), __fadd_rn(o.y, qb4v[j].y), __fadd_rn(o.z, qb4v[j].z),
+                               __fadd_rn(o.w, qb4v[j].w)};
+          bool risky = false;
+          float q0 = ofq_lsq_level_rcp(xe[0], q_ra, a.qlo, a.qhi, q_hmt, risky);
+          float q1 = ofq_lsq_level_rcp(xe[1], q_ra, a.qlo, a.qhi, q_hmt, risky);
+          float q2 = ofq_lsq_level_rcp(xe[2], q_ra, a.qlo, a.qhi, q_hmt, risky);
+          float q3 = ofq_lsq_level_rcp(xe[3], q_ra, a.qlo, a.qhi, q_hmt, risky);
+          if (risky) {
+            q0 = ofq_lsq_level_exact(xe[0], q_al, a.qlo, a.qhi);
+            q1 = ofq_lsq_level_exact(xe[1], q_al, a.qlo, a.qhi);
+            q2 = ofq_lsq_level_exact(xe[2], q_al, a.qlo, a.qhi);
+            q3 = ofq_lsq_level_exact(xe[3], q_al, a.qlo, a.qhi);
+          }
           *reinterpret_cast<char4*>(a.qcodes + r * a.C + col) =
               make_char4((signed char)(int)q0, (signed char)(int)q1, (signed char)(int)q2, (signed char)(int)q3);
         }
@@ -150,6 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       float sa = 0.f, sb = 0.f;
       if (Q) {       // sv holds the gradient of the quantised tensor: turn it into the gradient of n = LN(xs)
         const float al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+        const float ral = ofq_div(1.0f, al);
         float rds = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -157,16 +175,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           const float xx[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, gg[4] = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
           const float gm[4] = {gam[j].x, gam[j].y, gam[j].z, gam[j].w}, bt[4] = {bet[j].x, bet[j].y, bet[j].z, bet[j].w};
           const float b4[4] = {qb4v[j].x, qb4v[j].y, qb4v[j].z, qb4v[j].w};
-          float dq[4];
+          float dq[4], dsc[4], xq[4];
+          bool risky = false;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float n = (xx[e] - mu) * rs * gm[e] + bt[e];            // same expression as the forward
-            float q, v;
-            ofq_lsq_quant(__fadd_rn(n, b4[e]), al, a.qlo, a.qhi, q, v);
-            const bool inr = (v >= a.qlo) && (v <= a.qhi);
-            dq[e] = inr ? ofq_div(__fmul_rn(gg[e], al), al) : 0.f;
-            rds += gg[e] * (inr ? (q - v) : q);
+            xq[e] = __fadd_rn(n, b4[e]);
+            ofq_lsq_bwd_fast(xq[e], gg[e], al, ral, a.qlo, a.qhi, q_hmt, q_tol, risky, dq[e], dsc[e]);
           }
+          if (risky) {       // an element within a few ulp of a rounding / range boundary: the IEEE divisions decide
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ofq_lsq_bwd_exact(xq[e], gg[e], al, a.qlo, a.qhi, dq[e], dsc[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rds += dsc[e];
           acc_a[j].x += gg[0]; acc_a[j].y += gg[1]; acc_a[j].z += gg[2]; acc_a[j].w += gg[3];
           sv[j] = make_float4(dq[0], dq[1], dq[2], dq[3]);
         }
