@@ -232,7 +232,8 @@ def test_cga_hooks_in_train_step_follow_the_reference_sequence():
         with torch.no_grad():
             for n in cga_names:                                                # cga.py:994-997
                 leaves[n].copy_(O.cga_restore(leaves[n].detach(), saved[n], idx[n]))
-        assert abs(float(loss.detach()) - float(lo)) < 1e-4 * abs(float(lo)), (step, float(loss.detach()), float(lo))
+        lo = float(lo.detach())
+        assert abs(float(loss.detach()) - lo) < 1e-4 * abs(lo), (step, float(loss.detach()), lo)
         for n, p in model.named_parameters():
             ref = leaves[n].detach()
             got = p.detach().cpu()
