@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import ops
+from . import parallel as _parallel
 
 
 def pad4(n):
@@ -125,7 +126,8 @@ class CodesLinearFn(torch.autograd.Function):
             # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
             # dY also yields the bias gradient (column sums)
             dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
-                                        aux["act_gscale"], None, aux["baft"], compute_db=True)
+                                        aux["act_gscale"], None, aux["baft"], compute_db=True,
+                                        out=_parallel.grad_slot(aux.get("w_leaf")))
         else:
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
@@ -150,7 +152,9 @@ def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=N
     aux = {"xcodes": xcodes, "wcodes": wquant._codes, "w_scale": wquant._s_dev, "r": wquant._r,
            "wcodesT": wquant.codes_T() if torch.is_grad_enabled() else None,   # bf16 [in][out] for dX
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
-           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc}
+           "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc,
+           # StatsQ's backward is the identity (statsq.py:148), so dW of a leaf weight IS its .grad: see parallel.grad_slot
+           "w_leaf": weight if (weight.is_leaf and weight.requires_grad) else None}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 

@@ -417,8 +417,9 @@ def qgemm_bf16s_nt_lsq(dy2d, B_bf16, k_scale, alpha, x2d, s, b4, g, want_bias_gr
     return dx, ds, db4, dbaft
 
 
-def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False):
-    """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c];  compute_db: also returns db = colsum(dy)"""
+def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False, out=None):
+    """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c];  compute_db: also returns db = colsum(dy).
+    out: write dW there (a contiguous (o, c) fp32 tensor, e.g. the weight's slice of a gradient bucket)."""
     Ktok, M = dy2d.shape
     N = xcodes2d.shape[1]
     if split is None:
@@ -428,7 +429,10 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
         else:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
             split = max(1, min(512 // tiles, (Ktok + 31) // 32 // 4))
-    dW = torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
+    if out is not None and (tuple(out.shape) != (M, N) or not out.is_contiguous() or out.dtype != torch.float32
+                            or out.device != dy2d.device):
+        raise ValueError("qgemm_bf16s_tn: out must be a contiguous fp32 (%d, %d) tensor on the operands' device" % (M, N))
+    dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
     if compute_db:
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
