@@ -158,6 +158,28 @@ def test_data_parallel_over_rccl_one_rank_equals_plain_step_and_graph():
         assert gs.captures == 1
         assert le == lg
         _same(se, sg)
+        # the large weight gradients are written into their bucket slices by the dW kernels (parallel.grad_slot): the pack
+        # copy of a step moves only what is left (heads, stem, embeddings, q / k of the tiny model), and never a quantised linear layer's weight
+        import copy
+        from ofq_amd.quantization.utils import KDLossSoftandHard
+        model = copy.deepcopy(base).train()
+        dp = mk(model)
+        opt = engine.make_optimizer(model)
+        names = {id(p): n for n, p in model.named_parameters()}
+        packed = []
+        real_launch = dp._launch
+
+        def launch(b):
+            packed.extend(names[id(p)] for v, p in zip(b.views, b.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr())
+            return real_launch(b)
+        dp._launch = launch
+        for _ in range(2):
+            engine.train_step(model, opt, b0[0], b0[1], b0[2], KDLossSoftandHard(), dp=dp)
+        total = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        copied = sum(dict(model.named_parameters())[n].numel() for n in set(packed))
+        assert copied < 0.6 * total, (copied, total)
+        assert not [n for n in packed if n.endswith(("fc1.weight", "fc2.weight", "proj.weight", "attn.v.weight"))
+                    and "blocks" in n], packed
     finally:
         dist.destroy_process_group()
 
