@@ -260,3 +260,31 @@ def test_bench_self_launch_ends_every_rank_when_one_fails():
     assert b'"metric"' not in r.stdout
     assert time.time() - t0 < 240
 
+
+def test_grad_slot_hands_out_bucket_slices_only_when_safe():
+    """parallel.grad_slot: the bucket slice a dW kernel may write into.  None without a synchronised DataParallel, None
+    when the parameter already holds a gradient (a second backward must accumulate), None for a parameter that merely
+    reuses the id of a dead one; otherwise a NEW tensor object on the slice's memory (autograd adopts it without a copy)."""
+    import torch
+    from ofq_amd import parallel
+    lin = torch.nn.Linear(4, 3)
+    assert parallel.grad_slot(lin.weight) is None and parallel.grad_slot(None) is None
+    dp = parallel.DataParallel(lin, broadcast=False)
+    assert parallel.grad_slot(lin.weight) is None                       # world size 1, no force_sync: no slots registered
+    dp.sync = True
+    dp._build_buckets(1.0)
+    b = dp._bucket_of[lin.weight]
+    view = [v for v, p in zip(b.views, b.params) if p is lin.weight][0]
+    a = parallel.grad_slot(lin.weight)
+    assert a is not None and a is not view and a.data_ptr() == view.data_ptr() and a.shape == lin.weight.shape
+    lin.weight.grad = torch.zeros_like(lin.weight)
+    assert parallel.grad_slot(lin.weight) is None
+    lin.weight.grad = None
+    stale = parallel._GRAD_SLOTS[id(lin.weight)]
+    other = torch.nn.Parameter(torch.zeros(3, 4))
+    parallel._GRAD_SLOTS[id(other)] = stale                             # an id that now belongs to another parameter
+    assert parallel.grad_slot(other) is None
+    del parallel._GRAD_SLOTS[id(other)]
+    for h in dp._hooks:
+        h.remove()
+
