@@ -24,10 +24,14 @@ struct QSsArgs {
 // the k-loop of one workgroup then runs under the softmax arithmetic of the other two.  Phase 2 reads whole float4 chunks
 // up to column 255: with the short stride they run into the following rows (masked by column) and, for the last row,
 // into 256 B of slack behind the tile.
-template <int QSS_SLD>
+// CB = 4: 256-key panel, four waves side by side (DeiT); CB = 1: 64-key panel, 2 x 2 waves of one 32 x 32 block each -- the
+// 49-token Swin windows, where a 256-key panel would be three quarters padding (one window and head per workgroup).
+template <int QSS_SLD, int CB = 4>
 __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   const QGemmArgs& p = q.g;
-  constexpr int BM = 64, BN = 256;
+  constexpr int BM = 64, BN = 64 * CB;
+  constexpr int WGM = CB == 4 ? 1 : 2, MI = CB == 4 ? 2 : 1, NJ = CB == 4 ? 2 : 1;      // wave grid WGM x (4 / WGM), blocks per wave
+  constexpr int KCH = CB;                                 // 64-column chunks of a score row in phase 2
   constexpr int STAGE = (BM + BN) * QI8_LD;
   constexpr int TILE_BYTES = BM * QSS_SLD * 4 + 256;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(2 * STAGE > TILE_BYTES ? 2 * STAGE : TILE_BYTES) + 2 * BM * 4];
@@ -43,21 +47,22 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
   const unsigned char* B = (const unsigned char*)p.B + b0 * p.sB0 + b1 * p.sB1;
   // epilogue parameters are requested before the k-loop (see qgemm_i8_nt_kernel)
-  float pre_ra, pre_rb, pre_s2[2], pre_tq[2];
+  float pre_ra, pre_rb, pre_s2[NJ], pre_tq[NJ];
+  const int wm = wid / (4 / WGM), wn = wid % (4 / WGM);
   {
     const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
     pre_ra = p.s[m % p.S];
     pre_rb = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nc = min(wid * 64 + j * 32 + l31, p.N - 1);
+    for (int j = 0; j < NJ; ++j) {
+      const int nc = min(wn * 32 * NJ + j * 32 + l31, p.N - 1);
       pre_s2[j] = p.s2[nc * p.s2s0 + b1 * p.s2s1];
       pre_tq[j] = p.tq[((int64_t)b0 * p.N + nc) * p.nb1 + b1];
     }
   }
   const float zz = p.z[b1];
-  i32x16 acc[2][2];
-  i8_mainloop_g<1, 4, 1, 2, 2>(p, A, B, m0, 0, smem, acc);
+  i32x16 acc[MI][NJ];
+  i8_mainloop_g<1, CB, WGM, MI, NJ>(p, A, B, m0, 0, smem, acc);
   if (tid < BM) {
     row_a[tid] = ofq_lsq_eff_scale(pre_ra, p.gscale);
     row_b[tid] = pre_rb;
@@ -65,21 +70,21 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   __syncthreads();             // (also: every wave has left the k-loop, the staging buffers may be overwritten)
   {
     // S[n,m] = ax[n] * (aq[m] * I + u[n]) + aq[m] * tq[m] + z   -- qgemm_i8_nt_kernel<1>'s expression
-    float aq[2], tqa[2];
+    float aq[NJ], tqa[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       aq[j] = ofq_lsq_eff_scale(pre_s2[j], p.gscale2);
       tqa[j] = __fadd_rn(__fmul_rn(aq[j], pre_tq[j]), zz);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int mr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int mr = wm * 32 * MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const float ax = row_a[mr], uu = row_b[mr];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = wid * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+          const int col = wn * 32 * NJ + j * 32 + l31;
           if (QSS_SLD >= BN || col < QSS_SLD)        // (short stride: columns past it belong to the next row)
             stile[mr * QSS_SLD + col] = __fadd_rn(__fmul_rn(ax, __fadd_rn(__fmul_rn(aq[j], (float)acc[i][j][e]), uu)), tqa[j]);
         }
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
     const int mr = wid * 16 + it * 4 + rg;
     const bool rok = (m0 + mr) < p.M;
     const int64_t R = (int64_t)gby * p.M + min(m0 + mr, p.M - 1);      // row of the (B, H, N) x ld matrices
-    float t[4][4];
+    float t[KCH][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KCH; ++k) {
       const int c0 = 4 * lr + 64 * k;
       const float4 vin = *reinterpret_cast<const float4*>(stile + mr * QSS_SLD + c0);
       float4 ain = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -115,12 +120,12 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(fmaxf(t[k][0], t[k][1]), fmaxf(t[k][2], t[k][3])));
+    for (int k = 0; k < KCH; ++k) m = fmaxf(m, fmaxf(fmaxf(t[k][0], t[k][1]), fmaxf(t[k][2], t[k][3])));
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < KCH; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         t[k][e] = (4 * lr + 64 * k + e < n) ? expf(t[k][e] - m) : 0.f;
@@ -134,10 +139,10 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
     const float rsum = __fdiv_rn(1.f, sum), ra = __fdiv_rn(1.f, a);
     const float half_m_tol = 0.5f - ofq_lsq_level_tol(0.f, q.hi);
     float qsum = 0.f;
-    float pr[4][4], qq[4][4];
+    float pr[KCH][4], qq[KCH][4];
     bool risky = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < KCH; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pr[k][e] = ofq_div_by_rcp(t[k][e], sum, rsum);
@@ -145,12 +150,12 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
       }
     if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < KCH; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) qq[k][e] = ofq_lsq_level_exact(pr[k][e], a, 0.f, q.hi);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KCH; ++k) {
       const int c0 = 4 * lr + 64 * k;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -191,7 +196,9 @@ extern "C" int ofq_qattn_scores_softmax_i8(const int8_t* acodes, const int8_t* b
   a.tiles_m = (int)ceil_div(N, 64); a.tiles_n = 1;
   q.sm_s = sm_s; q.addend = addend; q.prob = prob; q.codes = codes; q.rowsum = rowsum; q.ld = ld;
   q.add_period = addend ? add_period : 1; q.S = (int)N; q.sm_gscale = sm_gscale; q.alpha = alpha; q.hi = (float)hi;
-  if (N <= 200)
+  if (N <= 64 && ld <= 64)          // Swin windows: one (window, head) per workgroup, 64-key panel (S tile rows of 68 floats)
+    hipLaunchKernelGGL((qattn_scores_softmax_kernel<68, 1>), dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);
+  else if (N <= 200)
     hipLaunchKernelGGL(qattn_scores_softmax_kernel<200>, dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);
   else
     hipLaunchKernelGGL(qattn_scores_softmax_kernel<260>, dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);

@@ -659,9 +659,12 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
 
 
 def scores_softmax_fusable(N):
-    """The fused kernel holds a 64 x 256 score panel: every key of a row must fit (N <= 256); for the 49-token Swin windows
-    three quarters of that panel would be padding, so they keep the separate 64 x 64 kernels."""
-    return FUSE_SCORES_SOFTMAX and 64 < N <= 256 and pad16(N) <= 256
+    """The fused kernel holds a 64-query x 256-key score panel (every key of a row must fit: N <= 256), or a 64 x 64 one
+    for the 49-token Swin windows (one window and head per workgroup)."""
+    return FUSE_SCORES_SOFTMAX and N <= 256 and pad16(N) <= 256 and (N > 64 or not NO_WINDOW_SCORES_SOFTMAX)
+
+
+NO_WINDOW_SCORES_SOFTMAX = os.environ.get("OFQ_NO_WINDOW_SCORES_SOFTMAX") is not None      # A/B switch
 
 
 class PVCodesFn(torch.autograd.Function):

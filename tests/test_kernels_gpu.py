@@ -790,9 +790,12 @@ def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [("qkr", 3, 6, 198, 384, 2), ("qkr_small", 2, 3, 70, 96, 4), ("plain", 3, 3, 198, 64, 4),
-                                 ("plain_256", 1, 2, 256, 32, 3)])
+                                 ("plain_256", 1, 2, 256, 32, 3),
+                                 ("qkr_window", 64, 3, 49, 96, 3), ("plain_window", 32, 6, 49, 32, 3), ("qkr_win_tiny", 4, 2, 7, 32, 2),
+                                 ("plain_win64", 6, 2, 64, 16, 4)])
 def test_fused_scores_softmax_equals_the_two_kernels(ops, cfg):
-    """ofq_qattn_scores_softmax_i8 (score panel kept in LDS) against ofq_qattn_scores(_plain)_i8 followed by
+    """ofq_qattn_scores_softmax_i8 (score panel kept in LDS; the *window* cases take its 64-key form) against
+    ofq_qattn_scores(_plain)_i8 followed by
     ofq_softmax_lsq_fwd (attention.py:96-99 / :207-216): same expressions element for element -- the probabilities agree to
     the last bits (only the order of the row sum differs), the uint8 codes are identical except where a probability sits on a
     rounding tie, the code row sums follow the codes."""
@@ -821,6 +824,9 @@ def test_fused_scores_softmax_equals_the_two_kernels(ops, cfg):
     sm_s = torch.rand(N, device="cuda", generator=g) * 0.02 + 0.01
     alpha, hi = CK ** -0.5 if plain else (C // H) ** -0.5, 2 ** bits - 1
     addend = torch.randn(2, N, Np, device="cuda", generator=g) if name == "qkr_small" else None      # B*H % 2 == 0
+    if "window" in name:          # Swin: relative-position bias + shift mask, one slab per (window of the image, head)
+        addend = torch.randn(4 * H, N, Np, device="cuda", generator=g)
+        addend[1::2, :, : N // 2] -= 100.0
     if plain:
         S = ops.qattn_scores_plain(ac, bc, sa, 0.01, sb, 0.02, u, tq, z, B, H, N, CK, Np)
     else:
