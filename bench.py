@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 # dense matrix-core peaks, /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters" / "Matrix cores (MFMA)")
 PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
          "qgemm_bf16s": 2500.0,    # Peak BF16 MFMA dense; the fp32-exact product issues 3 bf16 MFMAs per algorithmic FMA
-         "qgemm_i8": 5000.0}       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
+         "qgemm_i8": 5000.0,       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
+         "qattn_scores_softmax": 5000.0}   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
 
 
 def parse():

@@ -373,7 +373,7 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
     dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     colmode = int(q.get("colmode", 0))
     ws = workspace(lib().ofq_qgemm_i8_lsq_bwd_ws_bytes(M, N, colmode), dev)
-    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * M * N * K):
+    with _Timed('qgemm_i8_lsqbwd (int8 recompute + LSQ backward epilogue)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_i8_lsq_bwd(xc.data_ptr(), wc.data_ptr(), _p(prod["bias"]), prod["w_scale"].data_ptr(),
                                         prod["w_mult"], _p(prod["r"]), prod["act_s"].data_ptr(), prod["act_S"],
                                         prod["act_gscale"], M, N, K, xc.stride(0), wc.stride(0), gy2d.data_ptr(),
@@ -513,7 +513,7 @@ def qattn_scores_softmax(acodes, bcodes, sa, ga, sb, gb, u, tq, z, plain, sm_s, 
     codes = torch.empty((B, H, N, ld), dtype=torch.uint8, device=dev)
     rsum = torch.empty(B * H * N, dtype=torch.float32, device=dev)
     gscale = 1.0 / math.sqrt(hi * (B * H * N))
-    with _Timed('qgemm_i8_nt (v_mfma_i32_32x32x32_i8)', 2.0 * B * H * N * N * CK):
+    with _Timed('qattn_scores_softmax (int8 scores + softmax + LSQ)', 2.0 * B * H * N * N * CK):
         _chk(lib().ofq_qattn_scores_softmax_i8(acodes.data_ptr(), bcodes.data_ptr(), sa.data_ptr(), ga, sb.data_ptr(), gb,
                                                u.data_ptr(), tq.data_ptr(), z.data_ptr(), int(plain), sm_s.data_ptr(), gscale,
                                                alpha, int(hi), _p(addend), addend.shape[0] if addend is not None else 1,

@@ -16,7 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CLASSES = [("qgemm_bf16s_tn", ("qgemm_bf16s_tn_wide_kernel", "qgemm_bf16s_tn_kernel")),
            ("qgemm_bf16s_nt", ("qgemm_bf16s_nt_wide_kernel", "qgemm_bf16s_nt_kernel")),
            ("qgemm_bf16s_nn", ("qgemm_bf16s_nn_wide_kernel", "qgemm_bf16s_nn_kernel")),
-           ("qgemm_i8_nt", ("qgemm_i8_nt_kernel", "qgemm_i8_lsqbwd_kernel")),
+           ("qgemm_i8_nt", ("qgemm_i8_nt_kernel",)),
+           ("qgemm_i8_lsqbwd", ("qgemm_i8_lsqbwd_kernel",)),
+           ("qattn_scores_softmax", ("qattn_scores_softmax_kernel",)),
            ("gemm_f32", ("gemm_f32_fast_kernel", "gemm_f32_kernel"))]
 
 
