@@ -421,3 +421,33 @@ def test_bf16_plane_gemm_is_fp32_grade():
     e9 = float(((ops.gemm_bf16x3x3_nt(x, planes, b, products=9).double() - ref).abs() / den).max())
     e6 = float(((ops.gemm_bf16x3x3_nt(x, planes, b, products=6).double() - ref).abs() / den).max())
     assert e9 <= 1.5 * e_f32 + 1e-8 and e6 <= 3.0 * e_f32 + 1e-7, (e_f32, e9, e6)
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints exactly one JSON line with the driver's fields, the roofline block of the dominant kernel
+    class (a bf16-split backward GEMM; at 128 images the dW GEMM) and the CPU baseline block (small step counts here: the numbers are not checked)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch-per-gpu", "16",
+                        "--cpu-batch", "1", "--cpu-steps", "1", "--no-c1-baseline"], cwd=root, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "images/s" and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["value"] - 16 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+    roof = d["roofline"]
+    # (which class dominates depends on the batch: at 128 images the dW GEMM, at 16 any of the GEMM classes)
+    assert roof["kernel"].split(" ")[0] in ("qgemm_bf16s_tn", "qgemm_bf16s_nt", "qgemm_bf16s_nn", "qgemm_i8_nt", "gemm_f32",
+                                             "qgemm_i8_lsqbwd", "qattn_scores_softmax")
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
