@@ -184,6 +184,20 @@ size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split);
 int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S, float gscale,
                        float* db, int compute_db, const float* baft, int64_t Ktok, int64_t M, int64_t N, int64_t lda,
                        int64_t ldb, int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
+/*  several weight gradients in one GEMM launch + one reduce launch (each job = one ofq_qgemm_bf16s_tn call, same
+ *            results bit for bit).  The weight gradients of F.linear (qlinear.py:69) have no consumer before the
+ *            optimiser step / gradient all-reduce (train.py:927-933), so a caller may collect the ones of a whole
+ *            transformer block (Block.forward deit_vision_transformer.py:154-164: v, W_qk, proj, fc1, fc2) and run them
+ *            here: each workgroup then owns a long token range, and the split-K partials shrink fivefold.
+ *            Every job: N >= 256, N % 16 == 0, S >= 32; all jobs of one tile class (N % 384 == 0 for all or none);
+ *            njobs <= 8; `split` (>= 1) is common, about 256 / (sum of ceil(M/128) * ceil(N/384) over the jobs). */
+typedef struct ofq_tn_job {
+  const float* dY; const int8_t* codes; float* dW; const float* lsq_s; float* db; const float* baft;
+  int64_t S, Ktok, M, N, lda, ldb;
+  float gscale; int32_t compute_db;
+} ofq_tn_job;
+size_t ofq_qgemm_bf16s_tn_group_ws_bytes(const ofq_tn_job* jobs, int njobs, int split);
+int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
 /*  int8 codes [rows][cols] -> bf16 [cols][rows];   out[r] = sum_k vec[k]*codes[r][k] */
 int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
 int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);

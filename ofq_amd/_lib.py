@@ -23,6 +23,12 @@ class GemmDesc(C.Structure):
                 ("split_k", C.c_int32), ("alpha", f32), ("accumulate", C.c_int32), ("tile_hint", C.c_int32)]
 
 
+class TnJob(C.Structure):
+    _fields_ = [("dY", vp), ("codes", vp), ("dW", vp), ("lsq_s", vp), ("db", vp), ("baft", vp),
+                ("S", i64), ("Ktok", i64), ("M", i64), ("N", i64), ("lda", i64), ("ldb", i64),
+                ("gscale", f32), ("compute_db", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "ofq_abi_version": (i32, []),
@@ -52,6 +58,8 @@ SIGNATURES = {
                                      i64, i64, vp, sz, vp]),
     "ofq_qgemm_bf16s_tn_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "ofq_qgemm_bf16s_tn_group_ws_bytes": (sz, [C.POINTER(TnJob), i32, i32]),
+    "ofq_qgemm_bf16s_tn_group": (i32, [C.POINTER(TnJob), i32, i32, vp, sz, vp]),
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),

@@ -1446,8 +1446,11 @@ __device__ unsigned long long g_tnw_dbg[8][8];     // [wave][phase] cycles of bl
 #define TNW_T(slot) do {} while (0)
 #endif
 
+// The body of the wide dW kernel: workgroup `lid` of the problem `p` (tile = lid % ntiles, split index = lid / ntiles),
+// batch entry `gby`.  Two entry points share it: one problem per launch (qgemm_bf16s_tn_wide_kernel) and several
+// problems per launch (qgemm_bf16s_tn_wide_group_kernel, the deferred weight gradients of a transformer block).
 template <int NJ>
-__global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
+__device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, const int gby) {
   constexpr int BM = 128, BN = 128 * NJ, NS = 3;
   constexpr int LDA = QTN_LD;                 // 320 B: 4 consecutive k rows land on disjoint 64-B bank slots
   constexpr int LDB = BN * 2 + 64;            // same residue (64) modulo the 256-B bank line
@@ -1456,8 +1459,6 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   constexpr int CPR = BN / 8;                 // 8-byte code chunks per k row
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int ntiles = p.tiles_m * p.tiles_n;
-  int lid, gby;
-  xcd_remap_grid(lid, gby);
   const int tile = lid % ntiles, sidx = lid / ntiles;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -1846,21 +1847,50 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   }
 }
 
+template <int NJ>
+__global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
+  int lid, gby;
+  xcd_remap_grid(lid, gby);
+  tn_wide_body<NJ>(p, lid, gby);
+}
+
+// Several split-K problems in one launch.  The weight-gradient GEMMs of the linear layers have no consumer before the
+// optimiser step (or the gradient bucket's all-reduce), so the host defers them (functional.queue_dw) and launches the
+// ones of a whole transformer block together: 45-48 tiles x split 5 instead of five launches of 3-18 tiles x split
+// 14-85.  A workgroup then owns ~160 k-steps instead of 9-57 (prologue, epilogue and the first memory round trip are paid
+// once), and the partials of a block shrink from ~250 MB to ~47 MB (256 workgroups x 196 KB per LAUNCH, whatever the
+// problem: fewer launches, fewer partials).
+#define QTN_GROUP_MAX 8
+struct QTnGroup {
+  QTnArgs job[QTN_GROUP_MAX];
+  int wg_start[QTN_GROUP_MAX + 1];      // first workgroup of job j in the launch order (after the XCD remap)
+  int njobs;
+};
+template <int NJ>
+__global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_group_kernel(QTnGroup g) {
+  int L, gby;
+  xcd_remap_grid(L, gby);
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < QTN_GROUP_MAX; ++q) j += (q < g.njobs && L >= g.wg_start[q]) ? 1 : 0;
+  tn_wide_body<NJ>(g.job[j], L - g.wg_start[j], 0);
+}
+
 // Split-K reduce, latency-parallel version (N % 4 == 0, N >= 256): the row-per-block kernel below walks the `split`
 // partials of an element four at a time, i.e. split/4 dependent memory round trips in a launch of only M blocks (384 rows =
 // 1.5 blocks per CU) -- 86 % of its wave time is parked.  Here a block owns 64 float4 chunks of the output and its four
 // waves each sum every fourth partial, four loads in flight (split/16 round trips), combined through LDS in a fixed order
 // (deterministic).  db[o] = sum_s csum[s][o] is computed by the block(s) touching row o (written by the one holding
 // the row's first chunk); dW[o][c] += db[o] * baft[c] as before.
-__global__ __launch_bounds__(256) void qgemm_tn_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ C,
-                                                               const float* __restrict__ csum, float* __restrict__ db,
-                                                               const float* __restrict__ baft, int M, int N, int split) {
+__device__ __forceinline__ void tn_reduce4_body(const int bx, const float* __restrict__ ws, float* __restrict__ C,
+                                                const float* __restrict__ csum, float* __restrict__ db,
+                                                const float* __restrict__ baft, int M, int N, int split) {
   __shared__ float4 red[3][64];
   __shared__ float dbs[2];
   const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int N4 = N >> 2;
   const int64_t MN = (int64_t)M * N;
-  const int g0 = blockIdx.x * 64;
+  const int g0 = bx * 64;
   const int total = M * N4;
   const int o_first = g0 / N4, o_last = min(g0 + 63, total - 1) / N4;      // N4 >= 64: at most two rows per block
   if (part < 2) {
@@ -1911,6 +1941,24 @@ __global__ __launch_bounds__(256) void qgemm_tn_reduce4_kernel(const float* __re
     }
     *reinterpret_cast<float4*>(C + (int64_t)o * N + 4 * c4) = t;
   }
+}
+
+__global__ __launch_bounds__(256) void qgemm_tn_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ C,
+                                                               const float* __restrict__ csum, float* __restrict__ db,
+                                                               const float* __restrict__ baft, int M, int N, int split) {
+  tn_reduce4_body(blockIdx.x, ws, C, csum, db, baft, M, N, split);
+}
+
+// the reduces of a grouped launch (qgemm_bf16s_tn_wide_group_kernel) in one launch
+struct QTnRedJob { const float* ws; float* C; const float* csum; float* db; const float* baft; int M, N, split, blk_start; };
+struct QTnRedGroup { QTnRedJob job[QTN_GROUP_MAX]; int njobs; };
+__global__ __launch_bounds__(256) void qgemm_tn_reduce4_group_kernel(QTnRedGroup g) {
+  const int bx = blockIdx.x;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < QTN_GROUP_MAX; ++q) j += (q < g.njobs && bx >= g.job[q].blk_start) ? 1 : 0;
+  const QTnRedJob& r = g.job[j];
+  tn_reduce4_body(bx - r.blk_start, r.ws, r.C, r.csum, r.db, r.baft, r.M, r.N, r.split);
 }
 
 // one block per output row o:  db[o] = sum_s csum[s][o] (when the GEMM produced column sums), then
@@ -1990,6 +2038,62 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   else
     hipLaunchKernelGGL(qgemm_tn_reduce_kernel, dim3((unsigned)M), dim3(256), 0, st, (const float*)ws, dW,
                        compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool tn_wide_ok(int64_t Ktok, int64_t N, int64_t S, int64_t lda, int64_t ldb) {
+  return N > 128 && (N & 7) == 0 && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31);
+}
+
+extern "C" size_t ofq_qgemm_bf16s_tn_group_ws_bytes(const ofq_tn_job* jobs, int njobs, int split) {
+  size_t b = 0;
+  for (int j = 0; jobs && j < njobs; ++j) b += ofq_qgemm_bf16s_tn_ws_bytes(jobs[j].M, jobs[j].N, split);
+  return b;
+}
+
+// Several weight-gradient GEMMs (same semantics as ofq_qgemm_bf16s_tn, one ofq_tn_job each) in one GEMM launch and one
+// reduce launch: see qgemm_bf16s_tn_wide_group_kernel.  Every job must be wide-tile eligible and all of one tile class
+// (N % 384 == 0 for all, or for none); the common `split` is the caller's choice (about 256 / total tiles).
+extern "C" int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int split, void* ws, size_t ws_bytes,
+                                        ofq_stream_t stream) {
+  if (!jobs || njobs < 1 || njobs > QTN_GROUP_MAX || split < 1 || !ws) return OFQ_EINVAL;
+  if (ws_bytes < ofq_qgemm_bf16s_tn_group_ws_bytes(jobs, njobs, split)) return OFQ_ENOWS;
+  QTnGroup g = {};
+  QTnRedGroup r = {};
+  const bool three = jobs[0].N % 384 == 0;
+  float* wsf = (float*)ws;
+  int wg = 0, blk = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const ofq_tn_job& q = jobs[j];
+    if (!q.dY || !q.codes || !q.dW || !q.lsq_s || q.Ktok <= 0 || q.M <= 0 || q.N <= 0 || q.S <= 0) return OFQ_EINVAL;
+    if ((q.M & 3) || (q.N & 15) || (q.lda & 3) || (q.ldb & 15) || !al16(q.dY) || !al16(q.codes) || q.Ktok >= (1ll << 30))
+      return OFQ_EINVAL;
+    if (!tn_wide_ok(q.Ktok, q.N, q.S, q.lda, q.ldb) || (q.N % 384 == 0) != three || q.N < 256) return OFQ_EINVAL;
+    if (q.compute_db && !q.db) return OFQ_EINVAL;
+    QTnArgs& a = g.job[j];
+    a.A = q.dY; a.B = q.codes; a.ws = wsf; a.s = q.lsq_s; a.lda = q.lda; a.ldb = q.ldb;
+    a.M = (int)q.M; a.N = (int)q.N; a.Ktok = (int)q.Ktok; a.S = (int)q.S; a.split = split;
+    a.tiles_m = (int)ceil_div(q.M, 128); a.tiles_n = three ? (int)(q.N / 384) : (int)ceil_div(q.N, 256);
+    a.gscale = q.gscale; a.nb1 = 1;
+    a.csum = q.compute_db ? wsf + (size_t)split * q.M * q.N : nullptr;
+    g.wg_start[j] = wg;
+    wg += a.tiles_m * a.tiles_n * split;
+    QTnRedJob& rj = r.job[j];
+    rj.ws = wsf; rj.C = q.dW; rj.csum = a.csum; rj.db = q.db; rj.baft = q.baft;
+    rj.M = a.M; rj.N = a.N; rj.split = split; rj.blk_start = blk;
+    blk += (int)ceil_div(q.M * (q.N / 4), 64);
+    wsf += (size_t)split * q.M * (q.N + 1);
+  }
+  g.wg_start[njobs] = wg;
+  g.njobs = r.njobs = njobs;
+  hipStream_t st = (hipStream_t)stream;
+  if (three)
+    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_group_kernel<3>, dim3((unsigned)wg), dim3(512), 0, st, g);
+  else
+    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_group_kernel<2>, dim3((unsigned)wg), dim3(512), 0, st, g);
+  OFQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qgemm_tn_reduce4_group_kernel, dim3((unsigned)blk), dim3(256), 0, st, r);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -228,7 +228,15 @@ def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
             F_ofq.STEP_CACHE_ACTIVE = False
             invalidate_weight_codes(model)      # the operands are captured by the autograd graph; the cache itself ends here
     loss = loss_fn(out, target, soft_target)
-    loss.backward()
+    F_ofq.DW_DEFER = True                       # weight-gradient GEMMs are queued and launched a block at a time
+    try:
+        loss.backward()
+    except BaseException:
+        F_ofq.drop_dw()
+        raise
+    finally:
+        F_ofq.DW_DEFER = False
+    F_ofq.flush_dw()
     if dp is not None:
         dp.finish_gradient_sync()
     if cga is not None:

@@ -62,6 +62,55 @@ def _shared_grad(acc, shape, device):
     return buf, True, None
 
 
+# ---- deferred weight gradients -----------------------------------------------------------------------------------------
+# dW of a linear layer has no consumer inside the backward pass (StatsQ's backward is the identity, so it goes straight to
+# the parameter's .grad, or to AllWqkFn at the very end).  Inside engine's training step (DW_DEFER set around
+# loss.backward()) CodesLinearFn.backward therefore only *queues* its dW GEMM -- output tensors allocated, returned to
+# autograd, not yet written -- and the queue is launched as ONE grouped GEMM (ops.qgemm_bf16s_tn_group) once it holds about
+# a transformer block's worth of tiles: long token ranges per workgroup instead of 9-57 k-steps, a fifth of the split-K
+# partials.  Everything that READS a gradient flushes first: the bucket all-reduce (parallel.DataParallel._launch),
+# AllWqkFn.backward, and engine._step_body right after loss.backward().  Outside the training step nothing is deferred.
+DW_DEFER = False
+DW_GROUP = os.environ.get("OFQ_NO_DW_GROUP") is None       # A/B switch
+DW_FLUSH_TILES = int(os.environ.get("OFQ_DW_FLUSH_TILES", "40"))
+_DW_QUEUE = []
+_DW_TILES = [0]
+
+
+def flush_dw():
+    """Launch every queued weight-gradient GEMM (no-op when the queue is empty)."""
+    q = _DW_QUEUE
+    while q:
+        three = q[0]["xcodes2d"].shape[1] % 384 == 0
+        n = 1
+        while n < len(q) and n < ops.TN_GROUP_MAX and (q[n]["xcodes2d"].shape[1] % 384 == 0) == three:
+            n += 1
+        ops.qgemm_bf16s_tn_group(q[:n])
+        del q[:n]
+    _DW_TILES[0] = 0
+
+
+def drop_dw():
+    """Forget the queue (a backward pass that raised)."""
+    del _DW_QUEUE[:]
+    _DW_TILES[0] = 0
+
+
+def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):
+    """Queue dW = dy2d^T @ (a_eff * codes + baft) and db = colsum(dy2d); returns the (not yet written) output tensors."""
+    M, N = dy2d.shape[1], xcodes2d.shape[1]
+    dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
+    db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
+    q = _DW_QUEUE
+    if q and ((q[-1]["xcodes2d"].shape[1] % 384 == 0) != (N % 384 == 0) or len(q) >= ops.TN_GROUP_MAX):
+        flush_dw()
+    q.append({"dy2d": dy2d, "xcodes2d": xcodes2d, "lsq_s": lsq_s, "S": S, "gscale": gscale, "baft": baft, "dW": dW, "db": db})
+    _DW_TILES[0] += ops.tn_tiles(M, N)
+    if _DW_TILES[0] >= DW_FLUSH_TILES:
+        flush_dw()
+    return dW, db
+
+
 class CodesLinearFn(torch.autograd.Function):
     """Same function as LinearFn, computed on the integer codes: forward is one exact int8-MFMA GEMM with the
     scales applied in the epilogue (ofq_qgemm_i8_nt), dX is the 3-way bf16-split GEMM against the transposed
@@ -125,9 +174,14 @@ class CodesLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and N_out % 4 == 0 and K_in % 16 == 0:
             # dY^T @ (a_eff*codes + baft): bf16-split TN GEMM on the codes + rank-1 offset term; the same pass over
             # dY also yields the bias gradient (column sums)
-            dW, db = ops.qgemm_bf16s_tn(dy2d, aux["xcodes"].view(-1, K_in), aux["act_s"], aux["act_S"],
-                                        aux["act_gscale"], None, aux["baft"], compute_db=True,
-                                        out=_parallel.grad_slot(aux.get("w_leaf")))
+            xc2 = aux["xcodes"].view(-1, K_in)
+            slot = _parallel.grad_slot(aux.get("w_leaf"))
+            if DW_DEFER and DW_GROUP and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"], dy2d.stride(0),
+                                                          xc2.stride(0)):
+                dW, db = queue_dw(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], aux["baft"], slot)
+            else:
+                dW, db = ops.qgemm_bf16s_tn(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], None, aux["baft"],
+                                            compute_db=True, out=slot)
         else:
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
@@ -173,6 +227,7 @@ class WqkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        flush_dw()
         Wq, Wk = ctx.saved_tensors
         H = ctx.H
         C = Wq.shape[1]
@@ -212,6 +267,7 @@ class AllWqkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        flush_dw()                         # the W_qk gradients of the last blocks may still be queued
         Wq, Wk = ctx.saved_tensors
         H = ctx.H
         L, _, C = Wq.shape

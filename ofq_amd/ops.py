@@ -443,6 +443,50 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     return (dW, db) if compute_db else dW
 
 
+TN_GROUP_MAX = 8
+
+
+def tn_tiles(M, N):
+    """Workgroup tiles of one wide dW problem (128 x 384, or 128 x 256 when N is not a multiple of 384)."""
+    return ((M + 127) // 128) * (N // 384 if N % 384 == 0 else (N + 255) // 256)
+
+
+def tn_groupable(Ktok, M, N, S, lda, ldb):
+    """May this dW problem join a grouped launch (ofq_qgemm_bf16s_tn_group)?"""
+    return (N >= 256 and N % 16 == 0 and M % 4 == 0 and S >= 32 and lda % 4 == 0 and ldb % 16 == 0
+            and Ktok * lda < (1 << 31) and Ktok * ldb < (1 << 31))
+
+
+def qgemm_bf16s_tn_group(jobs, split=None):
+    """jobs: list of dicts (dy2d, xcodes2d, lsq_s, S, gscale, baft, dW, db) -- dW (M, N) / db (M) are OUTPUT tensors the
+    caller has allocated; every job computes what qgemm_bf16s_tn(compute_db=db is not None) would.  One GEMM launch and
+    one reduce launch for all of them."""
+    n = len(jobs)
+    assert 1 <= n <= TN_GROUP_MAX
+    arr = (_lib.TnJob * n)()
+    tiles = 0
+    flops = 0.0
+    nkt = 1
+    for i, j in enumerate(jobs):
+        dy, xc = j["dy2d"], j["xcodes2d"]
+        Ktok, M = dy.shape
+        N = xc.shape[1]
+        tiles += tn_tiles(M, N)
+        flops += 2.0 * Ktok * M * N
+        nkt = max(nkt, (Ktok + 31) // 32)
+        a = arr[i]
+        a.dY, a.codes, a.dW, a.lsq_s = dy.data_ptr(), xc.data_ptr(), j["dW"].data_ptr(), j["lsq_s"].data_ptr()
+        a.db, a.baft = _p(j["db"]), _p(j["baft"])
+        a.S, a.Ktok, a.M, a.N, a.lda, a.ldb = j["S"], Ktok, M, N, dy.stride(0), xc.stride(0)
+        a.gscale, a.compute_db = j["gscale"], int(j["db"] is not None)
+    if split is None:
+        split = max(1, min(256 // tiles, nkt // 4))
+    dev = jobs[0]["dy2d"].device
+    ws = workspace(lib().ofq_qgemm_bf16s_tn_group_ws_bytes(arr, n, split), dev)
+    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', flops):
+        _chk(lib().ofq_qgemm_bf16s_tn_group(arr, n, split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn_group")
+
+
 # ------------------------------------------------------------------------------------------------ attention on codes
 def lsq_eff_scale(s, gscale):
     """(a - a*g) + a*g with a = max(s, 1e-5): the scale VALUE the LSQ kernels divide by (fp32, lsq.py:6-18)."""

@@ -25,6 +25,7 @@ the global ones).  Design notes for MI355X:
 StatsQ statistics need no collective: s = 2*mean|W| is a pure function of replica-identical weights
 (SURVEY.md §2.3); `check_statsq_consistency` verifies exactly that with one tiny all-reduce.
 """
+import sys
 import weakref
 
 import torch
@@ -176,6 +177,9 @@ class DataParallel(torch.nn.Module):
         """Pack the bucket's gradients into its flat buffer with one multi-tensor copy, start the asynchronous
         all-reduce (its stream waits for the kernels queued so far, then runs next to the rest of backward) and point
         every p.grad at its slice, which will hold the averaged value once the work completes."""
+        fn = sys.modules.get(__package__ + ".functional")
+        if fn is not None:
+            fn.flush_dw()             # deferred weight-gradient GEMMs (functional.queue_dw) write into these gradients
         have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
         if len(have) < len(b.params):
             # torch's DDP with find_unused_parameters=False (the reference, train.py:727) fails here as well

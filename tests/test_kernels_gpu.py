@@ -435,6 +435,39 @@ def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
     assert rel_err(dW.cpu(), dW2.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("cls", [3, 2])
+def test_qgemm_tn_group_equals_single_launches(ops, cls):
+    """ofq_qgemm_bf16s_tn_group (the deferred weight gradients of a block in one launch) == one ofq_qgemm_bf16s_tn call
+    per job with the same split, bit for bit (same partials, same reduction order), dW and db; different token counts,
+    step-vector lengths and leading dimensions per job, with and without the offset term."""
+    shapes = ([(792, 384, 384), (792, 1536, 384), (594, 384, 1536), (1188, 2304, 384), (396, 128, 768)] if cls == 3 else
+              [(792, 576, 192 + 64), (640, 192, 768 + 256), (500, 72, 272)])
+    rs = np.random.RandomState(6)
+    jobs, refs = [], []
+    for i, (Ktok, Mo, Nc) in enumerate(shapes):
+        lda = Mo + (8 if i % 2 else 0)
+        dyb = (T(det_normalish((Ktok, lda), 191 + i, 1.0)) * T(det_uniform((Ktok, 1), 192 + i, 1e-3, 10.0))).cuda()
+        dy = dyb[:, :Mo]
+        codes = torch.from_numpy(rs.randint(-8, 8, (Ktok, Nc)).astype(np.int8)).cuda()
+        S = 198 if Ktok % 198 == 0 else Ktok
+        s = T(det_uniform((S,), 193 + i, 0.1, 1.0)).cuda()
+        baft = T(det_uniform((Nc,), 194 + i, -0.05, 0.05)).cuda() if i != 1 else None
+        for split in (3,):
+            rW, rb = ops.qgemm_bf16s_tn(dy, codes, s, S, 0.01, None, baft, split=split, compute_db=True)
+        refs.append((rW, rb))
+        jobs.append({"dy2d": dy, "xcodes2d": codes, "lsq_s": s, "S": S, "gscale": 0.01, "baft": baft,
+                     "dW": torch.full((Mo, Nc), float("nan"), device="cuda"), "db": torch.full((Mo,), float("nan"), device="cuda")})
+    ops.qgemm_bf16s_tn_group(jobs, split=3)
+    for j, (rW, rb) in zip(jobs, refs):
+        assert torch.equal(j["dW"], rW) and torch.equal(j["db"], rb)
+    # default split (about 256 / tiles): against fp64
+    for j in jobs:
+        j["dW"].fill_(float("nan"))
+    ops.qgemm_bf16s_tn_group(jobs)
+    for j, (rW, rb) in zip(jobs, refs):
+        assert rel_err(j["dW"].cpu(), rW.cpu()) < 1e-5 and rel_err(j["db"].cpu(), rb.cpu()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ attention on codes
 def test_qattn_code_kernels_vs_fp64(ops):
     B, H, N, d = 2, 3, 198, 32

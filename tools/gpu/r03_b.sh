@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r03_b; mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "tn" > $O/tests.txt 2>&1; echo "tests rc=$?"; tail -5 $O/tests.txt
+timeout 300 python tools/tn_group_bench.py > $O/group.txt 2>&1; cat $O/group.txt
+for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>$O/bench.err | cut -c1-200; done
+OFQ_NO_DW_GROUP=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>>$O/bench.err | cut -c1-200

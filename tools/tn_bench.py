@@ -7,17 +7,17 @@ import torch
 from ofq_amd import ops
 from tools.gemm_bench import bench  # noqa
 
-M = 128 * 197
+M = 128 * 198
 which = os.environ.get("WHICH", "tn,nt").split(",")
-for (o, c) in [(1152, 384), (384, 384), (1536, 384), (384, 1536)]:
+for (o, c) in [(2304, 384), (384, 384), (1536, 384), (384, 1536)]:
     dy = torch.randn(M, o, device="cuda") * 1e-3
     codes = torch.randint(-2, 2, (M, c), dtype=torch.int8, device="cuda")
-    s = torch.rand(197, device="cuda") + 0.1
+    s = torch.rand(198, device="cuda") + 0.1
     baft = torch.rand(c, device="cuda")
     if "tn" in which:
         for split in [None] + [int(x) for x in os.environ.get("SPLITS", "").split(",") if x]:
             bench("TN dW o=%d c=%d split=%s" % (o, c, split),
-                  lambda: ops.qgemm_bf16s_tn(dy, codes, s, 197, 0.01, None, baft, split=split, compute_db=True), 2.0 * M * o * c)
+                  lambda: ops.qgemm_bf16s_tn(dy, codes, s, 198, 0.01, None, baft, split=split, compute_db=True), 2.0 * M * o * c)
     if "nt" in which:
         qw = (2 * torch.randint(-2, 2, (o, c), device="cuda") + 1).to(torch.int8)
         wT = ops.codes_transpose_bf16(qw)
