@@ -104,7 +104,10 @@ def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):
     q = _DW_QUEUE
     if q and ((q[-1]["xcodes2d"].shape[1] % 384 == 0) != (N % 384 == 0) or len(q) >= ops.TN_GROUP_MAX):
         flush_dw()
-    q.append({"dy2d": dy2d, "xcodes2d": xcodes2d, "lsq_s": lsq_s, "S": S, "gscale": gscale, "baft": baft, "dW": dW, "db": db})
+    # the outputs are queued as raw addresses: autograd must hold the only reference to dW / db, or AccumulateGrad would
+    # clone them (still unwritten) instead of adopting them as .grad; they stay alive as .grad / in autograd's input buffers
+    q.append({"dy2d": dy2d, "xcodes2d": xcodes2d, "lsq_s": lsq_s, "S": S, "gscale": gscale, "baft": baft,
+              "dW": dW.data_ptr(), "db": db.data_ptr()})
     _DW_TILES[0] += ops.tn_tiles(M, N)
     if _DW_TILES[0] >= DW_FLUSH_TILES:
         flush_dw()
@@ -142,6 +145,7 @@ class CodesLinearFn(torch.autograd.Function):
         ctx.save_for_backward(*(() if ctx.codes_only else (x2d,)))
         ctx.aux = aux
         ctx.has_bias = bias is not None
+        ctx.bias_leaf = bias if (bias is not None and bias.is_leaf) else None
         ctx.in_shape = shp
         return y.view(*shp[:-1], Wq.shape[0])
 
@@ -176,8 +180,13 @@ class CodesLinearFn(torch.autograd.Function):
             # dY also yields the bias gradient (column sums)
             xc2 = aux["xcodes"].view(-1, K_in)
             slot = _parallel.grad_slot(aux.get("w_leaf"))
-            if DW_DEFER and DW_GROUP and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"], dy2d.stride(0),
-                                                          xc2.stride(0)):
+            # a queued result is still unwritten when autograd accumulates it: that is only sound when accumulating means
+            # adopting the tensor (no gradient there yet), never adding to one
+            w_leaf, b_leaf = aux.get("w_leaf"), ctx.bias_leaf
+            adopt = ((w_leaf is None or w_leaf.grad is None) and (b_leaf is None or b_leaf.grad is None)
+                     and (not ctx.has_bias or b_leaf is not None))
+            if DW_DEFER and DW_GROUP and adopt and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"],
+                                                                    dy2d.stride(0), xc2.stride(0)):
                 dW, db = queue_dw(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], aux["baft"], slot)
             else:
                 dW, db = ops.qgemm_bf16s_tn(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], None, aux["baft"],

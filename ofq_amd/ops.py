@@ -475,10 +475,15 @@ def qgemm_bf16s_tn_group(jobs, split=None):
         flops += 2.0 * Ktok * M * N
         nkt = max(nkt, (Ktok + 31) // 32)
         a = arr[i]
-        a.dY, a.codes, a.dW, a.lsq_s = dy.data_ptr(), xc.data_ptr(), j["dW"].data_ptr(), j["lsq_s"].data_ptr()
-        a.db, a.baft = _p(j["db"]), _p(j["baft"])
+        # dW / db may be given as raw device addresses: a caller that has handed the tensors to autograd must not keep a
+        # second reference (AccumulateGrad adopts a gradient only when it holds the last one, and clones it otherwise)
+        pw, pb = j["dW"], j["db"]
+        a.dY, a.codes, a.lsq_s = dy.data_ptr(), xc.data_ptr(), j["lsq_s"].data_ptr()
+        a.dW = pw if isinstance(pw, int) else pw.data_ptr()
+        a.db = pb if isinstance(pb, int) else _p(pb)
+        a.baft = _p(j["baft"])
         a.S, a.Ktok, a.M, a.N, a.lda, a.ldb = j["S"], Ktok, M, N, dy.stride(0), xc.stride(0)
-        a.gscale, a.compute_db = j["gscale"], int(j["db"] is not None)
+        a.gscale, a.compute_db = j["gscale"], int(pb is not None)
     if split is None:
         split = max(1, min(256 // tiles, nkt // 4))
     dev = jobs[0]["dy2d"].device

@@ -74,7 +74,13 @@ class QAttention(deit_attention):
         if m.attn_drop.p != 0:
             raise ValueError("attention dropout is 0 in every OFQ recipe; the quantised attention core does not apply it "
                              "(the reference applies attn_drop after the softmax quantiser, attention.py:100 / :217)")
-        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
+        # Like the reference (attention.py:18-24) the base class is built WITHOUT qkv_bias, and the two QLinear wrappers
+        # below take `self.qkv` / `self.proj` -- the layers this constructor has just created -- not `m.qkv` / `m.proj`
+        # (attention.py:29-30, :42-43): with pretrained_initialized the qkv / proj weights of a QAttention are therefore
+        # the fresh default initialisation (and qkv.bias the QLinear's own), NOT the source module's.  Reproduced, with the
+        # same order of random draws, so that a seeded construction gives the reference's parameters bit for bit
+        # (tests/golden g10); checkpoints loaded afterwards (train.py:515-516) override them either way.
+        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, attn_drop=m.attn_drop.p,
                          proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
         self.weight_bits = weight_bits
         self.input_bits = input_bits
@@ -83,8 +89,8 @@ class QAttention(deit_attention):
             raise ValueError("QAttention: input_bits >= 32 (no activation quantisation) is not on the hot path")
         kw = _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise, weight_quant_method,
                              input_quant_method, aq_learnable, wq_learnable, pretrained_initialized)
-        self.qkv = QLinear(m=m.qkv, **kw)
-        self.proj = QLinear(m=m.proj, **kw)
+        self.qkv = QLinear(m=self.qkv, **kw)
+        self.proj = QLinear(m=self.proj, **kw)
         self.quan_a_q_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
         self.quan_a_k_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
         self.quan_a_v_fn = LsqQuantizer4v(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
@@ -173,7 +179,9 @@ class QAttention_qkreparam(deit_attention):
         if m.attn_drop.p != 0:
             raise ValueError("attention dropout is 0 in every OFQ recipe; the quantised attention core does not apply it "
                              "(the reference applies attn_drop after the softmax quantiser, attention.py:100 / :217)")
-        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, qkv_bias=True, attn_drop=m.attn_drop.p,
+        # base class without qkv_bias and proj wrapped from `self.proj`, as the reference does (attention.py:113-119,
+        # :143-144): q / k / v are copied from the source module, proj keeps this constructor's fresh initialisation
+        super().__init__(dim=m.qkv.in_features, num_heads=m.num_heads, attn_drop=m.attn_drop.p,
                          proj_drop=m.proj_drop.p, qqkkvv=m.qqkkvv)
         self.weight_bits = weight_bits
         self.input_bits = input_bits
@@ -192,7 +200,7 @@ class QAttention_qkreparam(deit_attention):
                 self.v.bias.copy_(b[2 * C:3 * C])
         self.qk_quant = self._make_qk_quant(wq_learnable, boundaryRange)
         self.v_quant = StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
-        self.proj = QLinear(m=m.proj, **_qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise,
+        self.proj = QLinear(m=self.proj, **_qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise,
                                                         weight_quant_method, input_quant_method, aq_learnable,
                                                         wq_learnable, pretrained_initialized))
         self.quan_a_qkx_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)

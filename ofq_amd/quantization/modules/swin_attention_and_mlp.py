@@ -62,7 +62,8 @@ class _SwinQBase(ShiftedWindowAttention):
         self.attention_dropout = 0.0
         self.dropout = 0.0
         # like the reference (:129-141) the Q-module starts from a FRESH trunc-normal bias table: the source module's
-        # table is not copied, even with pretrained_initialized (ShiftedWindowAttention.__init__ above created it)
+        # table is not copied, even with pretrained_initialized (ShiftedWindowAttention.__init__ above created it); the
+        # same holds for proj (and qkv on the plain path): the QLinear wrappers take self.proj / self.qkv (:89-90, :297-298)
 
     def _window_forward(self, x, core):
         g = WindowGeometry(x, self.window_size, self.shift_size)
@@ -82,8 +83,9 @@ class QAttention_swin(_SwinQBase):
         self._base_init(m, weight_bits, input_bits, input_channelwise)
         kw = _qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise, weight_quant_method,
                              input_quant_method, aq_learnable, wq_learnable, pretrained_initialized)
-        self.qkv = QLinear(m=m.qkv, **kw)
-        self.proj = QLinear(m=m.proj, **kw)
+        # `self.qkv` / `self.proj` (created by _base_init), not the source module's: swin_attention_and_mlp.py:89-90, :102-103
+        self.qkv = QLinear(m=self.qkv, **kw)
+        self.proj = QLinear(m=self.proj, **kw)
         self.quan_a_q_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
         self.quan_a_k_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
         self.quan_a_v_fn = LsqQuantizer4v(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)
@@ -120,7 +122,7 @@ class QAttention_swin_qkreparam(_SwinQBase):
                 self.v.bias.copy_(b[2 * C:3 * C])
         self.qk_quant = self._make_qk_quant(wq_learnable, boundaryRange)
         self.v_quant = StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
-        self.proj = QLinear(m=m.proj, **_qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise,
+        self.proj = QLinear(m=self.proj, **_qlinear_kwargs(weight_bits, input_bits, weight_channelwise, input_channelwise,
                                                         weight_quant_method, input_quant_method, aq_learnable,
                                                         wq_learnable, pretrained_initialized))
         self.quan_a_qkx_fn = LsqQuantizer(bit=input_bits, all_positive=False, per_channel=True, learnable=aq_learnable)

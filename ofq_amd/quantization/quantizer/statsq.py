@@ -11,6 +11,15 @@ class _StatsQFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bits, holder, want_codes, rvec=None, need_values=True, want_T=False):
         holder._r = None
+        if holder._scale_override is not None:
+            # test hook (tests/test_depth12_gpu.py): quantise with a GIVEN per-row scale (ofq_statsq_fwd, scale_given = 1)
+            # instead of 2 * mean|W|, e.g. the torch-CPU value of the same weights, which can differ from the kernel's
+            # correctly rounded fp64 row sum by one ulp.  The unfused operand path: codes^T and the offset row-dots are
+            # built on demand by their consumers.
+            out, s, codes = ops.statsq_fwd(weight, bits, want_levels=want_codes, scale=holder._scale_override.to(weight.device),
+                                           odd_codes=want_codes)
+            holder._s_dev, holder._codes, holder._codesT = s, codes, None
+            return out
         if want_codes and (rvec is not None or not need_values):
             # code path of a linear layer: scale, codes, transposed bf16 codes and the offset row-dot in ONE launch;
             # the fp32 fake-quant values are not written (nothing reads them), a zero-stride tensor carries the edge
@@ -50,6 +59,7 @@ class StatsQuantizer(nn.Module):
         self._r = None
         self._last_args = None      # (leaf weight or None, bits, rvec, want_T) of the last code-path forward
         self._pre = None            # (weight, rvec, has_T, (s, codes, codesT, r)) filled by engine.refresh_weight_codes()
+        self._scale_override = None  # test hook: a per-row scale to use instead of 2 * mean|W| (see _StatsQFn.forward)
 
     def codes_T(self):
         """Weight codes transposed to [in][out] as bf16 (exact small integers) for dX = dY @ W_hat."""

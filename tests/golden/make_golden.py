@@ -558,9 +558,115 @@ def g9_swin():
     save("g9_swin_tiny", out)
 
 
+# ------------------------------------------------------------------------------------------------
+# G10 the modules at PRODUCTION dimensions (the shapes that select the production kernel instances); weights from
+#     detgen seeds (not stored), outputs / gradients in compact form -- tests/golden/prodcases.py
+# ------------------------------------------------------------------------------------------------
+def g10_prod():
+    torch.manual_seed(0)
+    import prodcases as PC
+    from src.swin import ShiftedWindowAttention
+    from src.quantization.modules.swin_attention_and_mlp import QAttention_swin_qkreparam, QMLP_swin
+    from torchvision.ops.misc import MLP as swin_MLP
+    ns = {"QLinear": QLinear, "QMLP": QMLP, "Mlp": Mlp, "Attention": Attention, "QAttention": QAttention,
+          "QAttention_qkreparam": QAttention_qkreparam, "ShiftedWindowAttention": ShiftedWindowAttention,
+          "QAttention_swin_qkreparam": QAttention_swin_qkreparam, "QMLP_swin": QMLP_swin, "swin_MLP": swin_MLP}
+    out = {}
+    for name in PC.CASES:
+        q, x, oi = PC.build(name, ns)
+        q.train()
+        with torch.no_grad():
+            q(x)                                              # lazy LSQ init (setup_alpha, train.py:997)
+        PC.randomize_small_params(q, PC.CASES[name]["seed"] + 100)
+        xg = x.clone().requires_grad_(True)
+        y = q(xg)
+        if oi is not None:
+            y = y[oi]
+        g = PC.upstream_grad(name, y.shape)
+        (y * g).sum().backward()
+        # tie-free by construction: the same module in fp64, and in fp32 on one thread (another summation order), must give
+        # the same outputs and gradients; otherwise some value sits on a rounding tie and the case has no single answer
+        def rerun(mod, xin):
+            xr = xin.clone().requires_grad_(True)
+            yr = mod(xr)
+            yr = yr[oi] if oi is not None else yr
+            mod.zero_grad()
+            (yr * g.to(yr.dtype)).sum().backward()
+            r = {"y": yr.detach().double(), "dx": xr.grad.double()}
+            r.update({n: p.grad.double().clone() for n, p in mod.named_parameters() if p.grad is not None and "move_" not in n})
+            return r
+        ref32 = {"y": y.detach().double(), "dx": xg.grad.double()}
+        ref32.update({n: p.grad.double().clone() for n, p in q.named_parameters() if p.grad is not None and "move_" not in n})
+        r64 = rerun(copy.deepcopy(q).double(), x.double())
+        torch.set_num_threads(1)
+        r1 = rerun(copy.deepcopy(q), x)
+        torch.set_num_threads(4)
+        for kk in ref32:
+            e64 = float((ref32[kk] - r64[kk]).norm() / (r64[kk].norm() + 1e-30))
+            e1 = float((ref32[kk] - r1[kk]).norm() / (ref32[kk].norm() + 1e-30))
+            assert e64 < 1e-5 and e1 < 1e-5, "case %s is not tie-free (%s: fp64 %.1e, 1 thread %.1e): pick another seed" % (
+                name, kk, e64, e1)
+        d = {}
+        PC.compact(d, "y", npy(y))
+        PC.compact(d, "dx", npy(xg.grad))
+        for n, p in q.state_dict().items():
+            if PC.is_big_weight(p):
+                d["w2:" + n] = np.array(float(p.double().norm()))      # regenerable from the seeds: only its norm
+            else:
+                d["p:" + n] = npy(p)
+        for n, p in q.named_parameters():
+            if p.grad is not None:
+                PC.compact(d, "grad:" + n, npy(p.grad))
+        for kk, v in d.items():
+            out[name + ":" + kk] = v
+        print("  %-14s y%s  %d entries" % (name, tuple(y.shape), len(d)))
+    save("g10_prod", out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G11 the fp32 KD teacher (train.py:428-442, :906-910): the UNQUANTISED distilled DeiT of the reference, train and
+#     eval mode outputs.  Parameters from detgen seeds by parameter index (not stored).
+# ------------------------------------------------------------------------------------------------
+TEACHER_CASES = {"tiny_d12": dict(dim=192, depth=12, heads=3, B=2, ncls=1000, seed=4000),
+                 "small_d2": dict(dim=384, depth=2, heads=6, B=2, ncls=1000, seed=4100)}
+
+
+def teacher_fill(model, seed):
+    with torch.no_grad():
+        for i, (n, p) in enumerate(model.named_parameters()):
+            if p.dim() >= 2 and "norm" not in n:
+                p.copy_(T(det_normalish(tuple(p.shape), seed + i, 0.05)))
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(T(det_uniform(tuple(p.shape), seed + i, 0.8, 1.2)))
+            else:
+                p.copy_(T(det_uniform(tuple(p.shape), seed + i, -0.1, 0.1)))
+
+
+def g11_teacher():
+    torch.manual_seed(0)
+    out = {}
+    for name, c in TEACHER_CASES.items():
+        model = DistilledVisionTransformer(img_size=224, patch_size=16, embed_dim=c["dim"], depth=c["depth"],
+                                           num_heads=c["heads"], mlp_ratio=4, qkv_bias=True, num_classes=c["ncls"],
+                                           norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU)
+        teacher_fill(model, c["seed"])
+        img = T(det_uniform((c["B"], 3, 224, 224), c["seed"] + 900, -2.0, 2.0))
+        model.train()                                        # the reference never puts its teacher in eval mode
+        with torch.no_grad():
+            (cls_o, dist_o), _ = model(img)
+            model.eval()
+            ev, _ = model(img)
+        out[name + ":cls"] = npy(cls_o)
+        out[name + ":dist"] = npy(dist_o)
+        out[name + ":eval"] = npy(ev)
+        out[name + ":meta"] = np.array([c["dim"], c["depth"], c["heads"], c["B"], c["ncls"], c["seed"]])
+        out[name + ":w2"] = np.array(float(sum(p.double().pow(2).sum() for p in model.parameters()) ** 0.5))
+    save("g11_teacher", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = {"g1": g1_statsq, "g2": g2_lsq, "g3": g3_qlinear, "g4": g4_attention, "g5": g5_qmlp, "g6": g6_stem_head,
-           "g7": g7_tiny_deit, "g8": g8_cga, "g9": g9_swin}
+           "g7": g7_tiny_deit, "g8": g8_cga, "g9": g9_swin, "g10": g10_prod, "g11": g11_teacher}
     for w in which:
         fns[w]()

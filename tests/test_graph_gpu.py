@@ -92,6 +92,47 @@ def test_graph_replay_equals_eager_steps_bit_for_bit():
     assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
 
 
+def test_deferred_weight_gradients_equal_immediate():
+    """engine's step queues the dW GEMMs of the linear layers and launches them grouped (functional.queue_dw): every
+    gradient must be the one the immediate launches give (same products; the split-K factor differs, so 1e-6 instead
+    of bit equality), none may be a copy taken before the deferred kernel ran, and three steps must track each other."""
+    from ofq_amd import engine
+    import ofq_amd.functional as Fn
+    base = _tiny(depth=3)
+    b0 = _batch(seed=5)
+    engine.setup_alpha(base, b0[0])
+    res = {}
+    for grouped in (False, True):
+        Fn.DW_GROUP = grouped
+        try:
+            model = copy.deepcopy(base).train()
+            opt = engine.make_optimizer(model, lr=1e-4, weight_decay=0.05)
+            # one step with the optimiser update switched off: gradients of identical weights
+            for g in opt.param_groups:
+                g["lr"] = 0.0
+                g["weight_decay"] = 0.0
+            engine.train_step(model, opt, *b0)
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            for g in opt.param_groups:
+                g["lr"] = 1e-4
+            losses = [float(engine.train_step(model, opt, *b0).detach()) for _ in range(3)]
+            res[grouped] = (grads, losses)
+        finally:
+            Fn.DW_GROUP = True
+    ga, gb = res[False][0], res[True][0]
+    assert ga.keys() == gb.keys()
+    queued = 0
+    for n in ga:
+        a, b = ga[n].double(), gb[n].double()
+        assert torch.isfinite(b).all(), n
+        err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
+        assert err < 2e-6, (n, err)
+        queued += int(n.endswith("fc2.weight"))
+    assert queued == 3
+    for x, y in zip(res[False][1], res[True][1]):
+        assert abs(x - y) < 1e-4 * abs(x), (res[False][1], res[True][1])
+
+
 def test_graph_replay_with_cga_hooks_equals_eager():
     """Config C5: QAttention_qkreparam_4_cga model, freeze masks recomputed from the weights inside every replay, mask and
     restore folded into the AdamW launch (cga.py:953-1013).  boundaryRange 0.05 so that a good share of weights freezes."""

@@ -39,15 +39,20 @@ def test_statsq_golden_bit_exact_given_scale(ops):
 
 def test_statsq_golden_own_scale(ops):
     d = load_golden("g1_statsq")
+    nbad = ntot = 0
     for c in range(int(d["ncases"])):
         g = group(d, "c%d" % c)
         bits = int(g["shape"][2])
         out, s, lv = ops.statsq_fwd(G(g["W"]), bits, want_levels=True)
         assert rel_err(s.cpu(), g["s"]) < 5e-7
-        # a level may only differ where c*n-0.5 sits within an ulp of a rounding tie
+        # a level may only differ where c*n-0.5 sits within an ulp of a rounding tie (the kernel sums |W| in fp64 and rounds
+        # once, torch-CPU in an fp32 cascade: the scales can differ by one ulp)
         bad = (lv.cpu() != T(g["L"]))
-        assert bad.float().mean() < 1e-4
+        nbad += int(bad.sum())
+        ntot += bad.numel()
+        assert int(bad.sum()) <= 1
         assert rel_err(out.cpu(), g["y"]) < 1e-6 or bad.any()
+    assert nbad <= 1e-5 * ntot, (nbad, ntot)          # measured: 0 of 127 k levels (full-size tensors: ~4e-7)
 
 
 def test_statsq_real_shapes_vs_oracle(ops):

@@ -275,6 +275,115 @@ def test_g9_swin_tiny_full_step():
         assert n > 80
 
 
+def _ofq_namespace():
+    from ofq_amd.deit_vision_transformer import Attention, Mlp
+    from ofq_amd.swin import ShiftedWindowAttention, MLP
+    from ofq_amd.quantization.modules.qlinear import QLinear, QMLP
+    from ofq_amd.quantization.modules.attention import QAttention, QAttention_qkreparam
+    from ofq_amd.quantization.modules.swin_attention_and_mlp import QAttention_swin_qkreparam, QMLP_swin
+    return {"QLinear": QLinear, "QMLP": QMLP, "Mlp": Mlp, "Attention": Attention, "QAttention": QAttention,
+            "QAttention_qkreparam": QAttention_qkreparam, "ShiftedWindowAttention": ShiftedWindowAttention,
+            "QAttention_swin_qkreparam": QAttention_swin_qkreparam, "QMLP_swin": QMLP_swin, "swin_MLP": MLP}
+
+
+def prod_oracle_forward(name):
+    """The oracle function of a tests/golden/prodcases.py case as f(x, params)."""
+    import prodcases as PC
+    c = PC.CASES[name]
+    k, wb, ab = c["kind"], c["wb"], c["ab"]
+    if k == "qlinear":
+        return lambda x, p: O.qlinear(x, p, wb, ab, unsigned=not c["sym"])
+    if k in ("qmlp", "swin_mlp"):
+        return lambda x, p: O.qmlp(x, p, wb, ab)
+    if k == "qkr":
+        return lambda x, p: O.qattention_qkr(x, p, c["H"], wb, ab)
+    if k == "plain":
+        return lambda x, p: O.qattention(x, p, c["H"], wb, ab)
+    return lambda x, p: O.swin_window_attention(x, p, c["H"], [7, 7], [c["shift"], c["shift"]], wb, ab, True)
+
+
+def prod_params(name, g):
+    """Parameter dict of a production-dimension case: the big weights come from the seeded constructor (the drop-in
+    module's own: its q / k / v split and copies are part of what is compared), everything else from the fixture."""
+    import prodcases as PC
+    q, x, _ = PC.build(name, _ofq_namespace())
+    p = {k: v.detach().clone() for k, v in q.state_dict().items()}
+    for k, v in g.items():
+        if k.startswith("p:"):
+            p[k[2:]] = T(v).clone()
+        if k.startswith("w2:"):
+            assert abs(float(p[k[3:]].double().norm()) - float(v)) < 1e-9 * float(v), k     # same weights as the generator's
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "clip_val" not in k and "relative_position_index" not in k:
+            v.requires_grad_(True)
+    return p, x
+
+
+def test_g10_production_dimension_modules():
+    """The oracle against the reference at the dimensions of the production kernels (DeiT-S fc1 / fc2 / QMLP / QKR
+    attention C=384 H=6, DeiT-T plain attention C=192 H=3, Swin-T window attention dim 96 and dim 384, QMLP_swin at
+    28 x 28 x 192): outputs, input gradient and every parameter gradient."""
+    import prodcases as PC
+    d = load_golden("g10_prod")
+    assert set(case_names(d)) == set(PC.CASES)
+    for name in PC.CASES:
+        g = group(d, name)
+        p, x = prod_params(name, g)
+        x = x.clone().requires_grad_(True)
+        y = prod_oracle_forward(name)(x, p)
+        (y * PC.upstream_grad(name, y.shape)).sum().backward()
+        errs = {"y": PC.compare(y, g, "y"), "dx": PC.compare(x.grad, g, "dx")}
+        n = 0
+        for k in list(g):
+            if k.startswith("grad:"):
+                pn = k[5:].split("@")[0]
+                if pn in errs:
+                    continue
+                assert p[pn].grad is not None, (name, pn)
+                errs[pn] = PC.compare(p[pn].grad, g, "grad:" + pn)
+                n += 1
+        assert n >= 5, (name, n)
+        for k, e in errs.items():
+            # summation order (einsum / bmm blocking) is the only difference: 1e-5 on the tensor scale
+            assert e["max"] < 2e-5 and e["l2"] < 2e-5 and e.get("norm", 0.0) < 1e-5, (name, k, e)
+
+
+def test_g11_fp32_teacher():
+    """The oracle's fp32 distilled DeiT (the KD teacher, train.py:428-442) against the reference's unquantised
+    DistilledVisionTransformer: train-mode (cls, dist) and eval-mode averaged logits."""
+    from ofq_amd.deit import DistilledVisionTransformer
+    from functools import partial
+    import torch.nn as nn
+    d = load_golden("g11_teacher")
+    for name in case_names(d):
+        g = group(d, name)
+        dim, depth, heads, B, ncls, seed = [int(v) for v in g["meta"]]
+        model = DistilledVisionTransformer(img_size=224, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads,
+                                           mlp_ratio=4, qkv_bias=True, num_classes=ncls,
+                                           norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU)
+        teacher_fill(model, seed)
+        w2 = float(sum(p.double().pow(2).sum() for p in model.parameters()) ** 0.5)
+        assert abs(w2 - float(g["w2"])) < 1e-9 * w2
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        img = T(det_uniform((B, 3, 224, 224), seed + 900, -2.0, 2.0))
+        with torch.no_grad():
+            c, dd = O.deit_fp32_forward(img, sd, depth, heads, training=True)
+            ev = O.deit_fp32_forward(img, sd, depth, heads, training=False)
+        assert rel_err(c, g["cls"]) < 1e-5 and rel_err(dd, g["dist"]) < 1e-5 and rel_err(ev, g["eval"]) < 1e-5
+
+
+def teacher_fill(model, seed):
+    """make_golden.teacher_fill: parameters from detgen seeds by parameter index."""
+    with torch.no_grad():
+        for i, (n, p) in enumerate(model.named_parameters()):
+            if p.dim() >= 2 and "norm" not in n:
+                p.copy_(T(det_normalish(tuple(p.shape), seed + i, 0.05)))
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(T(det_uniform(tuple(p.shape), seed + i, 0.8, 1.2)))
+            else:
+                p.copy_(T(det_uniform(tuple(p.shape), seed + i, -0.1, 0.1)))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree only exists in the build container")
 def test_committed_fixtures_are_what_the_generator_writes(tmp_path):
     """tests/golden/make_golden.py (which imports the reference itself) regenerates every committed fixture bit for bit:
@@ -285,7 +394,7 @@ def test_committed_fixtures_are_what_the_generator_writes(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, OFQ_GOLDEN_OUT=str(tmp_path))
     # reversed order on purpose: the files must not depend on which generators ran before
-    order = ["g9", "g8", "g7", "g6", "g5", "g4", "g3", "g2", "g1"]
+    order = ["g11", "g10", "g9", "g8", "g7", "g6", "g5", "g4", "g3", "g2", "g1"]
     subprocess.check_call([sys.executable, os.path.join(here, "golden", "make_golden.py")] + order, env=env,
                           stdout=subprocess.DEVNULL)
     committed = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith(".npz"))
