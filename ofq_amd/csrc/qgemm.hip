@@ -1854,6 +1854,376 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   tn_wide_body<NJ>(p, lid, gby);
 }
 
+// ---- persistent direct-mode variant (attention dqkx: K = the 198 tokens of an image, 7 k-steps per tile) ---------------
+// One workgroup walks `tpw` consecutive tiles of ONE outer batch entry (image): tile q -> inner batch b1 = q / (tiles_m *
+// tiles_n) (the head), tile q % (...).  The k-steps of all its tiles form one continuous stream through the same
+// two-stage LDS ring and two register prefetch slots as above: the loads of global step g+3 and the staging of step g+1
+// run behind the MFMAs of step g whichever tiles those steps belong to, so a tile boundary costs its epilogue (the stores
+// of the finished 128 x 384 tile) and nothing else -- no pipeline drain, no fresh memory round trip.  The one-tile-per-
+// workgroup launch of the same problem (1536 workgroups of 7 k-steps on 256 CUs: six rounds of prologue + 7 steps +
+// epilogue) took 178 us per DeiT-S block for 35 us of MFMA work.
+template <int NJ>
+__device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int chunk, const int b0, const int tpw) {
+  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int LDA = QTN_LD;
+  constexpr int LDB = BN * 2 + 64;
+  constexpr int PLANE = QTN_BK * LDA;
+  constexpr int STAGE = NS * PLANE + QTN_BK * LDB;
+  constexpr int CPR = BN / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float sred[16 * 32 * 4 + BM + BN];   // column sums of a finished tile, its offsets
+  const int tpi = p.tiles_m * p.tiles_n;                 // tiles per inner batch entry
+  const int T = tpi * p.nb1;
+  const int q0 = chunk * tpw, q1 = min(T, q0 + tpw);
+  if (q0 >= q1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
+  const int a_k = tid >> 5, a_t = (tid & 31) * 4;
+  const int ldA = (int)p.lda, ldB = (int)p.ldb;
+  int b_row[NJ], b_col[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int f = tid + 512 * i;
+    b_row[i] = f / CPR;
+    b_col[i] = (f % CPR) * 8;
+  }
+  unsigned rowA[2], rowB[NJ];                            // byte offsets of this lane's rows inside a k-step
+#pragma unroll
+  for (int i = 0; i < 2; ++i) rowA[i] = 4u * (unsigned)((a_k + 16 * i) * ldA);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) rowB[j] = (unsigned)(b_row[j] * ldB);
+  const unsigned maxA = 4u * (unsigned)((p.Ktok - 1) * ldA), maxB = (unsigned)((p.Ktok - 1) * ldB);
+
+  // ---- load cursor: the tile / k-step the NEXT global loads fetch --------------------------------------------------------
+  // (tile bases are wave-uniform -> scalar registers; a lane adds one 32-bit offset: row part clamped to the last token,
+  // column part zeroed for columns outside the matrix, whose products are never stored)
+  int lq = q0, lk = 0;
+  const char* LAs;                                       // cursor tile's A panel, column m0          (uniform)
+  const char* LBs;                                       // cursor tile's B panel, column n0          (uniform)
+  unsigned colA;                                         // this lane's column quad inside the tile, in bytes
+  unsigned colB[NJ];
+  bool la_ok;
+  auto set_load_tile = [&](int q) {
+    const int qc = min(q, q1 - 1);
+    const int b1 = qc / tpi, t = qc - b1 * tpi;
+    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+    la_ok = (m0 + a_t) < p.M;
+    LAs = reinterpret_cast<const char*>(p.A + b0 * p.sA0 + b1 * p.sA1 + m0);
+    LBs = reinterpret_cast<const char*>(p.B + b0 * p.sB0 + b1 * p.sB1 + n0);
+    colA = la_ok ? 4u * (unsigned)a_t : 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) colB[j] = (n0 + b_col[j]) < p.N ? (unsigned)b_col[j] : 0u;
+  };
+  set_load_tile(lq);
+  auto advance_cursor = [&]() {
+    if (++lk == nkt) {
+      lk = 0;
+      ++lq;
+      set_load_tile(lq);
+    }
+  };
+
+  f32x4v ra[2][2];
+  float rs[2][2];
+  bool rok[2][2];
+  u32x2v rb[2][NJ];
+  // prologue-style (un-interleaved) load / stage, used for the first three steps of the stream only
+  auto gload = [&](auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const bool live = lq < q1;
+    const int k0 = lk * QTN_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + a_k + 16 * i;
+      rok[sl][i] = la_ok && k < p.Ktok && live;
+      ra[sl][i] = *reinterpret_cast<const f32x4v*>(LAs + (min(4u * (unsigned)(k0 * ldA) + rowA[i], maxA) + colA));
+      rs[sl][i] = p.s[min(k, p.S - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      rb[sl][j] = *reinterpret_cast<const u32x2v*>(LBs + (min((unsigned)(k0 * ldB) + rowB[j], maxB) + colB[j]));
+    advance_cursor();
+  };
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto lstore = [&](unsigned char* sb, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rb[sl][j]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float sc = rok[sl][i] ? ofq_lsq_eff_scale(rs[sl][i], p.gscale) : 0.f;
+      const float okf = rok[sl][i] ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
+      const f32x2v v01 = {ra[sl][i][0], ra[sl][i][1]}, v23 = {ra[sl][i][2], ra[sl][i][3]};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(v01 * sc, lo);
+      split_pair_bf16<NS>(v23 * sc, hi);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 w;
+        w.x = lo[q];
+        w.y = hi[q];
+        *reinterpret_cast<uint2*>(&sb[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      unsigned bw[4];
+      valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+      valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+      *reinterpret_cast<uint4*>(&sb[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  f32x16q acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int p16 = lane & 15;
+  const int fr_a = (8 * lh + (p16 >> 2)) * LDA + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  const int fr_b = (8 * lh + (p16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
+  static_assert(QTN_BK == 32, "two MFMA steps per k-step");
+
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  constexpr int NM = 12 * NJ, NPA = 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;
+  // one k-step of the stream: MFMA on `cur`, staging of the next step (register slot SLOT -> `nxt`), loads at the cursor
+  // into the freed slot; the piece list is the one of tn_wide_body
+  bool skip_i1 = false;           // this wave's second 32-row block lies outside the matrix in the tile being computed
+  auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    bf16x8 av[NS][2], bv[2][NJ];
+    const unsigned char* sa = &cur[fr_a + wm * 64 * 2];
+    const unsigned char* sbb = &cur[NS * PLANE + fr_b + wn * 32 * NJ * 2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[0][j] = tr_frag_ld<LDB>(sbb + j * 64);
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + i * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    float sc = 0.f, okf = 0.f, x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+    unsigned lo[NS], hi[NS], bw[4];
+    const bool live = lq < q1;
+    const int rows_left = p.Ktok - lk * QTN_BK;
+    const unsigned kofsA = 4u * (unsigned)(lk * QTN_BK * ldA), kofsB = (unsigned)(lk * QTN_BK * ldB);
+    const int kbase = lk * QTN_BK;
+    auto piece = [&](auto P_) {
+      constexpr int P = decltype(P_)::value;
+      if constexpr (P < 2 * NPA) {
+        constexpr int i = P / NPA, r = P % NPA;
+        if constexpr (r == 0) {
+          asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));
+          const float e = valu_eff_scale(rs[sl][i], p.gscale);
+          sc = rok[sl][i] ? e : 0.f;
+          okf = rok[sl][i] ? 1.f : 0.f;
+        } else if constexpr (r < 15) {
+          constexpr int pr = (r - 1) / 7, rr = (r - 1) % 7;
+          if constexpr (rr < 6) {
+            constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+            if constexpr (st == 0) {
+              valu_mul_hi16(ra[sl][i][e], sc, x_, p0v[el]);
+              cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
+            }
+            if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+          } else {
+            valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
+          }
+        } else {
+          constexpr int q = r - 15;
+          uint2 w;
+          w.x = lo[q];
+          w.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+        }
+      } else if constexpr (P < 2 * NPA + NPB * NJ) {
+        constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
+        if constexpr (r == 0) {
+          asm volatile("" : "+v"(rb[sl][j]));
+          valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+        } else if constexpr (r == 1) {
+          valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+        } else {
+          *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+        }
+      } else if constexpr (P < 2 * NPA + NPB * NJ + 2) {
+        constexpr int i = P - 2 * NPA - NPB * NJ;
+        rok[sl][i] = la_ok && (a_k + 16 * i) < rows_left && live;
+        ra[sl][i] = *reinterpret_cast<const f32x4v*>(LAs + (min(kofsA + rowA[i], maxA) + colA));
+        rs[sl][i] = p.s[min(kbase + a_k + 16 * i, p.S - 1)];
+      } else {
+        constexpr int j = P - 2 * NPA - NPB * NJ - 2;
+        rb[sl][j] = *reinterpret_cast<const u32x2v*>(LBs + (min(kofsB + rowB[j], maxB) + colB[j]));
+      }
+    };
+    static_for<NM>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+#ifdef TNS_SKIP_PAD_BLOCKS
+      if (i == 0 || !skip_i1)
+#endif
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (ks == 0) {
+        if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
+        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+      }
+      constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+    advance_cursor();
+  };
+  auto set_compute_tile = [&](int q) {
+    const int t = q % tpi;
+    skip_i1 = ((t / p.tiles_n) * BM + wm * 64 + 32) >= p.Mstore;
+  };
+
+  // the finished tile q: C (+ colsum_k(A)[m] * baft[n]) to global memory, accumulators back to zero.  Nothing here may
+  // wait on the vector-memory counter: the prefetch loads of the next steps are in flight (the offset vector comes from
+  // LDS, where bf_reg -- loaded at the tile's first step -- was parked before the tile's last barrier).
+  auto epilogue = [&](int q) {
+    const int b1 = q / tpi, t = q - b1 * tpi;
+    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+    float* red1 = sred + 16 * 32 * 4;
+    float* sbf = red1 + BM;
+    if (p.baft) {
+      float4* red = reinterpret_cast<float4*>(sred);       // the tile's partial column sums: stored before its last step
+      if (a_k == 0) {
+        float4 tt = red[tid & 31];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) {
+          const float4 u = red[g * 32 + (tid & 31)];
+          tt.x += u.x; tt.y += u.y; tt.z += u.z; tt.w += u.w;
+        }
+        *reinterpret_cast<float4*>(red1 + a_t) = tt;
+      }
+      lds_barrier();
+    }
+    // uniform tile base + one 32-bit lane offset per store (an image's slab of C is far below 2^31 bytes: host check).
+    // The lane ids pass through an empty volatile asm: otherwise the 32 row offsets are loop-invariant, get hoisted out
+    // of the k-step stream and cost 60+ live VGPRs there (the kernel spilled 170 registers)
+    int l31e = l31, lhe = lh;
+    asm volatile("" : "+v"(l31e), "+v"(lhe));
+    float* Cs = p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m0 * p.ldc + n0;
+    const int ldc = (int)p.ldc;
+    const bool full_n = (n0 + BN) <= p.Nstore;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rv = p.Mstore - (m0 + wm * 64 + i * 32);   // valid rows of this wave's 32-row block (wave-uniform)
+      if (rv <= 0) continue;                               // all padding: its MFMAs were skipped, acc stayed zero
+      float rsum[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        rsum[e] = p.baft ? red1[wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhe] : 0.f;
+      if (full_n && rv >= 32) {                            // interior block: straight stores
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn * 32 * NJ + j * 32 + l31e;
+          const float bf = p.baft ? sbf[nl] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhe;
+            Cs[ml * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn * 32 * NJ + j * 32 + l31e;
+          const bool nok = (n0 + nl) < p.Nstore;
+          const float bf = p.baft ? sbf[nl] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int mr = (e & 3) + 8 * (e >> 2) + 4 * lhe;
+            const int ml = wm * 64 + i * 32 + mr;
+            if (nok && mr < rv) Cs[ml * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+        }
+      }
+    }
+    if (p.baft) lds_barrier();      // sred / red1 / sbf are rewritten during the next tile
+  };
+
+  gload(Slot0());
+  gload(Slot1());
+  lstore(smem, Slot0());
+  gload(Slot0());
+  lds_barrier();
+  int cq = q0, ck = 0;
+  const int G = (q1 - q0) * nkt;
+  float bf_reg = 0.f;             // this thread's element of the tile's offset vector baft[n0 .. n0 + BN)
+  auto load_bf = [&](int q) {
+    if (p.baft && tid < BN) {
+      const int b1 = q / tpi, t = q - b1 * tpi;
+      const int n = (t % p.tiles_n) * BN + tid;
+      bf_reg = p.baft[min(n, p.Nstore - 1) + b1 * p.sBf1];
+    }
+  };
+  auto pre = [&]() {
+    if (ck == 0) load_bf(cq);
+    if (ck == nkt - 1) {          // every k-step of tile cq has been staged: the staging of this step feeds the next tile
+      // (sred is free: the previous tile's epilogue ended with an LDS barrier; this step's barrier publishes the stores)
+      reinterpret_cast<float4*>(sred)[a_k * 32 + (tid & 31)] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      if (p.baft && tid < BN) sred[16 * 32 * 4 + BM + tid] = bf_reg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] = 0.f;
+    }
+  };
+  auto post = [&]() {
+    if (++ck == nkt) {
+      epilogue(cq);
+      ck = 0;
+      ++cq;
+      set_compute_tile(min(cq, q1 - 1));
+    }
+  };
+  set_compute_tile(q0);
+  int g = 0;
+  for (; g + 1 < G; g += 2) {
+    pre();
+    step(smem, smem + STAGE, Slot1());
+    post();
+    pre();
+    step(smem + STAGE, smem, Slot0());
+    post();
+  }
+  if (g < G) {
+    pre();
+    step(smem, smem + STAGE, Slot1());
+    post();
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_stream_kernel(QTnArgs p, int tpw, int stagger) {
+  int chunk, b0;
+  xcd_remap_grid(chunk, b0);
+  // All workgroups start together and every tile takes the same time, so without this they would all reach their
+  // epilogues (196 KB of stores each, 50 MB chip-wide) in the same microsecond, six times per launch -- and on gfx9 the
+  // vector-memory counter is shared by loads and stores: a wave cannot consume a prefetched load that it issued after its
+  // epilogue stores before those stores have retired, so the store burst stalls the k-step stream (measured: 15 us per
+  // tile boundary).  Phase-shifting the workgroups by a fraction of a tile period spreads the stores over the launch.
+  if (stagger > 0) {
+    const int phase = (blockIdx.y * gridDim.x + blockIdx.x) % stagger;
+    for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(70);           // ~2.2 us each (64 x 70 clocks)
+  }
+  tn_wide_stream_body<NJ>(p, chunk, b0, tpw);
+}
+
 // Several split-K problems in one launch.  The weight-gradient GEMMs of the linear layers have no consumer before the
 // optimiser step (or the gradient bucket's all-reduce), so the host defers them (functional.queue_dw) and launches the
 // ones of a whole transformer block together: 45-48 tiles x split 5 instead of five launches of 3-18 tiles x split
@@ -3521,6 +3891,21 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
   static const bool narrow_only = getenv("OFQ_TN_NARROW") != nullptr;
   if (C % 384 == 0 && N >= QTN_BK && !narrow_only && N * ldS < (1ll << 31) && N * C < (1ll << 31)) {
     a.tiles_n = (int)(C / 384);       // one split of a dS panel feeds all 384 columns
+    static const bool no_stream = getenv("OFQ_TN_NO_STREAM") != nullptr;      // A/B switch
+    const int64_t T = (int64_t)a.tiles_m * a.tiles_n * H;                     // tiles per image
+    if (!no_stream && T >= 2) {
+      // persistent workgroups: each walks `tpw` tiles of one image (about one workgroup per CU in total)
+      int64_t tpw = (B * T) / 256;
+      if (const char* e = getenv("OFQ_TN_STREAM_TPW")) tpw = atoi(e);       // test hook: tiles per workgroup
+      tpw = tpw < 1 ? 1 : (tpw > T ? T : tpw);
+      while (T % tpw) --tpw;                                                  // equal chunks
+      int stagger = 0;                                                      // measured: 121 us without, 149 us with a 6-phase shift
+      if (const char* e = getenv("OFQ_TN_STREAM_STAGGER")) stagger = atoi(e);  // A/B switch
+      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_stream_kernel<3>, dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
+                         (hipStream_t)stream, a, (int)tpw, stagger);
+      OFQ_LAUNCH_CHECK();
+      return 0;
+    }
     hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(512), 0,
                        (hipStream_t)stream, a);
     OFQ_LAUNCH_CHECK();

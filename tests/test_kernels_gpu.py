@@ -473,6 +473,36 @@ def test_qgemm_tn_group_equals_single_launches(ops, cls):
         assert rel_err(j["dW"].cpu(), rW.cpu()) < 1e-5 and rel_err(j["db"].cpu(), rb.cpu()) < 1e-5
 
 
+def test_qattn_dqkx_persistent_stream_any_tiles_per_workgroup(ops, monkeypatch):
+    """ofq_qattn_dqkx_bf16s at DeiT-S dimensions runs on persistent workgroups that walk several (head, m-tile) tiles of
+    an image as one k-step stream (qgemm_bf16s_tn_wide_stream_kernel).  The result must not depend on how many tiles a
+    workgroup walks (1, 2, 4, 12 of the 12 tiles of an image; 5 is rounded down to a divisor): bit-identical outputs, and
+    the fp32-exact product of (dS * a_eff) with the codes plus the offset term (attention.py:210 autograd) against fp64."""
+    B, H, N, C = 3, 6, 198, 384
+    Np = 208
+    rs = np.random.RandomState(11)
+    dS = torch.from_numpy(rs.randn(B, H, N, Np).astype(np.float32)) * T(det_uniform((B, H, N, 1), 301, 1e-3, 10.0))
+    xcodes = torch.from_numpy(rs.randint(-2, 2, (B, N, C)).astype(np.int8))
+    sx = T(det_uniform((N,), 302, 0.1, 1.0))
+    bax = T(det_uniform((C,), 303, -0.05, 0.05))
+    gx = 0.01
+    ae = O.lsq_effective_scale(sx, gx).double()
+    d = dS[..., :N].double()                                              # [b,h,n,m]
+    ref = torch.einsum("bhnm,bnc->bmhc", d * ae[None, None, :, None], xcodes.double()) \
+        + d.sum(2).permute(0, 2, 1)[..., None] * bax.double()[None, None, None, :]
+    den = torch.einsum("bhnm,bnc->bmhc", (d * ae[None, None, :, None]).abs(), xcodes.double().abs()) + 1e-30
+    outs = []
+    for tpw in ("1", "2", "4", "12", "5"):
+        monkeypatch.setenv("OFQ_TN_STREAM_TPW", tpw)
+        dq = ops.qattn_dqkx(dS.cuda(), xcodes.cuda(), sx.cuda(), gx, bax.cuda(), B, H, N, C, Np)
+        outs.append(dq.cpu())
+        assert float(((dq.cpu().double() - ref).abs() / den).max()) < 2e-6, tpw
+    monkeypatch.delenv("OFQ_TN_STREAM_TPW")
+    dq = ops.qattn_dqkx(dS.cuda(), xcodes.cuda(), sx.cuda(), gx, bax.cuda(), B, H, N, C, Np)
+    for o in outs:
+        assert torch.equal(o, dq.cpu())
+
+
 # ------------------------------------------------------------------------------------------------ attention on codes
 def test_qattn_code_kernels_vs_fp64(ops):
     B, H, N, d = 2, 3, 198, 32
