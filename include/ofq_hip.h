@@ -239,6 +239,15 @@ int ofq_qattn_pv_i8(const int8_t* pcodes, const int8_t* vcodesT, float* O, const
                     int64_t d, int64_t Np, ofq_stream_t stream);
 int ofq_qattn_dp_bf16s(const float* dO, const int8_t* vcodes, float* dP, const float* sv, float gscale_v, const float* w,
                        int64_t B, int64_t H, int64_t N, int64_t d, int64_t ldP, ofq_stream_t stream);
+/*  dP GEMM + backward of P_hat = LSQ_unsigned(softmax(alpha * S)) in one kernel (autograd of attention.py:213-219):
+ *  dS[b,h,n,:] from dO[b,n,h*d:(h+1)*d], the v codes / step sv (+ offset bav: the row constant dO . bav), the saved
+ *  probabilities `prob` and the softmax quantiser's steps sm_s; dP never reaches memory.  ds[N] (optional) = the step
+ *  gradient, ds_rowsum (optional) = row sums of dS.  N, ld <= 256, ld % 4 == 0, d % 16 == 0. */
+size_t ofq_qattn_dp_softmax_bwd_ws_bytes(int64_t B, int64_t H, int64_t N);
+int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, const float* sv, float gscale_v, const float* bav,
+                             const float* prob, const float* sm_s, float sm_gscale, float alpha, int hi, float* dS,
+                             float* ds, float* ds_rowsum, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ld,
+                             void* ws, size_t ws_bytes, ofq_stream_t stream);
 int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
                        int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream);
 int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ofq_qattn_pv_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dp_softmax_bwd_ws_bytes": (sz, [i64, i64, i64]),
+    "ofq_qattn_dp_softmax_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, f32, f32, i32, vp, vp, vp, i64, i64, i64, i64, i64, vp, sz, vp]),
     "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp]),
     "ofq_rowdot_i8_multi": (i32, [vp, vp, vp, i64, i64, i32, vp]),

@@ -651,6 +651,7 @@ class SoftmaxLsqCodesFn(torch.autograd.Function):
 
 
 FUSE_SCORES_SOFTMAX = os.environ.get("OFQ_NO_SCORES_SOFTMAX_FUSE") is None
+FUSE_DP_SOFTMAX_BWD = os.environ.get("OFQ_NO_DP_SOFTMAX_FUSE") is None          # A/B switch
 ATTN_PREP = os.environ.get("OFQ_NO_ATTN_PREP") is None          # u, tq, v^T in one launch (A/B switch)
 
 
@@ -695,6 +696,10 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         ctx.dims = (B, H, N, C, Np)
         ctx.mark_non_differentiable(codes, rsum)
         ctx.set_materialize_grads(False)
+        vl = aux.get("vlink")
+        if vl is not None:
+            # the P.V product that consumes these codes hands its dO over instead of a materialised dP (PVCodesFn.backward)
+            vl["fuse_dp"] = FUSE_DP_SOFTMAX_BWD and 64 < N <= 256 and Np <= 256 and (C // H) % 16 == 0 and C % 4 == 0
         return ops.placeholder((B, H, N, Np), prob.device), codes, rsum
 
     @staticmethod
@@ -705,8 +710,14 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         aux = ctx.aux
         B, H, N, C, Np = ctx.dims
         rows, alpha, hi = B * H * N, aux["alpha"], aux["hi"]
-        g = g.contiguous()
-        dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, rows, inplace=True, want_rowsum=True)
+        vl = aux.get("vlink")
+        dO = vl.pop("dO_for_dp", None) if vl is not None else None
+        if dO is not None:
+            dS, ds, rs = ops.qattn_dp_softmax_bwd(dO, vl["vcodes"], vl["sv"], vl["gv"], vl["bav"], prob, s, alpha, hi, B, H, N,
+                                                  dO.shape[-1] // H, Np, want_rowsum=KEEP_ZERO_ROWSUM_TERM)
+        else:
+            g = g.contiguous()
+            dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, rows, inplace=True, want_rowsum=True)
         dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[4]) else None
         if aux["plain"]:
             d = C // H
@@ -754,9 +765,14 @@ class PVCodesFn(torch.autograd.Function):
         B, H, N, d, Np = ctx.dims
         C = H * d
         dO = dO.contiguous()
+        dV = ops.qattn_dv(dO, aux["pcodes"], aux["sp"], aux["gp"], B, H, N, d, Np)
+        if aux.get("fuse_dp"):
+            # dP is not materialised: the backward of the softmax quantiser (ScoresSoftmaxCodesFn.backward, the only
+            # consumer of this gradient) computes it tile by tile from dO inside ofq_qattn_dp_softmax_bwd
+            aux["dO_for_dp"] = dO
+            return ops.placeholder((B, H, N, Np), dO.device), dV, None
         w = ops.rowdot_f32_seg(dO.view(B * N, C), aux["bav"], H, d)
         dP = ops.qattn_dp(dO, aux["vcodes"], aux["sv"], aux["gv"], w, B, H, N, d, Np)
-        dV = ops.qattn_dv(dO, aux["pcodes"], aux["sp"], aux["gp"], B, H, N, d, Np)
         return dP, dV, None
 
 

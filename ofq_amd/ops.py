@@ -605,6 +605,21 @@ def qattn_dp(dO, vcodes, sv, gv, w, B, H, N, d, ldP):
     return dP
 
 
+def qattn_dp_softmax_bwd(dO, vcodes, sv, gv, bav, prob, sm_s, alpha, hi, B, H, N, d, ld, want_rowsum=False):
+    """dS, ds (softmax quantiser step gradient), [row sums of dS] from dO: the dP GEMM and ofq_softmax_lsq_bwd in one kernel
+    (same values as qattn_dp + softmax_lsq_bwd up to the summation order inside the K = d products)."""
+    dS = torch.empty((B, H, N, ld), dtype=torch.float32, device=dO.device)
+    ds = torch.empty_like(sm_s)
+    rs = torch.empty(B * H * N, dtype=torch.float32, device=dO.device) if want_rowsum else None
+    gscale = 1.0 / math.sqrt(hi * (B * H * N))
+    ws = workspace(lib().ofq_qattn_dp_softmax_bwd_ws_bytes(B, H, N), dO.device)
+    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+        _chk(lib().ofq_qattn_dp_softmax_bwd(dO.data_ptr(), vcodes.data_ptr(), sv.data_ptr(), float(gv), _p(bav), prob.data_ptr(),
+                                            sm_s.data_ptr(), gscale, float(alpha), int(hi), dS.data_ptr(), ds.data_ptr(), _p(rs),
+                                            B, H, N, d, ld, ws.data_ptr(), ws.numel(), _stream()), "ofq_qattn_dp_softmax_bwd")
+    return dS, ds, rs
+
+
 def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
     dV = torch.empty((B, N, H * d), dtype=torch.float32, device=dO.device)
     with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):

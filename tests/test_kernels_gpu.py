@@ -503,6 +503,50 @@ def test_qattn_dqkx_persistent_stream_any_tiles_per_workgroup(ops, monkeypatch):
         assert torch.equal(o, dq.cpu())
 
 
+@pytest.mark.parametrize("dims", [(3, 6, 198, 64, 208, 3), (2, 3, 198, 64, 208, 15), (2, 2, 250, 32, 256, 3), (2, 4, 100, 48, 112, 7)])
+def test_qattn_dp_softmax_bwd_fused_equals_the_two_kernels(ops, dims):
+    """ofq_qattn_dp_softmax_bwd (dP GEMM + softmax-LSQ backward, dP never in memory) against ofq_qattn_dp followed by
+    ofq_softmax_lsq_bwd: dS, the step gradient ds and the row sums; and against fp64 of the same formulas
+    (attention.py:213-219 under autograd).  Head dims 64 / 32 / 48, 2- and 4-bit codes, N up to 250 keys."""
+    B, H, N, d, Np, hi = dims
+    C = H * d
+    rs = np.random.RandomState(21)
+    dO = torch.from_numpy(rs.randn(B, N, C).astype(np.float32)) * T(det_uniform((B, N, 1), 401, 1e-3, 3.0))
+    vcodes = torch.from_numpy(rs.randint(-4, 4, (B, N, C)).astype(np.int8))
+    sv = T(det_uniform((C,), 402, 0.05, 0.5))
+    bav = T(det_uniform((C,), 403, -0.05, 0.05))
+    gv = 0.02
+    logits = torch.from_numpy(rs.randn(B, H, N, N).astype(np.float32)) * 2.0
+    prob = torch.zeros(B, H, N, Np)
+    prob[..., :N] = torch.softmax(logits, -1)
+    sm_s = T(det_uniform((N,), 404, 0.02, 0.2))
+    alpha = d ** -0.5
+    rows = B * H * N
+    cu = lambda t: t.cuda()
+    w = ops.rowdot_f32_seg(cu(dO).view(B * N, C), cu(bav), H, d)
+    dP = ops.qattn_dp(cu(dO), cu(vcodes), cu(sv), gv, w, B, H, N, d, Np)
+    dS0, ds0, rs0 = ops.softmax_lsq_bwd(dP.clone(), cu(prob), cu(sm_s), rows, N, Np, N, alpha, hi, rows, inplace=True,
+                                        want_rowsum=True)
+    dS1, ds1, rs1 = ops.qattn_dp_softmax_bwd(cu(dO), cu(vcodes), cu(sv), gv, cu(bav), cu(prob), cu(sm_s), alpha, hi, B, H, N, d,
+                                             Np, want_rowsum=True)
+    assert rel_err(dS1[..., :N].cpu(), dS0[..., :N].cpu()) < 2e-6
+    assert rel_err(ds1.cpu(), ds0.cpu()) < 1e-5
+    assert float((rs1.cpu() - rs0.cpu()).abs().max()) < 1e-5 * float(dS0[..., :N].abs().max())
+    assert float(dS1[..., N:].abs().max()) == 0.0 if Np > N else True
+    # fp64 of the formulas
+    ae = O.lsq_effective_scale(sv, gv).double()
+    vh = vcodes.double() * ae + bav.double()
+    dPr = torch.einsum("bnhj,bmhj->bhnm", dO.double().view(B, N, H, d), vh.view(B, N, H, d))
+    a = O.lsq_effective_scale(sm_s, 1.0 / (hi * rows) ** 0.5).double()[None, None, :, None]
+    p = prob[..., :N].double()
+    v = p / a
+    inr = (v >= 0) & (v <= hi)
+    dq = torch.where(inr, dPr, torch.zeros_like(dPr))
+    dot = (dq * p).sum(-1, keepdim=True)
+    ref = (dq - dot) * p * alpha
+    assert rel_err(dS1[..., :N].cpu(), ref.float()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ attention on codes
 def test_qattn_code_kernels_vs_fp64(ops):
     B, H, N, d = 2, 3, 198, 32
