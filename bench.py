@@ -63,6 +63,9 @@ def parse():
                     help="with --with-teacher: fp32-MFMA GEMMs, or the weights pre-split into bf16 planes (9 / 6 plane products)")
     ap.add_argument("--stock-teacher", action="store_true",
                     help="with --with-teacher: run the teacher through stock PyTorch-ROCm (hipBLASLt) instead of the HIP kernels")
+    ap.add_argument("--sync-statsq", action="store_true",
+                    help="also all-reduce the StatsQ scale vectors each step and assert that it changes nothing (north_star's "
+                         "'StatsQ statistics' collective: not in the reference, a no-op by construction)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -259,7 +262,8 @@ def main():
     torch.cuda.synchronize()
     say("setup_alpha done")
     model.train()
-    dp = parallel.DataParallel(model, bucket_mb=24.0, force_sync=args.force_dp) if (world > 1 or args.force_dp) else None
+    dp = (parallel.DataParallel(model, bucket_mb=24.0, force_sync=args.force_dp, sync_statsq=args.sync_statsq)
+          if (world > 1 or args.force_dp) else None)
     opt = engine.make_optimizer(model, lr=5.47e-4, weight_decay=0.05)
     cga = engine.CGAHooks(model, args.wbits, 0.005, qk_reparam=not args.no_qkr) if args.cga else None
     loss_fn = KDLossSoftandHard()

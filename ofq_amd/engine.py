@@ -341,6 +341,16 @@ class GraphedTrainStep:
             before = q.latched()
             q._latch(q.latch_input(images, getattr(m, "move_b4").bias))
             flipped |= q.latched() != before
+        if self.dp is not None and self.dp.sync and self.dp.world > 1 and self._latches:
+            # every rank must take the same decision (re-capture or replay): one rank's batch may flip the latch while the
+            # others' do not -- and sync_buffers() hands rank 0's flag to everybody on the next call anyway
+            import torch.distributed as dist
+            f = torch.tensor([1.0 if flipped else 0.0], device=images.device)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.dp.group)
+            if float(f) > 0 and not flipped:
+                for m, q in self._latches:
+                    q.force_latch()
+                flipped = True
         if self.graph is not None and (flipped or any(a.shape != b.shape or a.dtype != b.dtype
                                                       for a, b in zip((images, target, soft_target), self.static))):
             self.graph = None                              # clamp bounds / shapes are baked into the captured launches

@@ -50,6 +50,12 @@ def grad_slot(param):
     hit = _GRAD_SLOTS.get(id(param))
     if hit is None or hit[0]() is not param:
         return None
+    if hit[2][0]:
+        # a second node asks for the same leaf's slot in one backward (a module called twice, weight tying, checkpointing):
+        # both would write the slice and autograd would then add two aliases of one memory -- only the first writer gets
+        # the slot, the others produce ordinary gradients that autograd accumulates
+        return None
+    hit[2][0] = True
     return hit[1].detach()        # a new tensor object on the same memory: autograd adopts it as .grad without a copy
 
 
@@ -63,13 +69,22 @@ class GradBucket:
 
 
 class DataParallel(torch.nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=24.0, broadcast=True, force_sync=False):
+    def __init__(self, module, process_group=None, bucket_mb=24.0, broadcast=True, force_sync=False, sync_statsq=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_sync: run the hooks / collectives even in a one-rank group (exercises the RCCL path on a 1-GPU box)
         self.sync = self.world > 1 or (force_sync and dist.is_initialized())
+        # sync_statsq: BASELINE.json's north_star names an all-reduce "of StatsQ statistics".  The reference has none and needs
+        # none: s = 2 * mean|W| is a pure function of weights that are identical on every rank after the gradient all-reduce
+        # (SURVEY.md 2.3 / 8e).  With this flag the per-row scales of every StatsQ quantiser are all-reduced (mean) right
+        # behind the last gradient bucket of each step and ASSERTED to be a no-op (checked on the host every
+        # `statsq_check_every` steps, so that the step itself gains no synchronisation point)
+        self.sync_statsq = bool(sync_statsq) and self.sync
+        self.statsq_check_every = 50
+        self._statsq_pending = None
+        self._steps = 0
         self._hooks = []
         self._bucket_mb = bucket_mb
         self._arrival = None               # parameter arrival order of the first synchronised backward (then: buckets rebuilt)
@@ -158,7 +173,7 @@ class DataParallel(torch.nn.Module):
             for p, v in zip(grp, b.views):
                 self._bucket_of[p] = b
                 if self.sync:
-                    _GRAD_SLOTS[id(p)] = (weakref.ref(p), v)
+                    _GRAD_SLOTS[id(p)] = (weakref.ref(p), v, [False])      # [taken in the current backward]
         if self.sync:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -170,6 +185,11 @@ class DataParallel(torch.nn.Module):
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+            if self.sync:
+                for p in b.params:
+                    hit = _GRAD_SLOTS.get(id(p))
+                    if hit is not None:
+                        hit[2][0] = False
         if self.sync and not self._rebuilt and self._arrival is None:
             self._arrival = []                        # record the first synchronised backward
 
@@ -219,11 +239,23 @@ class DataParallel(torch.nn.Module):
             for b in self.buckets:
                 if b.work is None:                      # bucket with parameters that got no gradient this step
                     self._launch(b)
+            if self.sync_statsq:
+                self._statsq_all_reduce()
             for b in self.buckets:
                 b.work.wait()
+            if not self._rebuilt and self._arrival and _capturing(self.buckets[0].flat):
+                # a first synchronised backward inside a stream capture cannot rebuild (allocation, copies): drop the
+                # recording and take the next eager backward's (hooks do not fire during replays, so keeping it would
+                # append a second pass and hand every parameter to _build_buckets twice)
+                self._arrival = None
             if not self._rebuilt and self._arrival and not _capturing(self.buckets[0].flat):
                 # same autograd graph on every rank => same arrival order on every rank => same buckets
-                order, self._arrival, self._rebuilt = self._arrival, None, True
+                seen, order = set(), []
+                for p in self._arrival:                # (first arrival counts, should a parameter ever be recorded twice)
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        order.append(p)
+                self._arrival, self._rebuilt = None, True
                 grads = {id(p): p.grad for b in self.buckets for p in b.params}
                 self._build_buckets(self._bucket_mb, order=order)
                 for b in self.buckets:                # this step's averaged gradients move to the new slices
@@ -235,8 +267,55 @@ class DataParallel(torch.nn.Module):
                 return
         self._reset()
 
+    def _statsq_all_reduce(self):
+        """all-reduce(mean) of every StatsQ scale vector of this step's forward; must leave them unchanged."""
+        vecs = [m._s_dev.reshape(-1) for m in self.module.modules() if getattr(m, "_s_dev", None) is not None]
+        if not vecs:
+            return
+        local = torch.cat(vecs)
+        mean = local.clone()
+        if self._avg:
+            dist.all_reduce(mean, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group)
+            mean.div_(self.world)
+        dev = (mean - local).abs().max()                 # stays on the device ...
+        self._statsq_pending = dev if self._statsq_pending is None else torch.maximum(self._statsq_pending, dev)
+        self._steps += 1
+        if self._steps % self.statsq_check_every == 0 and not _capturing(local):
+            self.check_statsq_pending()                   # ... and is looked at every few steps
+
+    def check_statsq_pending(self):
+        """Host check of the deviations accumulated by _statsq_all_reduce (a synchronisation point).  Averaging identical
+        values over a power-of-two number of ranks is exact; otherwise the mean may differ from the value in its last bit."""
+        if self._statsq_pending is None:
+            return 0.0
+        dev, self._statsq_pending = float(self._statsq_pending), None
+        if dev > 0.0 and (self.world & (self.world - 1)) == 0:
+            raise RuntimeError("ofq_amd DataParallel: StatsQ scales differ between ranks by %g -- the replicas' weights "
+                               "have diverged" % dev)
+        return dev
+
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    def release(self):
+        """Detach from the module: remove the gradient hooks and this wrapper's direct-write slots (grad_slot would
+        otherwise keep aliasing p.grad into the buckets of a wrapper that no longer synchronises anything)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for b in self.buckets:
+            for p in b.params:
+                hit = _GRAD_SLOTS.get(id(p))
+                if hit is not None and hit[0]() is p:
+                    del _GRAD_SLOTS[id(p)]
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def gradient_bytes(self):
         return sum(b.flat.numel() * 4 for b in self.buckets)

@@ -245,6 +245,12 @@ class LsqQuantizer4img(_LsqBase):
             self.signed.data.fill_(1)
             self._signed_host = True
 
+    def force_latch(self):
+        """Another rank has seen a negative value (engine.GraphedTrainStep all-reduces the decision so that every rank
+        re-captures together); DDP's buffer broadcast would hand over rank 0's flag on the next forward anyway."""
+        self.signed.data.fill_(1)
+        self._signed_host = True
+
     def _geom(self, shp, bias_len, prologue, ldx, ldy):
         B, Cc, Hh, Ww = shp
         return ops.LsqGeom(B, Cc, Hh * Ww, bias_len, 0, self.thd_neg, self.thd_pos, B * Hh * Ww, prologue)

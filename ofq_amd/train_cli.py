@@ -61,6 +61,12 @@ def build_parser(cga=False):
     p.add_argument('--aa', default=None, help='RandAugment runs in timm CPU workers on PIL images: not part of this path')
     p.add_argument('--no-graph', action='store_true',
                    help='launch every kernel from Python instead of replaying the captured hipGraph of the step')
+    p.add_argument('--sync-statsq', action='store_true',
+                   help='all-reduce the StatsQ scale vectors behind the last gradient bucket of every step and assert that it '
+                        'is a no-op (they are functions of replica-identical weights; the reference has no such collective)')
+    p.add_argument('--graph', action='store_true',
+                   help='capture the step in a hipGraph also when several ranks train together (the captured RCCL all-reduce '
+                        'has only been exercised with one rank: without this flag multi-rank runs launch eagerly, like bench.py)')
     # quantisation flags (train.py:297-366)
     p.add_argument('--quantized', action='store_true')
     p.add_argument('--wq-enable', action='store_true')
@@ -257,7 +263,7 @@ def main_worker(local_rank, args, cga, spawned):
         if "optimizer" in ck and not args.no_resume_opt:
             optimizer.load_state_dict(ck["optimizer"])
         start_epoch = ck.get("epoch", -1) + 1
-    dp = parallel.DataParallel(model) if world > 1 else None                                # train.py:727
+    dp = parallel.DataParallel(model, sync_statsq=args.sync_statsq) if world > 1 else None  # train.py:727
     kd_both = KDLossSoftandHard()
     kd_soft = KLLossSoft()
     # train.py:764-769: with mixup the smoothing is in the soft targets (SoftTargetCrossEntropy), else label smoothing
@@ -273,7 +279,8 @@ def main_worker(local_rank, args, cga, spawned):
     hooks = engine.CGAHooks(model, args.wq_bitw, args.boundaryRange, qk_reparam=qkr, model_type=args.model_type) if cga else None
     first, last = (args.epochs, args.epochs + args.freeze_for_n_epochs) if cga else (start_epoch, args.epochs + args.cooldown_epochs)
     graphed = None
-    if not args.no_graph and hasattr(optimizer, "advance_for_replay"):
+    multi_rank = dp is not None and getattr(dp, "world", 1) > 1
+    if not args.no_graph and hasattr(optimizer, "advance_for_replay") and (not multi_rank or args.graph):
         graphed = engine.GraphedTrainStep(model, optimizer, loss_fn, dp=dp, cga=hooks)
     no_soft = torch.zeros(args.batch_size, args.num_classes, device=dev)
     for epoch in range(first, last):                                                        # cga.py:760 / train.py:816

@@ -141,6 +141,136 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _SlotLinearFn(torch.autograd.Function):
+    """y = x @ W^T whose backward writes dW straight into the parameter's slice of its gradient bucket
+    (parallel.grad_slot), as functional.CodesLinearFn does."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        ctx.leaf = W
+        return x @ W.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from ofq_amd.parallel import grad_slot
+        x, W = ctx.saved_tensors
+        dW = g.t() @ x
+        slot = grad_slot(ctx.leaf)
+        if slot is not None:
+            slot.copy_(dW)
+            dW = slot
+        return g @ W, dW
+
+
+class _AllPairsFn(torch.autograd.Function):
+    """out_i = q_i^T k_i for every pair, ONE node: all 2n gradients arrive together at the end of backward
+    (functional.AllWqkFn)."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.save_for_backward(*ws)
+        return tuple(ws[2 * i].t() @ ws[2 * i + 1] for i in range(len(ws) // 2))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ws = ctx.saved_tensors
+        out = []
+        for i, g in enumerate(gs):
+            q, k = ws[2 * i], ws[2 * i + 1]
+            out += [k @ g.t(), q @ g]
+        return tuple(out)
+
+
+class _PairNet(nn.Module):
+    def __init__(self, n=6, d=8):
+        super().__init__()
+        self.qs = nn.ParameterList([nn.Parameter(torch.randn(4, d)) for _ in range(n)])
+        self.ks = nn.ParameterList([nn.Parameter(torch.randn(4, d)) for _ in range(n)])
+        self.lin = nn.ParameterList([nn.Parameter(torch.randn(d, d) * 0.3) for _ in range(n)])
+        self.tied = nn.Parameter(torch.randn(d, d) * 0.3)
+
+    def forward(self, x):
+        ws = []
+        for q, k in zip(self.qs, self.ks):
+            ws += [q, k]
+        wqk = _AllPairsFn.apply(*ws)
+        for i, W in enumerate(self.lin):
+            x = torch.tanh(_SlotLinearFn.apply(x, W) + x @ wqk[i])
+        # one leaf feeding two nodes of the same backward: only one of them may write the bucket slice
+        return _SlotLinearFn.apply(torch.tanh(_SlotLinearFn.apply(x, self.tied)), self.tied)
+
+
+def _worker_slots(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from ofq_amd.parallel import DataParallel
+    torch.manual_seed(5)
+    net = _PairNet()
+    ref_net = copy.deepcopy(net)
+    dp = DataParallel(net, bucket_mb=0.0005, sync_statsq=True)
+    dp.statsq_check_every = 1
+    torch.manual_seed(9)
+    X = torch.randn(8, 8)
+    xs = X[rank * 4:(rank + 1) * 4]
+    for step in range(3):
+        dp.zero_grad()
+        dp(xs).pow(2).mean().backward()
+        dp.finish_gradient_sync()
+        for p in ref_net.parameters():
+            p.grad = None
+        ref_net(X).pow(2).mean().backward()
+        for (n, p), (_, r) in zip(net.named_parameters(), ref_net.named_parameters()):
+            assert torch.allclose(p.grad, r.grad, rtol=1e-4, atol=2e-6), (step, n, float((p.grad - r.grad).abs().max()))
+        if step == 0:
+            # rebuilt in arrival order: the twelve q / k weights, which arrive from one node at the very end, sit together
+            # behind every linear layer's weight, each exactly once
+            assert dp._rebuilt
+            order = [id(p) for b in dp.buckets for p in b.params]
+            assert len(order) == len(set(order)) == len(list(net.parameters()))
+            late = {id(p) for p in list(net.qs) + list(net.ks)}
+            first_late = min(i for i, k in enumerate(order) if k in late)
+            assert all(k in late for k in order[first_late:]), "q / k gradients must be the tail of the bucket order"
+    # the StatsQ-scale all-reduce is a no-op while the replicas agree ...
+    class Holder(nn.Module):
+        pass
+    net.holder = Holder()
+    net.holder._s_dev = 2 * net.tied.detach().abs().mean(1)
+    dp._statsq_all_reduce()
+    assert dp.check_statsq_pending() == 0.0
+    # ... and raises when one rank's weights have drifted
+    net.holder._s_dev = net.holder._s_dev + (1e-3 if rank == 1 else 0.0)
+    dp.statsq_check_every = 10 ** 9
+    dp._statsq_all_reduce()
+    with pytest.raises(RuntimeError, match="StatsQ scales differ"):
+        dp.check_statsq_pending()
+    dp.release()
+    from ofq_amd import parallel as par
+    assert not any(id(p) in par._GRAD_SLOTS for p in net.parameters())
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_direct_write_slots_late_node_and_statsq_sync():
+    """grad_slot direct writes (functional.CodesLinearFn), a node that delivers many parameters' gradients at the very end of
+    backward (functional.AllWqkFn), a leaf feeding two nodes, and the optional StatsQ-scale all-reduce, world 2."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_slots, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
 def test_data_parallel_world2_gloo():
     world = 2
     port = _free_port()
