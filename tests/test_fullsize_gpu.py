@@ -126,7 +126,7 @@ def test_plain_attention_full_size_code_path_equals_fp32_gemm_path(ops, cfg):
     """BASELINE config 2 (DeiT-T W4A4, 256 images, plain QAttention, attention.py:67-105) at full size: the attention core
     on integer codes (int8 scores / P.V, bf16-split backward) is the same function as the fp32-MFMA GEMMs on the fake-quant
     values -- exact integer accumulation against fp32 accumulation.  The two paths' scores differ in the last bits (1e-5
-    of their scale, tools/debug_plain.py), so among the 3e7 softmax inputs of this size a handful land on the other side
+    of their scale), so among the 3e7 softmax inputs of this size a handful land on the other side
     of a rounding tie of the P quantiser and move one level (measured: relative L2 of the output 4e-4 at W4A4, 256 images):
     the comparison is norm-wise at BASELINE.json's 1e-3 and bounds the share of elements that differ visibly."""
     import copy

@@ -379,7 +379,7 @@ def test_train_cli_two_steps_save_resume_and_validate(tmp_path):
     # ... and they stay near the oracle's.  Only "near": the GPU sums |W| per row in fp64 (correctly rounded StatsQ scale),
     # torch-CPU in a vectorised fp32 cascade; the scales can differ by one ulp and a weight whose W / s lands within that
     # ulp of a rounding tie takes the neighbouring level (a fresh DeiT-T has about two such weights
-    # among 5.4 M, tools/debug_eval3.py), and twelve low-bit blocks amplify one flipped level to percents of the logits,
+    # among 5.4 M; tests/test_depth12_gpu.py measures the growth block by block), and twelve low-bit blocks amplify one flipped level to percents of the logits,
     # on either side.  Tie-free parity of the eval forward is pinned at 1e-3 by tests/test_modules_gpu.py (g7 eval_logits).
     dev_logits = float((own.cpu().double() - logits.double()).norm() / logits.double().norm())
     assert dev_logits < 0.5 and got["loss"] == pytest.approx(want_loss, rel=2e-2), (dev_logits, got["loss"], want_loss)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel-trace stats of the default bench -> gpurun_out/$1/kernel_stats.txt
 set -u
-TAG=${1:-r03_kt}
+TAG=${1:-kt}
 O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
