@@ -26,7 +26,7 @@ struct QSsArgs {
 // into 256 B of slack behind the tile.
 // CB = 4: 256-key panel, four waves side by side (DeiT); CB = 1: 64-key panel, 2 x 2 waves of one 32 x 32 block each -- the
 // 49-token Swin windows, where a 256-key panel would be three quarters padding (one window and head per workgroup).
-template <int QSS_SLD, int CB = 4>
+template <int QSS_SLD, int CB = 4, bool TAIL = false>
 __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   const QGemmArgs& p = q.g;
   constexpr int BM = 64, BN = 64 * CB;
@@ -94,16 +94,25 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   // ---- phase 2: softmax + LSQ (ofq_softmax_lsq_fwd's arithmetic).  16 lanes per row, 4 rows per wave at a time: lane l of
   // a group owns the float4 chunks l, l + 16, l + 32, l + 48 of its row (every store instruction covers 256 contiguous
   // bytes per row), the three row reductions are 16-lane butterflies, and four independent rows per wave keep the
-  // dependent chain max -> exp -> sum -> divide -> quantise fed
+  // dependent chain max -> exp -> sum -> divide -> quantise fed.
+  // TAIL (the 198-token DeiT rows, N <= 208): the fourth chunk would be columns 192..255, i.e. two busy lanes and fourteen
+  // that run 4 elements of padding each -- a quarter of this VALU-bound phase.  Instead lane l takes the ONE column
+  // 192 + l; its exponential is handed back to the lane that owned it in the chunk layout for the row sum, so the sum is
+  // formed in the same order and the probabilities stay bit-identical to ofq_softmax_lsq_fwd.  Row groups that lie entirely
+  // below the matrix (the fourth 64-row tile holds rows 192..197) are skipped.
+  constexpr int KF = TAIL ? KCH - 1 : KCH;                // full float4 chunks per lane
   const int n = p.N;
   const int lr = lane & 15, rg = lane >> 4;
   for (int it = 0; it < 4; ++it) {
+    if (m0 + wid * 16 + it * 4 >= p.M) continue;           // wave-uniform: none of the four rows exists
     const int mr = wid * 16 + it * 4 + rg;
     const bool rok = (m0 + mr) < p.M;
     const int64_t R = (int64_t)gby * p.M + min(m0 + mr, p.M - 1);      // row of the (B, H, N) x ld matrices
+    const int ct = 64 * KF + lr;                            // the tail column of this lane
     float t[KCH][4];
+    float tt = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < KF; ++k) {
       const int c0 = 4 * lr + 64 * k;
       const float4 vin = *reinterpret_cast<const float4*>(stile + mr * QSS_SLD + c0);
       float4 ain = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -118,19 +127,32 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
         }
       }
     }
-    float m = -INFINITY;
+    if (TAIL && ct < n) {
+      tt = __fmul_rn(stile[mr * QSS_SLD + ct], q.alpha);
+      if (q.addend) tt = __fadd_rn(tt, q.addend[(((R / q.S) % q.add_period) * q.S + (R % q.S)) * q.ld + ct]);
+    }
+    float m = TAIL ? tt : -INFINITY;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) m = fmaxf(m, fmaxf(fmaxf(t[k][0], t[k][1]), fmaxf(t[k][2], t[k][3])));
+    for (int k = 0; k < KF; ++k) m = fmaxf(m, fmaxf(fmaxf(t[k][0], t[k][1]), fmaxf(t[k][2], t[k][3])));
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k)
+    for (int k = 0; k < KF; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         t[k][e] = (4 * lr + 64 * k + e < n) ? expf(t[k][e] - m) : 0.f;
         sum += t[k][e];
       }
+    if (TAIL) {
+      tt = ct < n ? expf(tt - m) : 0.f;
+      // lane l < 4 owned columns 192 + 4 l .. + 3 in the chunk layout: their exponentials join its partial sum in that order
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = __shfl(tt, (lane & 48) + ((4 * lr + e) & 15), 64);
+        sum += lr < 4 ? v : 0.f;
+      }
+    }
     sum = ofq_group_sum<16>(sum);
     const float a = ofq_lsq_eff_scale(q.sm_s[R % q.S], q.sm_gscale);
     // p = e / sum and the level rint(clamp(p / a)) without the per-element IEEE division sequences: one exact reciprocal of
@@ -140,22 +162,28 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
     const float half_m_tol = 0.5f - ofq_lsq_level_tol(0.f, q.hi);
     float qsum = 0.f;
     float pr[KCH][4], qq[KCH][4];
+    float prt = 0.f, qqt = 0.f;
     bool risky = false;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k)
+    for (int k = 0; k < KF; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pr[k][e] = ofq_div_by_rcp(t[k][e], sum, rsum);
         qq[k][e] = ofq_lsq_level_rcp(pr[k][e], ra, 0.f, q.hi, half_m_tol, risky);
       }
+    if (TAIL) {
+      prt = ofq_div_by_rcp(tt, sum, rsum);
+      qqt = ofq_lsq_level_rcp(prt, ra, 0.f, q.hi, half_m_tol, risky);
+    }
     if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
 #pragma unroll
-      for (int k = 0; k < KCH; ++k)
+      for (int k = 0; k < KF; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) qq[k][e] = ofq_lsq_level_exact(pr[k][e], a, 0.f, q.hi);
+      if (TAIL) qqt = ofq_lsq_level_exact(prt, a, 0.f, q.hi);
     }
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < KF; ++k) {
       const int c0 = 4 * lr + 64 * k;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -166,6 +194,14 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
         *reinterpret_cast<float4*>(q.prob + R * q.ld + c0) = make_float4(pr[k][0], pr[k][1], pr[k][2], pr[k][3]);
         *reinterpret_cast<uchar4*>(q.codes + R * q.ld + c0) = make_uchar4((unsigned char)(int)qq[k][0], (unsigned char)(int)qq[k][1],
                                                                             (unsigned char)(int)qq[k][2], (unsigned char)(int)qq[k][3]);
+      }
+    }
+    if (TAIL) {
+      if (ct >= n) { prt = 0.f; qqt = 0.f; }
+      qsum += qqt;
+      if (rok && ct < q.ld) {
+        q.prob[R * q.ld + ct] = prt;
+        q.codes[R * q.ld + ct] = (unsigned char)(int)qqt;
       }
     }
     qsum = ofq_group_sum<16>(qsum);
@@ -198,6 +234,8 @@ extern "C" int ofq_qattn_scores_softmax_i8(const int8_t* acodes, const int8_t* b
   q.add_period = addend ? add_period : 1; q.S = (int)N; q.sm_gscale = sm_gscale; q.alpha = alpha; q.hi = (float)hi;
   if (N <= 64 && ld <= 64)          // Swin windows: one (window, head) per workgroup, 64-key panel (S tile rows of 68 floats)
     hipLaunchKernelGGL((qattn_scores_softmax_kernel<68, 1>), dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);
+  else if (N <= 200 && ld <= 208)     // (DeiT: 198 tokens, ld 208) three full chunks + a one-column tail per lane
+    hipLaunchKernelGGL((qattn_scores_softmax_kernel<200, 4, true>), dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);
   else if (N <= 200)
     hipLaunchKernelGGL(qattn_scores_softmax_kernel<200>, dim3((unsigned)a.tiles_m, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q);
   else
@@ -227,9 +265,12 @@ struct QDpArgs {
   float gscale_v, sm_gscale, alpha, hi;
 };
 
-template <int QSS_SLD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
+template <int QSS_SLD, bool TAIL = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QSS_SLD <= 200 ? 3 : 2, QSS_SLD <= 200 ? 3 : 2)))
+void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
   constexpr int BM = 64, BN = 256, NS = 3, KCH = 4;
+  constexpr int KF = TAIL ? KCH - 1 : KCH;                // full float4 chunks per lane; TAIL: + the one column 192 + lane
+                                                          // (see qattn_scores_softmax_kernel)
   constexpr int PLANE = BM * QBS_LD;                      // one bf16 plane of the dO tile: 64 rows x 32 k (+ pad)
   constexpr int STAGE = NS * PLANE + BN * QBS_LD;
   constexpr int TILE_BYTES = BM * QSS_SLD * 4 + 256;
@@ -251,17 +292,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // the saved probabilities of this thread's phase-2 rows are requested first: they arrive under phase 1
   const int lr = lane & 15, rg = lane >> 4;
-  float4 pin[4][KCH];
+  float4 pin[4][KF];
+  float pint[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ct = 64 * KF + lr;                             // this lane's tail column
   auto load_prob = [&](auto IT0) {                        // rows IT0, IT0 + 1 of this thread's four phase-2 rows
     constexpr int it0 = decltype(IT0)::value;
 #pragma unroll
     for (int it = it0; it < it0 + 2; ++it) {
       const int64_t R = (int64_t)gby * N + min(m0 + wn * 16 + it * 4 + rg, N - 1);
 #pragma unroll
-      for (int k = 0; k < KCH; ++k) {
+      for (int k = 0; k < KF; ++k) {
         const int c0 = 4 * lr + 64 * k;
         pin[it][k] = *reinterpret_cast<const float4*>(q.prob + R * q.ld + (c0 < q.ld ? c0 : 0));
       }
+      if (TAIL) pint[it] = q.prob[R * q.ld + (ct < q.ld ? ct : 0)];
     }
   };
   load_prob(std::integral_constant<int, 0>());            // (the other two rows once the accumulators are out of the way)
@@ -378,21 +422,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const float hi_m_tol = q.hi - tol, hi_p_tol = q.hi + tol;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
+    if (m0 + wn * 16 + it * 4 >= N) continue;              // wave-uniform: none of the four rows exists
     const int mr = wn * 16 + it * 4 + rg;
     const bool rok = (m0 + mr) < N;
     const int row = min(m0 + mr, N - 1);
     const int64_t R = (int64_t)gby * N + row;
     const float a = ofq_lsq_eff_scale(q.sm_s[row], q.sm_gscale);          // S == N: the step of query token `row`
     const float ra = __fdiv_rn(1.f, a);
-    float p[KCH][4], dq[KCH][4];
+    constexpr int NE = 4 * KF + (TAIL ? 1 : 0);
+    float p[NE], g[NE], dq[NE];
     float rowds = 0.f, dot = 0.f;
     bool risky = false;
-    // ofq_lsq_bwd_fast specialised for an unsigned quantiser on a non-negative input (a probability): v = p * ra >= 0 = lo
-    // holds exactly, in the division form as well, so closeness to the LOWER edge decides nothing (the generic routine
-    // flags it -- and a softmax row is full of probabilities below 1e-6 and of padding zeros: every group would take the
-    // exact redo).  Elements of column chunks that lie inside the matrix for every lane skip the padding masks.
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < KF; ++k) {
       const int c0 = 4 * lr + 64 * k;
       const float4 gin = *reinterpret_cast<const float4*>(stile + mr * QSS_SLD + c0);
       const float pp[4] = {pin[it][k].x, pin[it][k].y, pin[it][k].z, pin[it][k].w}, gg[4] = {gin.x, gin.y, gin.z, gin.w};
@@ -400,41 +442,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool in = full || (c0 + e) < N;
-        const float pe = in ? pp[e] : 0.f, ge = in ? gg[e] : 0.f;
-        const float v = __fmul_rn(pe, ra);
-        const float u = fminf(v, q.hi);
-        const float qq = rintf(u);
-        const bool inr = v <= q.hi;
-        bool rk = !(fabsf(__fsub_rn(u, qq)) < half_m_tol) | ((v > hi_m_tol) & (v < hi_p_tol));
-        const float t = __fmul_rn(ge, a);
-        float d0 = __fmul_rn(t, ra);
-        d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
-        d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
-        const float at = fabsf(t);
-        rk |= (at != 0.f) & !((at > 7.8886090522e-31f) & (at < 1.2676506002e30f));
-        risky |= rk;
-        p[k][e] = pe;
-        dq[k][e] = inr ? d0 : 0.f;
-        rowds += ge * (inr ? (qq - v) : qq);
-        dot += dq[k][e] * pe;
+        p[4 * k + e] = in ? pp[e] : 0.f;
+        g[4 * k + e] = in ? gg[e] : 0.f;
       }
+    }
+    if (TAIL) {
+      const bool in = ct < N;
+      p[NE - 1] = in ? pint[it] : 0.f;
+      g[NE - 1] = in ? stile[mr * QSS_SLD + ct] : 0.f;
+    }
+    // ofq_lsq_bwd_fast specialised for an unsigned quantiser on a non-negative input (a probability): v = p * ra >= 0 = lo
+    // holds exactly, in the division form as well, so closeness to the LOWER edge decides nothing (the generic routine
+    // flags it -- and a softmax row is full of probabilities below 1e-6 and of padding zeros: every group would take the
+    // exact redo)
+#pragma unroll
+    for (int x = 0; x < NE; ++x) {
+      const float v = __fmul_rn(p[x], ra);
+      const float u = fminf(v, q.hi);
+      const float qq = rintf(u);
+      const bool inr = v <= q.hi;
+      bool rk = !(fabsf(__fsub_rn(u, qq)) < half_m_tol) | ((v > hi_m_tol) & (v < hi_p_tol));
+      const float t = __fmul_rn(g[x], a);
+      float d0 = __fmul_rn(t, ra);
+      d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
+      d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
+      const float at = fabsf(t);
+      rk |= (at != 0.f) & !((at > 7.8886090522e-31f) & (at < 1.2676506002e30f));
+      risky |= rk;
+      dq[x] = inr ? d0 : 0.f;
+      rowds += g[x] * (inr ? (qq - v) : qq);
+      dot += dq[x] * p[x];
     }
     if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {       // rare: a value next to a rounding tie / the upper edge
       rowds = 0.f;
       dot = 0.f;
 #pragma unroll
-      for (int k = 0; k < KCH; ++k) {
-        const int c0 = 4 * lr + 64 * k;
-        const float4 gin = *reinterpret_cast<const float4*>(stile + mr * QSS_SLD + c0);
-        const float gg[4] = {gin.x, gin.y, gin.z, gin.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float ge = (c0 + e) < N ? gg[e] : 0.f;
-          float dsc;
-          ofq_lsq_bwd_exact(p[k][e], ge, a, 0.f, q.hi, dq[k][e], dsc);
-          rowds += dsc;
-          dot += dq[k][e] * p[k][e];
-        }
+      for (int x = 0; x < NE; ++x) {
+        float dsc;
+        ofq_lsq_bwd_exact(p[x], g[x], a, 0.f, q.hi, dq[x], dsc);
+        rowds += dsc;
+        dot += dq[x] * p[x];
       }
     }
     rowds = ofq_group_sum<16>(rowds);
@@ -442,15 +489,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (lr == 0 && rok) q.rowpart[R] = rowds;
     float rsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < KCH; ++k) {
+    for (int k = 0; k < KF; ++k) {
       const int c0 = 4 * lr + 64 * k;
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (dq[k][e] - dot) * p[k][e] * q.alpha;        // (padding columns: p = 0)
+        o[e] = (dq[4 * k + e] - dot) * p[4 * k + e] * q.alpha;              // (padding columns: p = 0)
         rsum += o[e];
       }
       if (rok && c0 < q.ld) *reinterpret_cast<float4*>(q.dS + R * q.ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (TAIL) {
+      const float o = (dq[NE - 1] - dot) * p[NE - 1] * q.alpha;
+      rsum += o;
+      if (rok && ct < q.ld) q.dS[R * q.ld + ct] = o;
     }
     if (q.ds_rowsum) {
       rsum = ofq_group_sum<16>(rsum);
@@ -482,7 +534,8 @@ extern "C" int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, c
   q.gscale_v = gscale_v; q.sm_gscale = sm_gscale; q.alpha = alpha; q.hi = (float)hi;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
-  if (N <= 200) hipLaunchKernelGGL(qattn_dp_softmax_bwd_kernel<200>, grid, dim3(256), 0, st, q);     // 51 KB: three per CU
+  if (N <= 200 && ld <= 208) hipLaunchKernelGGL((qattn_dp_softmax_bwd_kernel<200, true>), grid, dim3(256), 0, st, q);
+  else if (N <= 200) hipLaunchKernelGGL(qattn_dp_softmax_bwd_kernel<200>, grid, dim3(256), 0, st, q);     // 51 KB: three per CU
   else hipLaunchKernelGGL(qattn_dp_softmax_bwd_kernel<260>, grid, dim3(256), 0, st, q);
   OFQ_LAUNCH_CHECK();
   if (ds) {
