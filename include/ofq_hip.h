@@ -266,9 +266,11 @@ int ofq_codes_transpose_i8(const int8_t* in, int8_t* out, int64_t batches, int64
 /*  The three operand-preparation jobs of the QKR attention core (attention.py:207-219 on the codes) in one launch:
  *  u[b][n][h] = xcodes[b][n][:] . baq[h][:], tq[b][m][h] = qcodes[b][m][h][:] . bax[:], vT[b][c][Np] = transpose of
  *  vcodes[b][N][c] (zero-padded to Np).  Same values as ofq_rowdot_i8_multi / ofq_rowdot_i8 / ofq_codes_transpose_i8.
+ *  z (optional, [H]): z[h] = baq[h][:] . bax[:], the offset-offset term of the scores, by one extra workgroup.
  *  C % 16 == 0, C <= 512, Np % 4 == 0, 16-byte aligned operands. */
 int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, const int8_t* qcodes, const float* bax, float* tq,
-                   const int8_t* vcodes, int8_t* vT, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np, ofq_stream_t stream);
+                   const int8_t* vcodes, int8_t* vT, float* z, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np,
+                   ofq_stream_t stream);
 
 
 /* ---- column sum (bias gradients of F.linear: autograd of qlinear.py:71):  out[c] = sum_r x[r][c] */

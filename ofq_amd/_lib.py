@@ -78,7 +78,7 @@ SIGNATURES = {
     "ofq_rowdot_i8_multi": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "ofq_rowdot_f32_seg": (i32, [vp, vp, vp, i64, i32, i32, i64, vp]),
     "ofq_codes_transpose_i8": (i32, [vp, vp, i64, i64, i64, i64, vp]),
-    "ofq_qattn_prep": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_prep": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_colsum_ws_bytes": (sz, [i64, i64]),
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
     "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp]),

@@ -3159,7 +3159,34 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   }
 
   if constexpr (!LSQ) {
-    if (!p.accumulate) {
+    // interior tiles (every tile of the DeiT shapes): uniform tile base + one 32-bit lane offset per access, no
+    // per-element bounds checks (each one is an exec-mask branch around a single store)
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
+    if (interior) {
+      float* Cs = p.C + (int64_t)m0 * p.ldc + n0;
+      const int ldc = (int)p.ldc;
+      const int nl0 = wn * 32 * NJ + l31;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int eb = 0; eb < 4; ++eb) {
+          const int mlb = (wm * 64 + i * 32 + 8 * eb + 4 * lh) * ldc + nl0;
+          float old[4][NJ];
+          if (p.accumulate) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) old[ee][j] = Cs[mlb + ee * ldc + j * 32];
+          }
+#pragma unroll
+          for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const float v = acc[i][j][eb * 4 + ee] * p.alpha;
+              Cs[mlb + ee * ldc + j * 32] = p.accumulate ? v + old[ee][j] : v;
+            }
+        }
+    } else if (!p.accumulate) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * 32 * NJ + j * 32 + l31;
@@ -3564,7 +3591,8 @@ struct AttnPrepArgs {
   const int8_t* xcodes; const float* baq; float* u;          // job 0: [R0 = B*N][C] . [H][C] -> [R0][H]
   const int8_t* qcodes; const float* bax; float* tq;         // job 1: [R1 = B*N*H][C] . [C] -> [R1]
   const int8_t* vcodes; int8_t* vT;                          // job 2: [B][N][C] -> [B][C][Np]
-  int R0, R1, C, H, N, Np, nb0, nb1, tx2, ty2;               // nb0 / nb1: blocks of job 0 / 1; job 2 grid: tx2 x ty2 x B
+  float* z;                                                  // job 3 (one block, optional): z[h] = baq[h][:] . bax
+  int R0, R1, C, H, N, Np, nb0, nb1, tx2, ty2, nb2;          // nb0 / nb1 / nb2: blocks of jobs 0 / 1 / 2; job 2 grid: tx2 x ty2 x B
 };
 __global__ __launch_bounds__(256) void qattn_prep_kernel(AttnPrepArgs a) {
   __shared__ __attribute__((aligned(16))) int8_t tile[32][36];
@@ -3574,11 +3602,21 @@ __global__ __launch_bounds__(256) void qattn_prep_kernel(AttnPrepArgs a) {
   b -= a.nb0;
   if (b < a.nb1) { rowdot_i8_v16_body(b, a.qcodes, a.bax, a.tq, a.R1, a.C); return; }
   b -= a.nb1;
+  if (b >= a.nb2) {          // the offset-offset term of the scores (attention.py:206-210: move_qkx_aft . move_aft of x), one wave per head
+    const int lane = threadIdx.x & 63;
+    for (int h = threadIdx.x >> 6; h < a.H; h += 4) {
+      float acc = 0.f;
+      for (int c = lane; c < a.C; c += 64) acc += a.baq[h * a.C + c] * a.bax[c];
+      acc = ofq_wave_sum(acc);
+      if (lane == 0) a.z[h] = acc;
+    }
+    return;
+  }
   const int bx = b % a.tx2, by = (b / a.tx2) % a.ty2, bz = b / (a.tx2 * a.ty2);
   codes_transpose_i8_body(bx, by, bz, tile, a.vcodes, a.vT, a.N, a.C, a.Np);
 }
 extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, const int8_t* qcodes, const float* bax, float* tq,
-                              const int8_t* vcodes, int8_t* vT, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np,
+                              const int8_t* vcodes, int8_t* vT, float* z, int64_t B, int64_t H, int64_t N, int64_t C, int64_t Np,
                               ofq_stream_t stream) {
   if (!xcodes || !baq || !u || !qcodes || !bax || !tq || !vcodes || !vT || B <= 0 || H <= 0 || N <= 0 || Np < N) return OFQ_EINVAL;
   if ((C & 15) || (Np & 3) || C > 512 || !al16(xcodes) || !al16(qcodes) || !al16(baq) || !al16(bax) || !al16(vcodes) || !al16(vT) ||
@@ -3589,7 +3627,10 @@ extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, 
   a.R0 = (int)(B * N); a.R1 = (int)(B * N * H); a.C = (int)C; a.H = (int)H; a.N = (int)N; a.Np = (int)Np;
   a.nb0 = (int)ceil_div(B * N, 16); a.nb1 = (int)ceil_div(B * N * H, 16 * RD16_RPG);
   a.tx2 = (int)ceil_div(C, 32); a.ty2 = (int)ceil_div(Np, 32);
-  const int64_t total = (int64_t)a.nb0 + a.nb1 + (int64_t)a.tx2 * a.ty2 * B;
+  a.z = z;
+  if ((int64_t)a.tx2 * a.ty2 * B >= (1ll << 31)) return OFQ_EINVAL;
+  a.nb2 = (int)((int64_t)a.tx2 * a.ty2 * B);
+  const int64_t total = (int64_t)a.nb0 + a.nb1 + a.nb2 + (z ? 1 : 0);
   if (total >= (1ll << 31)) return OFQ_EINVAL;
   hipLaunchKernelGGL(qattn_prep_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();

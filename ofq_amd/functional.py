@@ -680,12 +680,12 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
             vlink = aux.get("vlink")
             if ATTN_PREP and vlink is not None and C <= 512 and baq2.is_contiguous() and aux["bax"].is_contiguous():
                 # u, tq and the transposed v codes (for the P.V GEMM that follows) in one launch
-                u, tq, vlink["vT"] = ops.qattn_prep(aux["xcodes"], baq2, aux["qcodes"], aux["bax"], vlink["vcodes"], B, H, N, C,
-                                                    pad16(N))
+                u, tq, vlink["vT"], z = ops.qattn_prep(aux["xcodes"], baq2, aux["qcodes"], aux["bax"], vlink["vcodes"], B, H, N,
+                                                       C, pad16(N))
             else:
                 u = ops.rowdot_i8_multi(aux["xcodes"].view(B * N, C), baq2)
                 tq = ops.rowdot_i8(aux["qcodes"].view(B * N * H, C), aux["bax"])
-            z = torch.mv(baq2, aux["bax"])
+                z = torch.mv(baq2, aux["bax"])
             ac, bc, sa, ga, sb, gb = aux["xcodes"], aux["qcodes"], aux["sx"], aux["gx"], aux["sq"], aux["gq"]
         Np = pad16(N)
         prob, codes, rsum = ops.qattn_scores_softmax(ac, bc, sa, ga, sb, gb, u, tq, z, plain, s, aux["alpha"], aux["hi"],

@@ -532,9 +532,10 @@ def qattn_prep(xcodes, baq2, qcodes, bax, vcodes, B, H, N, C, Np):
     u = torch.empty((B * N, H), dtype=torch.float32, device=dev)
     tq = torch.empty(B * N * H, dtype=torch.float32, device=dev)
     vT = torch.empty((B, C, Np), dtype=torch.int8, device=dev)
+    z = torch.empty(H, dtype=torch.float32, device=dev)              # z[h] = baq[h] . bax (was a torch.mv per block)
     _chk(lib().ofq_qattn_prep(xcodes.data_ptr(), baq2.data_ptr(), u.data_ptr(), qcodes.data_ptr(), bax.data_ptr(), tq.data_ptr(),
-                              vcodes.data_ptr(), vT.data_ptr(), B, H, N, C, Np, _stream()), "ofq_qattn_prep")
-    return u, tq, vT
+                              vcodes.data_ptr(), vT.data_ptr(), z.data_ptr(), B, H, N, C, Np, _stream()), "ofq_qattn_prep")
+    return u, tq, vT, z
 
 
 def qattn_scores(xcodes, qcodes, sx, gx, sq, gq, u, tq, z, B, H, N, C, ldS):

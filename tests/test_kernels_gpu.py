@@ -968,7 +968,8 @@ def test_attention_prep_launch_equals_the_three_kernels(ops):
     baq = torch.randn(H, C, device="cuda", generator=g)
     bax = torch.randn(C, device="cuda", generator=g)
     Np = pad16(N)
-    u, tq, vT = ops.qattn_prep(xc, baq, qc, bax, vc, B, H, N, C, Np)
+    u, tq, vT, z = ops.qattn_prep(xc, baq, qc, bax, vc, B, H, N, C, Np)
+    assert rel_err(z.cpu(), (baq.double() @ bax.double()).float().cpu()) < 1e-6          # z[h] = baq[h] . bax
     assert torch.equal(u, ops.rowdot_i8_multi(xc.view(B * N, C), baq))
     assert torch.equal(tq, ops.rowdot_i8(qc.view(B * N * H, C), bax))
     assert torch.equal(vT, ops.codes_transpose_i8(vc, Np))
