@@ -11,8 +11,12 @@ forward + KDLossSoftandHard + backward (+ bucketed RCCL all-reduce for N > 1) + 
 is captured once in a hipGraph (engine.GraphedTrainStep) and replayed -- every kernel of every timed step runs.
 
 Prints ONE JSON line on rank 0, with two extra objects:
-  roofline      — the dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs per launch / HIP-event time per launch,
-                  both measured live over the timed steps, against the 157.3 TFLOP/s fp32 MFMA peak
+  roofline      — the dominant matrix-core kernel class by time (at 128 images: qgemm_bf16s_nt_wide_kernel, the dX GEMM of
+                  the linear layers on 3 bf16 planes): algorithmic 2*M*N*K per launch / HIP-event time per launch, both
+                  measured live over a second pass of the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak
+                  (`frac`); every algorithmic FMA of the split kernels is three bf16 MFMA FMAs, so the matrix pipe is busy
+                  3x that fraction (`mfma_pipe_frac`); `mfma_util_pmc` / `traffic` come from the committed rocprofv3 PMC
+                  passes of the same kernel sources (profiles/r03_traffic.json)
   cpu_baseline  — oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path) timed on this box's
                   host cores on a bounded sample (DeiT-S W2A2 QKR, batch 8, a few steps), rank 0 at N = 1 only
 """
@@ -31,7 +35,9 @@ sys.path.insert(0, ROOT)
 PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
          "qgemm_bf16s": 2500.0,    # Peak BF16 MFMA dense; the fp32-exact product issues 3 bf16 MFMAs per algorithmic FMA
          "qgemm_i8": 5000.0,       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
-         "qattn_scores_softmax": 5000.0}   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
+         "qattn_scores_softmax": 5000.0,   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
+         "qattn_dp_softmax_bwd": 2500.0}   # (fused dP GEMM + softmax backward: VALU / HBM-bound)
+PROFILE_JSON = "r03_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
 
 
 def parse():
@@ -354,21 +360,25 @@ def main():
             achieved = sm["total_units"] / (sm["total_ms"] * 1e-3) / 1e12 if sm["total_ms"] > 0 else 0.0
             # HBM bytes per launch of this kernel class from the committed PMC passes -- only if they were taken on THESE
             # kernels (content hash of csrc/ + the header, ofq_amd/build.py); stale counters are not reported
-            traffic, traffic_note = None, "no profiles/r02_traffic.json"
+            traffic, mfma_util, traffic_note = None, None, "no profiles/" + PROFILE_JSON
             try:
                 from ofq_amd import build as _build
-                with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", PROFILE_JSON)) as fh:
                     tj = json.load(fh)
                 if tj.get("source_hash") == _build.source_hash():
                     traffic = tj.get(name.split(" ")[0], {}).get("traffic_bytes_per_launch")
-                    traffic_note = "profiles/r02_traffic.json (kernel sources %s)" % tj.get("source_hash")
+                    mfma_util = tj.get(name.split(" ")[0], {}).get("mfma_util_pmc")
+                    traffic_note = "profiles/%s (kernel sources %s)" % (PROFILE_JSON, tj.get("source_hash"))
                 else:
-                    traffic_note = ("profiles/r02_traffic.json was measured on kernel sources %s, this library is %s: not reported"
-                                    % (tj.get("source_hash"), _build.source_hash()))
+                    traffic_note = ("profiles/%s was measured on kernel sources %s, this library is %s: not reported"
+                                    % (PROFILE_JSON, tj.get("source_hash"), _build.source_hash()))
             except (OSError, ValueError):
                 pass
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    # the bf16-split kernels issue three bf16 MFMA FMAs per algorithmic FMA (what makes them fp32-exact)
+                    "mfma_pipe_frac": round((3.0 if name.startswith("qgemm_bf16s") else 1.0) * achieved / peak, 4),
+                    "mfma_util_pmc": mfma_util,
                     "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over a second, "
                             "instrumented pass of the same --steps steps (the throughput pass carries no events: they cost "
                             "2-4 ms/step); for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "

@@ -390,7 +390,7 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     N = B_bf16.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+    with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
                                       nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),
              "ofq_qgemm_bf16s_nt")
@@ -409,7 +409,7 @@ def qgemm_bf16s_nt_lsq(dy2d, B_bf16, k_scale, alpha, x2d, s, b4, g, want_bias_gr
     db4 = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     ws = workspace(lib().ofq_qgemm_bf16s_nt_lsq_ws_bytes(M, N), dev)
-    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+    with _Timed('qgemm_bf16s_nt_wide_lsq (linear dX + LSQ backward epilogue)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt_lsq(dy2d.data_ptr(), B_bf16.data_ptr(), _p(k_scale), alpha, x2d.data_ptr(), s.data_ptr(),
                                           g.S, g.gscale, _p(b4), g.lo, g.hi, int(g.prologue == 1), dx.data_ptr(), ds.data_ptr(),
                                           _p(db4), _p(dbaft), M, N, K, dy2d.stride(0), B_bf16.stride(0), x2d.stride(0),
@@ -436,7 +436,7 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     if compute_db:
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
-    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * Ktok * M * N):
+    with _Timed('qgemm_bf16s_tn_wide (linear dW, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * Ktok * M * N):
         _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
                                       _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
                                       split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
@@ -488,7 +488,7 @@ def qgemm_bf16s_tn_group(jobs, split=None):
         split = max(1, min(256 // tiles, nkt // 4))
     dev = jobs[0]["dy2d"].device
     ws = workspace(lib().ofq_qgemm_bf16s_tn_group_ws_bytes(arr, n, split), dev)
-    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', flops):
+    with _Timed('qgemm_bf16s_tn_wide_group (linear dW of a block, 3x v_mfma_f32_32x32x16_bf16)', flops):
         _chk(lib().ofq_qgemm_bf16s_tn_group(arr, n, split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn_group")
 
 
@@ -600,7 +600,7 @@ def qattn_dp(dO, vcodes, sv, gv, w, B, H, N, d, ldP):
     """dP[b,h,n,m] = sum_j dO[b,n,hd+j] * (av_eff[hd+j] * qv[b,m,hd+j]) + w[b,n,h]; av_eff = effective value of the step sv
     (taken inside the kernel when gv > 0; gv = 0: sv is used as is)"""
     dP = torch.empty((B, H, N, ldP), dtype=torch.float32, device=dO.device)
-    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+    with _Timed('qgemm_bf16s_nt (attention dP, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
         _chk(lib().ofq_qattn_dp_bf16s(dO.data_ptr(), vcodes.data_ptr(), dP.data_ptr(), sv.data_ptr(), float(gv), _p(w), B, H, N,
                                       d, ldP, _stream()), "ofq_qattn_dp_bf16s")
     return dP
@@ -614,7 +614,7 @@ def qattn_dp_softmax_bwd(dO, vcodes, sv, gv, bav, prob, sm_s, alpha, hi, B, H, N
     rs = torch.empty(B * H * N, dtype=torch.float32, device=dO.device) if want_rowsum else None
     gscale = 1.0 / math.sqrt(hi * (B * H * N))
     ws = workspace(lib().ofq_qattn_dp_softmax_bwd_ws_bytes(B, H, N), dO.device)
-    with _Timed('qgemm_bf16s_nt (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+    with _Timed('qattn_dp_softmax_bwd (dP GEMM + softmax-LSQ backward)', 2.0 * B * H * N * N * d):
         _chk(lib().ofq_qattn_dp_softmax_bwd(dO.data_ptr(), vcodes.data_ptr(), sv.data_ptr(), float(gv), _p(bav), prob.data_ptr(),
                                             sm_s.data_ptr(), gscale, float(alpha), int(hi), dS.data_ptr(), ds.data_ptr(), _p(rs),
                                             B, H, N, d, ld, ws.data_ptr(), ws.numel(), _stream()), "ofq_qattn_dp_softmax_bwd")
@@ -623,7 +623,7 @@ def qattn_dp_softmax_bwd(dO, vcodes, sv, gv, bav, prob, sm_s, alpha, hi, B, H, N
 
 def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
     dV = torch.empty((B, N, H * d), dtype=torch.float32, device=dO.device)
-    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
+    with _Timed('qgemm_bf16s_tn (attention dV, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * d):
         _chk(lib().ofq_qattn_dv_bf16s(dO.data_ptr(), pcodes.data_ptr(), dV.data_ptr(), sp.data_ptr(), gp, B, H, N, d, Np,
                                       _stream()), "ofq_qattn_dv_bf16s")
     return dV
@@ -631,7 +631,7 @@ def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
 
 def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS):
     dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
-    with _Timed('qgemm_bf16s_tn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+    with _Timed('qgemm_bf16s_tn_wide_stream (attention dqkx, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
                                         ldS, _stream()), "ofq_qattn_dqkx_bf16s")
     return dq
@@ -640,7 +640,7 @@ def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS):
 def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False):
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
-    with _Timed('qgemm_bf16s_nn (3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+    with _Timed('qgemm_bf16s_nn_wide (attention dxq, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
                                        H, N, C, ldS, _stream()), "ofq_qattn_dxq_bf16s")
     return out

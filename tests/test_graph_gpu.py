@@ -486,7 +486,10 @@ def test_bench_line_contract():
     roof = d["roofline"]
     # (which class dominates depends on the batch: at 128 images the dW GEMM, at 16 any of the GEMM classes)
     assert roof["kernel"].split(" ")[0] in ("qgemm_bf16s_tn", "qgemm_bf16s_nt", "qgemm_bf16s_nn", "qgemm_i8_nt", "gemm_f32",
-                                             "qgemm_i8_lsqbwd", "qattn_scores_softmax")
+                                             "qgemm_i8_lsqbwd", "qattn_scores_softmax", "qgemm_bf16s_nt_wide",
+                                             "qgemm_bf16s_tn_wide", "qgemm_bf16s_tn_wide_group", "qgemm_bf16s_tn_wide_stream",
+                                             "qgemm_bf16s_nn_wide", "qattn_dp_softmax_bwd")
+    assert "mfma_pipe_frac" in roof and roof["mfma_pipe_frac"] >= roof["frac"] - 1e-6
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac"] < 1
     cb = d["cpu_baseline"]

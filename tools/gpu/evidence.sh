@@ -22,6 +22,6 @@ grep -h '"metric"' $O/kt.log | tail -1 > $O/bench_under_kernel_trace.json
 python tools/pmc_summary.py $(db pf) > $O/pmc_fetch_size.txt
 python tools/pmc_summary.py $(db pw) > $O/pmc_write_size.txt
 python tools/pmc_mfma.py $(db pm) > $O/pmc_mfma_util.txt; head -12 $O/pmc_mfma_util.txt | cut -c1-160
-python tools/make_traffic.py $(db pf) $(db pw) 4.3 $O/traffic.json $(db pf6) $(db pw6) 3     # 1 warm-up + 3 timed steps + the setup_alpha forward; the 6-step passes give the steady-state step
+python tools/make_traffic.py $(db pf) $(db pw) 4.3 $O/traffic.json $(db pf6) $(db pw6) 3 $(db pm)     # 1 warm-up + 3 timed steps + the setup_alpha forward; the 6-step passes give the steady-state step
 find $O -name "*.db" -delete
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-400 $O/bench_default.json

@@ -13,13 +13,34 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CLASSES = [("qgemm_bf16s_tn", ("qgemm_bf16s_tn_wide_kernel", "qgemm_bf16s_tn_kernel")),
-           ("qgemm_bf16s_nt", ("qgemm_bf16s_nt_wide_kernel", "qgemm_bf16s_nt_kernel")),
-           ("qgemm_bf16s_nn", ("qgemm_bf16s_nn_wide_kernel", "qgemm_bf16s_nn_kernel")),
+# bench.py's timer classes (first word of the ops._Timed name) -> the kernel(s) behind them
+CLASSES = [("qgemm_bf16s_nt_wide", ("qgemm_bf16s_nt_wide_kernel",)),
+           ("qgemm_bf16s_tn_wide_group", ("qgemm_bf16s_tn_wide_group_kernel",)),
+           ("qgemm_bf16s_tn_wide_stream", ("qgemm_bf16s_tn_wide_stream_kernel",)),
+           ("qgemm_bf16s_tn_wide", ("qgemm_bf16s_tn_wide_kernel",)),
+           ("qgemm_bf16s_nn_wide", ("qgemm_bf16s_nn_wide_kernel",)),
+           ("qgemm_bf16s_tn", ("qgemm_bf16s_tn_kernel",)),
+           ("qgemm_bf16s_nt", ("qgemm_bf16s_nt_kernel",)),
+           ("qgemm_bf16s_nn", ("qgemm_bf16s_nn_kernel",)),
            ("qgemm_i8_nt", ("qgemm_i8_nt_kernel",)),
            ("qgemm_i8_lsqbwd", ("qgemm_i8_lsqbwd_kernel",)),
            ("qattn_scores_softmax", ("qattn_scores_softmax_kernel",)),
+           ("qattn_dp_softmax_bwd", ("qattn_dp_softmax_bwd_kernel",)),
            ("gemm_f32", ("gemm_f32_fast_kernel", "gemm_f32_kernel"))]
+
+
+def mfma_util(path):
+    """kernel name -> MfmaUtil % of a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...` pass (tools/pmc_mfma.py's formula
+    and calibration: raw = 100 * busy / (GRBM_GUI_ACTIVE * 1024 SIMDs), the back-to-back MFMA probe reads raw = 11.6)."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c and "name" in c][0]
+    ccol = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
+    vcol = "value" if "value" in cols else [c for c in cols if "value" in c][0]
+    d = {}
+    for k, c, sm in cur.execute("select %s, %s, sum(%s) from counters_collection group by %s, %s" % (kcol, ccol, vcol, kcol, ccol)):
+        d.setdefault(str(k), {})[c] = float(sm)
+    return d
 
 
 def per_kernel(path, counter):
@@ -37,7 +58,7 @@ def per_kernel(path, counter):
     return out
 
 
-def main(fetch_db, write_db, steps, out_path, fetch_db2=None, write_db2=None, extra_steps=None):
+def main(fetch_db, write_db, steps, out_path, fetch_db2=None, write_db2=None, extra_steps=None, mfma_db=None):
     """fetch_db2 / write_db2: the same passes with `extra_steps` more timed steps -- their difference is the traffic of
     exactly that many steady-state steps (setup_alpha's initialisation kernels and the warm-up cancel)."""
     from ofq_amd import build
@@ -73,6 +94,12 @@ def main(fetch_db, write_db, steps, out_path, fetch_db2=None, write_db2=None, ex
         if nf and nw:
             res[cls] = {"launches": nf, "fetch_size_kb_raw_per_launch": round(sf / nf, 1), "write_size_kb_per_launch": round(sw / nw, 1),
                         "traffic_bytes_per_launch": int((2 * sf / nf + sw / nw) * 1024)}
+            if mfma_db:
+                mu = mfma_util(mfma_db)
+                busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k, v in mu.items() if any(p in k for p in prefixes))
+                gui = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for k, v in mu.items() if any(p in k for p in prefixes))
+                if gui > 0:
+                    res[cls]["mfma_util_pmc"] = round(100.0 * busy / (gui * 1024) / 0.116, 1)
     top = sorted(((2 * f.get(k, (0, 0))[1] + w.get(k, (0, 0))[1]) * 1024 / steps / 1e9, k) for k in set(f) | set(w))[::-1][:25]
     res["top_kernels_GB_per_step"] = [[k[:70], round(g, 2)] for g, k in top]
     with open(out_path, "w") as fh:
@@ -85,4 +112,4 @@ def main(fetch_db, write_db, steps, out_path, fetch_db2=None, write_db2=None, ex
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:8])
+    main(*sys.argv[1:9])
