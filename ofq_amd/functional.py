@@ -72,7 +72,7 @@ def _shared_grad(acc, shape, device):
 # AllWqkFn.backward, and engine._step_body right after loss.backward().  Outside the training step nothing is deferred.
 DW_DEFER = False
 DW_GROUP = os.environ.get("OFQ_NO_DW_GROUP") is None       # A/B switch
-DW_FLUSH_TILES = int(os.environ.get("OFQ_DW_FLUSH_TILES", "40"))
+DW_FLUSH_TILES = int(os.environ.get("OFQ_DW_FLUSH_TILES", "46"))   # a DeiT-S QKR block queues 12 + 12 + 3 + 18 + 3 = 48
 _DW_QUEUE = []
 _DW_TILES = [0]
 

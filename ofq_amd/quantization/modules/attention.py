@@ -147,8 +147,9 @@ def plain_attention_core(self, x, scale, addend=None, pre_quant=None):
             saux = {"qcodes": qc, "kcodes": kc, "sq": self.quan_a_q_fn.s.detach(), "gq": gq.gscale,
                     "sk": self.quan_a_k_fn.s.detach(), "gk": gq.gscale, "bq": self.move_q_aft.bias.detach(),
                     "bk": self.move_k_aft.bias.detach(), "H": H, "link": link}
+            pv_aux = {"vcodes": vc, "sv": self.quan_a_v_fn.s.detach(), "gv": gv.gscale, "bav": self.move_v_aft.bias.detach()}
             if scores_softmax_fusable(N) and sm.initialized_alpha and sm.s is not None:
-                saux.update(plain=True, alpha=scale, hi=sm.thd_pos)
+                saux.update(plain=True, alpha=scale, hi=sm.thd_pos, vlink=pv_aux)      # (vlink: dP GEMM + softmax backward fused)
                 P, pcodes, rp = ScoresSoftmaxCodesFn.apply(q, k, sm.s, saux, _pad_addend(addend, N))                 # :96-99
             else:
                 S = QKScoresCodesFn.apply(q, k, saux)                                                                 # :96
@@ -156,9 +157,8 @@ def plain_attention_core(self, x, scale, addend=None, pre_quant=None):
                 _softmax_init(sm, S, N, scale, addend)
                 P, pcodes, rp = SoftmaxLsqCodesFn.apply(S, sm.s, N, scale, sm.thd_pos, link, addend)                  # :97-99
             gp = 1.0 / (sm.thd_pos * B * H * N) ** 0.5
-            return PVCodesFn.apply(P, v, {
-                "pcodes": pcodes, "rp": rp, "vcodes": vc, "sp": sm.s.detach(), "gp": gp,
-                "sv": self.quan_a_v_fn.s.detach(), "gv": gv.gscale, "bav": self.move_v_aft.bias.detach()})            # :102
+            pv_aux.update(pcodes=pcodes, rp=rp, sp=sm.s.detach(), gp=gp)
+            return PVCodesFn.apply(P, v, pv_aux)                                                                      # :102
         q, k, v = QKVSplitLsqFn.apply(qkv, self.move_qkv_b4.bias, self.quan_a_q_fn.s, self.quan_a_k_fn.s,
                                       self.quan_a_v_fn.s, self.move_q_aft.bias, self.move_k_aft.bias,
                                       self.move_v_aft.bias, gq, gq, gv)          # :71-90
