@@ -80,13 +80,17 @@ _DW_TILES = [0]
 def flush_dw():
     """Launch every queued weight-gradient GEMM (no-op when the queue is empty)."""
     q = _DW_QUEUE
-    while q:
-        three = q[0]["xcodes2d"].shape[1] % 384 == 0
-        n = 1
-        while n < len(q) and n < ops.TN_GROUP_MAX and (q[n]["xcodes2d"].shape[1] % 384 == 0) == three:
-            n += 1
-        ops.qgemm_bf16s_tn_group(q[:n])
-        del q[:n]
+    try:
+        while q:
+            three = q[0]["xcodes2d"].shape[1] % 384 == 0
+            n = 1
+            while n < len(q) and n < ops.TN_GROUP_MAX and (q[n]["xcodes2d"].shape[1] % 384 == 0) == three:
+                n += 1
+            ops.qgemm_bf16s_tn_group(q[:n])
+            del q[:n]
+    except BaseException:
+        drop_dw()                 # never carry raw output addresses of a failed step into the next one
+        raise
     _DW_TILES[0] = 0
 
 
