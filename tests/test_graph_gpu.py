@@ -464,6 +464,26 @@ def test_bf16_plane_gemm_is_fp32_grade():
     assert e9 <= 1.5 * e_f32 + 1e-8 and e6 <= 3.0 * e_f32 + 1e-7, (e_f32, e9, e6)
 
 
+def test_bf16_plane_gemm_wide_tile_equals_narrow_tile():
+    """ofq_gemm_bf16x3x3_nt runs 128 x 384 double-buffered tiles for N >= 256 (gemm_bf16x3x3_wide_kernel) and 128 x 128 tiles
+    below: same plane products in the same k order, so the wide result equals the narrow kernel's on 128-column slices of the
+    weight, bit for bit -- nine and six products, ragged M / N, K = 384 and 1536."""
+    from ofq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (M, N, K) in [(1000, 392, 1536), (25344 // 8, 1152, 1024), (300, 384, 384)]:      # (shapes the launcher sends to the wide tile)
+        x = torch.randn(M, K, device="cuda", generator=g)
+        W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+        b = torch.randn(N, device="cuda", generator=g)
+        planes = ops.split_f32_bf16x3(W)
+        for products in (9, 6):
+            wide = ops.gemm_bf16x3x3_nt(x, planes, b, products=products)
+            for c0 in range(0, N, 128):
+                c1 = min(N, c0 + 128)
+                sl = planes[:, c0:c1].contiguous()
+                narrow = ops.gemm_bf16x3x3_nt(x, sl, b[c0:c1].contiguous(), products=products)
+                assert torch.equal(wide[:, c0:c1], narrow), (M, N, K, products, c0)
+
+
 def test_bench_line_contract():
     """`python bench.py` prints exactly one JSON line with the driver's fields, the roofline block of the dominant kernel
     class (a bf16-split backward GEMM; at 128 images the dW GEMM) and the CPU baseline block (small step counts here: the numbers are not checked)."""
