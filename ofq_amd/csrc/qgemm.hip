@@ -3457,12 +3457,103 @@ __global__ __launch_bounds__(512) void gemm_bf16x3x3_wide_kernel(QGemmArgs p) {
   const int klast = nkt - 1;
   // loads of tile kt + 3 behind the staging of tile kt + 1, as in the other wide kernels (branch-free: past the end the
   // last tile is loaded again into a stage nobody reads)
+#ifdef QPW_SERIAL_STAGING
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     compute(cur);
     lstore(nxt, SLOT);
     gload(min(kt + 3, klast), SLOT);
     lds_barrier();
   };
+#else
+  // The staging of tile kt + 1 and the loads of tile kt + 3 cut into pieces of one or two instructions behind the MFMAs
+  // of tile kt (see the note at static_for: the first two instructions behind an MFMA of the same wave are free).  Run as
+  // a block after the MFMAs, staging + loads + barrier + the first fragment reads left the matrix pipe idle for a third
+  // of every k-step (both waves of a SIMD reach that phase together): 283 us at K = 1536 against 185 us of MFMA time.
+  // Pieces: the A float4 of this thread (its three planes: per element [x = a*z, p0], [r1, p1], [r2], a pack per pair, three
+  // stores), the B chunks (mask + store each), then the loads in consumption order.
+  constexpr int NPROD = PMAX >= 5 ? 9 : 6, NM = NPROD * 6;
+  constexpr int NPA = 17, NP = NPA + CHB + CHB + 1;
+  auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const unsigned char* a = &cur[(wm * 64 + l31) * QPW_LD + lh * 16];
+    const unsigned char* b = &cur[NS * PLANE_A + (wn * 96 + l31) * QPW_LD + lh * 16];
+    // A fragments ping-pong between two register pairs (plane q + 1 is read behind the first MFMA of plane q): 16 instead
+    // of 24 VGPRs -- the kernel sits at the 256-register limit of two waves per SIMD
+    bf16x8 avq[2][2], bv[NB][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) avq[0][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * QPW_LD);
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bv[r][j] = *reinterpret_cast<const bf16x8*>(b + r * PLANE_B + j * 32 * QPW_LD);
+    float z_ = 0.f, x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+    unsigned lo[NS], hi[NS];
+    const int k3 = min(kt + 3, klast) * QPW_BK;
+    auto piece = [&](auto P_) {
+      constexpr int P = decltype(P_)::value;
+      if constexpr (P < NPA) {
+        if constexpr (P == 0) {
+          asm volatile("" : "+v"(ra[sl]));                     // first touch of the slot: the wait for its loads lands here
+          z_ = (okA && rka[sl]) ? 1.f : 0.f;
+        }
+        if constexpr (P < 14) {
+          constexpr int pr = P / 7, rr = P % 7;
+          if constexpr (rr < 6) {
+            constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+            if constexpr (st == 0) valu_mul_hi16(ra[sl][e], z_, x_, p0v[el]);
+            if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+          } else {
+            valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
+          }
+        } else {
+          constexpr int q = P - 14;
+          uint2 w;
+          w.x = lo[q];
+          w.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE_A + arow * QPW_LD + akq * 2]) = w;
+        }
+      } else if constexpr (P < NPA + CHB) {
+        constexpr int i = P - NPA;
+        asm volatile("" : "+v"(rb[sl][i]));
+        const int f = tid + 512 * i;
+        if (CHB * 512 == NB * 2 * BN || f < NB * 2 * BN) {
+          const int m = (okB[i] && rkb[sl][(f % (2 * BN)) & 1]) ? -1 : 0;
+          *reinterpret_cast<i32x4*>(&nxt[boff[i]]) = rb[sl][i] & m;
+        }
+      } else if constexpr (P < NPA + 2 * CHB) {
+        constexpr int i = P - NPA - CHB;
+        if constexpr (i == 0) {
+          rkb[sl][0] = k3 < K;
+          rkb[sl][1] = (k3 + 8) < K;
+        }
+        rb[sl][i] = *reinterpret_cast<const i32x4*>(pb[i] + (k3 < K ? k3 : 0));
+      } else {
+        rka[sl] = (k3 + akq) < K;
+        ra[sl] = *reinterpret_cast<const f32x4v*>(pa + (rka[sl] ? k3 : 0));
+      }
+    };
+    static_for<NM>([&](auto G_) {
+      constexpr int G = decltype(G_)::value;
+      // product list in the narrow kernel's order: q outer, r inner, skipping q + r >= PMAX
+      constexpr int pidx = G / 6, ij = G % 6, i = ij / 3, j = ij % 3;
+      constexpr int q = PMAX >= 5 ? pidx / 3 : (pidx < 3 ? 0 : (pidx < 5 ? 1 : 2));
+      constexpr int r = PMAX >= 5 ? pidx % 3 : (pidx < 3 ? pidx : (pidx < 5 ? pidx - 3 : 0));
+      constexpr int Gq0 = PMAX >= 5 ? q * 18 : (q == 0 ? 0 : (q == 1 ? 18 : 30));       // first MFMA of plane q
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avq[q & 1][i], bv[r][j], acc[i][j], 0, 0, 0);
+      if constexpr (G == Gq0 + 5 && q + 1 < NS && (PMAX >= 5 || q + 1 < PMAX)) {
+        // plane q's predecessor has been used up six MFMAs ago: its registers take plane q + 1
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+          avq[(q + 1) & 1][ii] = *reinterpret_cast<const bf16x8*>(a + (q + 1) * PLANE_A + ii * 32 * QPW_LD);
+      }
+      constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+  };
+#endif
   gload(0, Slot0());
   gload(min(1, klast), Slot1());
   lstore(smem, Slot0());
@@ -3508,8 +3599,8 @@ extern "C" int ofq_gemm_bf16x3x3_nt(const float* A, const void* B_planes, float*
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = 1.f; a.nb1 = 1;
   static const bool narrow_only = getenv("OFQ_PLANE_GEMM_NARROW") != nullptr;       // A/B switch
-  // measured at 25 344 rows (tools/plane_gemm_bench.py, nine products, wide / narrow us): N = 384, K = 384: 94 / 108;
-  // N = 384, K = 1536: 283 / 343; N = 1152, K = 384: 275 / 229; N = 1536, K = 384: 340 / 276 -- the wide tile wins where a
+  // measured at 25 344 rows (tools/plane_gemm_bench.py, nine products, wide / narrow us): N = 384, K = 384: 80 / 108;
+  // N = 384, K = 1536: 238 / 346; N = 1152, K = 384: 234 / 239; N = 1536, K = 384: 300 / 281 -- the wide tile wins where a
   // workgroup's k-loop is long or the narrow grid (594 workgroups on 512 slots) quantises badly
   static const bool wide_always = getenv("OFQ_PLANE_GEMM_WIDE") != nullptr;
   if (!narrow_only && N >= 256 && 128 * ldc < (1ll << 28) && (K & 15) == 0 && (wide_always || K >= 1024 || N <= 384)) {
