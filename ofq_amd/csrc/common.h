@@ -39,16 +39,20 @@ __device__ __forceinline__ float ofq_lsq_quant(float xin, float a, float lo, flo
 // The level q = rint(clamp(x / a, lo, hi)) of ofq_lsq_quant without the IEEE division sequence in the common case.
 // `ra` is the correctly rounded 1 / a, so x * ra is within 1.5 ulp of the correctly rounded x / a, and the two round to
 // the same level unless the clamped product lies within `tol` = 8 ulp(max(|lo|, |hi|) + 1) of a half-integer.  Callers
-// OR the `risky` flags of a group of elements and redo the group with ofq_lsq_level_exact when any lane of the wave
-// raised one (rare: ~1e-5 per element at 2-4 bits), so the levels stay bit-identical at ~7 instead of ~16 VALU each.
+// accumulate the distance to the nearest integer over a group of elements and redo the group with ofq_lsq_level_exact
+// when any lane of the wave comes that close (rare: ~1e-5 per element at 2-4 bits), so the levels stay bit-identical at
+// ~6 instead of ~16 VALU each.
 __device__ __forceinline__ float ofq_lsq_level_tol(float lo, float hi) {
   const float m = fmaxf(fabsf(lo), fabsf(hi)) + 1.f;
   return 8.f * (m * 1.1920929e-7f);                   // 8 * ulp-ish (m * 2^-23 >= ulp(m))
 }
-__device__ __forceinline__ float ofq_lsq_level_rcp(float x, float ra, float lo, float hi, float half_m_tol, bool& risky) {
-  const float u = __builtin_amdgcn_fmed3f(__fmul_rn(x, ra), lo, hi);        // clamp in one instruction (lo <= hi)
+// The group's flag is a running maximum of |u - q| (two VALU instructions per element; a bool OR-ed per element costs
+// five: compare, select, shift, or, bit-op).  The caller tests !(dmax < half_m_tol) once per group.  A NaN takes the
+// fast level, which is the exact form's too (v_med3_f32 and fmaxf both fall to `lo`).
+__device__ __forceinline__ float ofq_lsq_level_rcp_d(float x, float ra, float lo, float hi, float& dmax) {
+  const float u = __builtin_amdgcn_fmed3f(__fmul_rn(x, ra), lo, hi);
   const float q = rintf(u);
-  risky |= !(fabsf(__fsub_rn(u, q)) < half_m_tol);                          // NaN -> risky
+  dmax = fmaxf(dmax, fabsf(__fsub_rn(u, q)));
   return q;
 }
 __device__ __forceinline__ float ofq_lsq_level_exact(float x, float a, float lo, float hi) {
@@ -82,20 +86,33 @@ __device__ __forceinline__ void ofq_lsq_bwd_exact(float xin, float g, float a, f
 //  * (g * a) / a: t = fl(g * a); q0 = fl(t * ra); two residual corrections q <- fma(fma(-a, q, t), ra, q) -- the tail of
 //    the hardware's own division expansion with an exact reciprocal in place of its refined estimate -- give the correctly
 //    rounded quotient whenever nothing under- or overflows; |t| outside [2^-100, 2^100] is flagged risky as well.
-__device__ __forceinline__ void ofq_lsq_bwd_fast(float xin, float g, float a, float ra, float lo, float hi, float half_m_tol,
-                                                 float tol, bool& risky, float& dq, float& dsc) {
+// The exactness conditions are accumulated over a group as extrema (OfqLsqFlags, ~9 VALU per element, no per-element
+// booleans) and tested once per group with ofq_lsq_flags_risky.
+struct OfqLsqFlags {
+  float dmax = 0.f;                       // max |u - rint(u)|
+  float emin = 3.0e38f;                   // min distance of v' to lo / hi
+  unsigned umin = 0xffffffffu;            // min over non-zero |t| of bits(|t|) - 1   (zero wraps to the top)
+  unsigned umax = 0u;                     // max bits(|t|)   (inf / NaN on top)
+};
+__device__ __forceinline__ bool ofq_lsq_flags_risky(const OfqLsqFlags& f, float half_m_tol, float tol) {
+  // |t| must lie strictly inside (2^-100, 2^100) unless it is zero
+  return !(f.dmax < half_m_tol) | (f.emin < tol) | (f.umin < 0x0D800000u) | (f.umax >= 0x71800000u);
+}
+__device__ __forceinline__ void ofq_lsq_bwd_fast(float xin, float g, float a, float ra, float lo, float hi, OfqLsqFlags& f,
+                                                 float& dq, float& dsc) {
   const float v = __fmul_rn(xin, ra);
   const float u = __builtin_amdgcn_fmed3f(v, lo, hi);
   const float q = rintf(u);
   const bool inr = (v >= lo) && (v <= hi);
-  risky |= !(fabsf(__fsub_rn(u, q)) < half_m_tol);
-  risky |= (fabsf(__fsub_rn(v, lo)) < tol) | (fabsf(__fsub_rn(v, hi)) < tol);
+  f.dmax = fmaxf(f.dmax, fabsf(__fsub_rn(u, q)));
+  f.emin = fminf(f.emin, fminf(fabsf(__fsub_rn(v, lo)), fabsf(__fsub_rn(v, hi))));
   const float t = __fmul_rn(g, a);
   float qq = __fmul_rn(t, ra);
   qq = __fmaf_rn(__fmaf_rn(-a, qq, t), ra, qq);
   qq = __fmaf_rn(__fmaf_rn(-a, qq, t), ra, qq);
-  const float at = fabsf(t);
-  risky |= (at != 0.f) & !((at > 7.8886090522e-31f) & (at < 1.2676506002e30f));
+  const unsigned tb = __float_as_uint(t) & 0x7fffffffu;
+  f.umin = min(f.umin, tb - 1u);
+  f.umax = max(f.umax, tb);
   dq = inr ? qq : 0.f;
   dsc = g * (inr ? (q - v) : q);
 }

@@ -146,12 +146,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           // so the codes stay bit-identical at ~5 instead of ~16 VALU per element
           const float xe[4] = {__fadd_rn(o.x, qb4v[j].x), __fadd_rn(o.y, qb4v[j].y), __fadd_rn(o.z, qb4v[j].z),
                                __fadd_rn(o.w, qb4v[j].w)};
-          bool risky = false;
-          float q0 = ofq_lsq_level_rcp(xe[0], q_ra, a.qlo, a.qhi, q_hmt, risky);
-          float q1 = ofq_lsq_level_rcp(xe[1], q_ra, a.qlo, a.qhi, q_hmt, risky);
-          float q2 = ofq_lsq_level_rcp(xe[2], q_ra, a.qlo, a.qhi, q_hmt, risky);
-          float q3 = ofq_lsq_level_rcp(xe[3], q_ra, a.qlo, a.qhi, q_hmt, risky);
-          if (risky) {
+          float dmax = 0.f;
+          float q0 = ofq_lsq_level_rcp_d(xe[0], q_ra, a.qlo, a.qhi, dmax);
+          float q1 = ofq_lsq_level_rcp_d(xe[1], q_ra, a.qlo, a.qhi, dmax);
+          float q2 = ofq_lsq_level_rcp_d(xe[2], q_ra, a.qlo, a.qhi, dmax);
+          float q3 = ofq_lsq_level_rcp_d(xe[3], q_ra, a.qlo, a.qhi, dmax);
+          if (!(dmax < q_hmt)) {
             q0 = ofq_lsq_level_exact(xe[0], q_al, a.qlo, a.qhi);
             q1 = ofq_lsq_level_exact(xe[1], q_al, a.qlo, a.qhi);
             q2 = ofq_lsq_level_exact(xe[2], q_al, a.qlo, a.qhi);
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           const float gm[4] = {gam[j].x, gam[j].y, gam[j].z, gam[j].w}, bt[4] = {bet[j].x, bet[j].y, bet[j].z, bet[j].w};
           const float b4[4] = {qb4v[j].x, qb4v[j].y, qb4v[j].z, qb4v[j].w};
           float dq[4], dsc[4], xq[4];
-          bool risky = false;
+          OfqLsqFlags fl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float n = (xx[e] - mu) * rs * gm[e] + bt[e];            // same expression as the forward
             xq[e] = __fadd_rn(n, b4[e]);
-            ofq_lsq_bwd_fast(xq[e], gg[e], al, ral, a.qlo, a.qhi, q_hmt, q_tol, risky, dq[e], dsc[e]);
+            ofq_lsq_bwd_fast(xq[e], gg[e], al, ral, a.qlo, a.qhi, fl, dq[e], dsc[e]);
           }
-          if (risky) {       // an element within a few ulp of a rounding / range boundary: the IEEE divisions decide
+          if (ofq_lsq_flags_risky(fl, q_hmt, q_tol)) {       // an element within a few ulp of a rounding / range boundary: the IEEE divisions decide
 #pragma unroll
             for (int e = 0; e < 4; ++e) ofq_lsq_bwd_exact(xq[e], gg[e], al, a.qlo, a.qhi, dq[e], dsc[e]);
           }

@@ -163,19 +163,19 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
     float qsum = 0.f;
     float pr[KCH][4], qq[KCH][4];
     float prt = 0.f, qqt = 0.f;
-    bool risky = false;
+    float dmax = 0.f;
 #pragma unroll
     for (int k = 0; k < KF; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pr[k][e] = ofq_div_by_rcp(t[k][e], sum, rsum);
-        qq[k][e] = ofq_lsq_level_rcp(pr[k][e], ra, 0.f, q.hi, half_m_tol, risky);
+        qq[k][e] = ofq_lsq_level_rcp_d(pr[k][e], ra, 0.f, q.hi, dmax);
       }
     if (TAIL) {
       prt = ofq_div_by_rcp(tt, sum, rsum);
-      qqt = ofq_lsq_level_rcp(prt, ra, 0.f, q.hi, half_m_tol, risky);
+      qqt = ofq_lsq_level_rcp_d(prt, ra, 0.f, q.hi, dmax);
     }
-    if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+    if (__builtin_amdgcn_ballot_w64(!(dmax < half_m_tol)) != 0ull) {
 #pragma unroll
       for (int k = 0; k < KF; ++k)
 #pragma unroll
@@ -419,7 +419,6 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
   __syncthreads();
   // ---- phase 2: LSQ backward + softmax backward per row (ofq_softmax_lsq_bwd's arithmetic)
   const float tol = ofq_lsq_level_tol(0.f, q.hi), half_m_tol = 0.5f - tol;
-  const float hi_m_tol = q.hi - tol, hi_p_tol = q.hi + tol;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     if (m0 + wn * 16 + it * 4 >= N) continue;              // wave-uniform: none of the four rows exists
@@ -432,7 +431,7 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
     constexpr int NE = 4 * KF + (TAIL ? 1 : 0);
     float p[NE], g[NE], dq[NE];
     float rowds = 0.f, dot = 0.f;
-    bool risky = false;
+    OfqLsqFlags fl;                                        // extrema instead of per-element booleans (common.h)
 #pragma unroll
     for (int k = 0; k < KF; ++k) {
       const int c0 = 4 * lr + 64 * k;
@@ -461,19 +460,20 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
       const float u = fminf(v, q.hi);
       const float qq = rintf(u);
       const bool inr = v <= q.hi;
-      bool rk = !(fabsf(__fsub_rn(u, qq)) < half_m_tol) | ((v > hi_m_tol) & (v < hi_p_tol));
+      fl.dmax = fmaxf(fl.dmax, fabsf(__fsub_rn(u, qq)));
+      fl.emin = fminf(fl.emin, fabsf(__fsub_rn(v, q.hi)));
       const float t = __fmul_rn(g[x], a);
       float d0 = __fmul_rn(t, ra);
       d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
       d0 = __fmaf_rn(__fmaf_rn(-a, d0, t), ra, d0);
-      const float at = fabsf(t);
-      rk |= (at != 0.f) & !((at > 7.8886090522e-31f) & (at < 1.2676506002e30f));
-      risky |= rk;
+      const unsigned tb = __float_as_uint(t) & 0x7fffffffu;
+      fl.umin = min(fl.umin, tb - 1u);
+      fl.umax = max(fl.umax, tb);
       dq[x] = inr ? d0 : 0.f;
       rowds += g[x] * (inr ? (qq - v) : qq);
       dot += dq[x] * p[x];
     }
-    if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {       // rare: a value next to a rounding tie / the upper edge
+    if (__builtin_amdgcn_ballot_w64(ofq_lsq_flags_risky(fl, half_m_tol, tol)) != 0ull) {       // rare: a value next to a rounding tie / the upper edge
       rowds = 0.f;
       dot = 0.f;
 #pragma unroll

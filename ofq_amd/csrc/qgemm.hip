@@ -127,7 +127,7 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
 #pragma unroll
         for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
           float xq[4][2], qv[4][2], rbv[4];
-          bool risky = false;
+          float dmax = 0.f;
 #pragma unroll
           for (int ee = 0; ee < 4; ++ee) {
             const int e = eg * 4 + ee;
@@ -150,12 +150,12 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
 #endif
               if (QMODE != 0) {
                 xq[ee][j] = __fadd_rn(QGELU ? ofq_gelu(yv) : yv, qb[j]);
-                qv[ee][j] = ofq_lsq_level_rcp(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, half_m_tol, risky);
+                qv[ee][j] = ofq_lsq_level_rcp_d(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, dmax);
               }
             }
           }
           if (QMODE != 0) {
-            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(!(dmax < half_m_tol)) != 0ull) {
 #pragma unroll
               for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
@@ -512,7 +512,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
 // for the stored-activation pair; the extra int8 GEMM (K = C) is free next to that.
 // QMODE 1: per-row step, index ((m * qrowmul + n / qcoldiv) % qS); QMODE 2: per-column step.
 // Partials: lrow[m][2 * tiles_n] (row mode: sum of dsc over each 64-column half tile), lcol[tiles_m][nacc][N].
-template <int QMODE, bool GELU>
+// INTERIOR (launch-time: M and N multiples of 128 and the tile offsets fit 32 bits, every DeiT-S shape): no bounds
+// selects, rows addressed through a uniform base plus one 32-bit lane offset.
+typedef __attribute__((address_space(1))) char* GlobalBytes;
+template <int QMODE, bool GELU, bool INTERIOR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qgemm_i8_lsqbwd_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
@@ -547,7 +550,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int ncl[2] = {min(ncol[0], p.N - 1), min(ncol[1], p.N - 1)};
   const bool cok[2] = {ncol[0] < p.N, ncol[1] < p.N};
   float g0[16][2], g1[16][2];
+  // gradient loads and dy stores of the INTERIOR form address rows through a uniform base (scalar registers) plus one
+  // 32-bit lane offset -- this epilogue is issue-bound at two waves per SIMD
+  const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
+  const unsigned lane_g = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldlx + (unsigned)(n0 + wn_s * 64 + l31));
+  const unsigned lane_c = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
+  const float* G_t = G + (int64_t)(m0 + wm_s * 64) * p.ldlx;
+  float* C_t = p.C + (int64_t)(m0 + wm_s * 64) * p.ldc;
   auto gload = [&](float (&g)[16][2], int i) {
+    if (INTERIOR) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        // the row base is pinned in scalar registers (else it is folded into 64-bit VALU adds per element); the pointer is
+        // rebuilt in the global address space, or the loads become flat_load
+        uintptr_t rp = reinterpret_cast<uintptr_t>(G_t + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldlx);
+        asm volatile("" : "+s"(rp));
+        const GlobalBytes rowp = reinterpret_cast<GlobalBytes>(rp);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g[e][j] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rowp + lane_g + 128 * j);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = min(m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, p.M - 1);
@@ -595,25 +618,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // 4 rows x 2 columns share one exactness check (see ofq_lsq_bwd_fast): a wave that raises it redoes the group with
       // the IEEE division sequences, so every value equals ofq_lsq_bwd's bit for bit
       float yv[4][2], xin[4][2], gev[4][2], alv[4][2], dq[4][2], dsc[4][2];
-      bool risky = false;
+      OfqLsqFlags fl;
 #pragma unroll
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
         const int mr = wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
-        const bool mok = (m0 + mr) < p.M;
+        const bool mok = INTERIOR || (m0 + mr) < p.M;
         const float ae = row_a[mr];
         const float alr = row_b[mr], rar = row_c[mr];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           yv[ee][j] = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
           xin[ee][j] = __fadd_rn(GELU ? ofq_gelu(yv[ee][j]) : yv[ee][j], qb[j]);
-          gev[ee][j] = (mok && cok[j]) ? g[e][j] : 0.f;
+          gev[ee][j] = (INTERIOR || (mok && cok[j])) ? g[e][j] : 0.f;
           alv[ee][j] = QMODE == 2 ? qsc[j] : alr;
-          ofq_lsq_bwd_fast(xin[ee][j], gev[ee][j], alv[ee][j], QMODE == 2 ? qrc[j] : rar, lo, hi, half_m_tol, tol, risky,
-                           dq[ee][j], dsc[ee][j]);
+          ofq_lsq_bwd_fast(xin[ee][j], gev[ee][j], alv[ee][j], QMODE == 2 ? qrc[j] : rar, lo, hi, fl, dq[ee][j], dsc[ee][j]);
         }
       }
-      if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+      if (__builtin_amdgcn_ballot_w64(ofq_lsq_flags_risky(fl, half_m_tol, tol)) != 0ull) {
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
@@ -623,13 +645,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
         const int m = m0 + wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
+        uintptr_t rp = reinterpret_cast<uintptr_t>(C_t + (int64_t)(i * 32 + ee + 8 * eg) * p.ldc);        // uniform
+        if (INTERIOR) asm volatile("" : "+s"(rp));
+        const GlobalBytes rowp = reinterpret_cast<GlobalBytes>(rp);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           cb4[j] += dq[ee][j];
           cba[j] += gev[ee][j];
           if (QMODE == 2) cds[j] += dsc[ee][j]; else rds[i * 16 + e] += dsc[ee][j];
           const float dy = GELU ? dq[ee][j] * ofq_gelu_grad(yv[ee][j]) : dq[ee][j];
-          if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
+          if (INTERIOR) *reinterpret_cast<__attribute__((address_space(1))) float*>(rowp + lane_c + 128 * j) = dy;
+          else if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
         }
       }
     }
@@ -2863,12 +2889,19 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
   a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
+  const bool interior = (M % 128) == 0 && (N % 128) == 0 && 4 * (4 * (ldd > ldg ? ldd : ldg) + N) < (int64_t)0x7fffffff;
+  auto launch = [&](auto QM, auto GE) {
+    constexpr int qm = decltype(QM)::value;
+    constexpr bool ge = decltype(GE)::value;
+    if (interior) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, false>), grid, block, 0, st, a);
+  };
   if (q_colmode) {
-    if (q_gelu) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<2, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<2, false>), grid, block, 0, st, a);
+    if (q_gelu) launch(std::integral_constant<int, 2>(), std::true_type());
+    else launch(std::integral_constant<int, 2>(), std::false_type());
   } else {
-    if (q_gelu) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<1, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<1, false>), grid, block, 0, st, a);
+    if (q_gelu) launch(std::integral_constant<int, 1>(), std::true_type());
+    else launch(std::integral_constant<int, 1>(), std::false_type());
   }
   OFQ_LAUNCH_CHECK();
   // second stage (fixed order, no atomics): ds over batches and half tiles / over row tiles; db4, dbaft over row tiles
