@@ -126,8 +126,10 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
-          float xq[4][2], qv[4][2], rbv[4];
-          float dmax = 0.f;
+          // QGELU: the level is decided on ofq_gelu_fast (common.h); its error bound, in level units, widens the
+          // half-integer margin of the group, and a flagged group is redone with erff and the IEEE division
+          float yq[4][2], xq[4][2], qv[4][2], rbv[4];
+          float dmax = 0.f, rmax = 0.f;
 #pragma unroll
           for (int ee = 0; ee < 4; ++ee) {
             const int e = eg * 4 + ee;
@@ -135,6 +137,7 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
             const float ae = ra_t[r];
             rbv[ee] = QMODE == 1 ? ra_t[BM + r] : 1.f;
             const float rrb = QMODE == 1 ? ra_t[2 * BM + r] : 1.f;
+            if (QGELU && QMODE == 1) rmax = fmaxf(rmax, rrb);
             float* rowp = Cb_t + (int64_t)r * p.ldc;           // uniform: lives in an SGPR pair
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -149,18 +152,26 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
               if (yv == 123.456f) asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off4), "v"(yv), "s"(rowp));
 #endif
               if (QMODE != 0) {
-                xq[ee][j] = __fadd_rn(QGELU ? ofq_gelu(yv) : yv, qb[j]);
-                qv[ee][j] = ofq_lsq_level_rcp_d(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, dmax);
+                if (QGELU) {
+                  yq[ee][j] = yv;
+                  qv[ee][j] = ofq_lsq_level_rcp_d(__fadd_rn(ofq_gelu_fast(yv), qb[j]), QMODE == 2 ? qrc[j] : rrb, qlo, qhi, dmax);
+                } else {
+                  xq[ee][j] = __fadd_rn(yv, qb[j]);
+                  qv[ee][j] = ofq_lsq_level_rcp_d(xq[ee][j], QMODE == 2 ? qrc[j] : rrb, qlo, qhi, dmax);
+                }
               }
             }
           }
           if (QMODE != 0) {
-            if (__builtin_amdgcn_ballot_w64(!(dmax < half_m_tol)) != 0ull) {
+            float thr = half_m_tol;
+            if (QGELU) thr = __builtin_fmaf(-OFQ_GELU_FAST_EPS, QMODE == 2 ? fmaxf(qrc[0], qrc[1]) : rmax, half_m_tol);
+            if (__builtin_amdgcn_ballot_w64(!(dmax < thr)) != 0ull) {
 #pragma unroll
               for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                  qv[ee][j] = ofq_lsq_level_exact(xq[ee][j], QMODE == 2 ? qsc[j] : rbv[ee], qlo, qhi);
+                  qv[ee][j] = ofq_lsq_level_exact(QGELU ? __fadd_rn(ofq_gelu(yq[ee][j]), qb[j]) : xq[ee][j],
+                                                  QMODE == 2 ? qsc[j] : rbv[ee], qlo, qhi);
             }
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee)

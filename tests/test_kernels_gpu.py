@@ -794,6 +794,56 @@ def test_i8_epilogue_levels_on_rounding_boundaries(ops, bits, signed, colmode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("colmode", [0, 1])
+def test_i8_epilogue_gelu_levels_next_to_rounding_boundaries(ops, colmode):
+    """fc1's epilogue decides fc2's input level on a cheap GELU (Abramowitz-Stegun erf on v_rcp / v_exp) and redoes a
+    group with erff + the IEEE division when the result lies within the approximation's error bound of a half-integer.
+    Every (pre-activation, step, offset) triple here puts (gelu(y) + b) / a within 1e-8 .. 1e-4 of a rounding boundary;
+    the interior-tile codes must equal those of an edge tile of the same kernel, whose epilogue is the plain exact form
+    (qlinear.py:128-134: act -> LSQ of fc2's input)."""
+    lo, hi = -2, 1
+    rng = np.random.RandomState(77 + colmode)
+    K = 16
+    for rep in range(6):
+        n = 1536 if colmode else 128
+        yv = rng.uniform(-7.0, 7.0, n)
+        yv[: n // 4] = rng.normal(0, 1.2, n // 4)
+        a = rng.uniform(0.03, 0.6, n)
+        g = 0.5 * yv * (1.0 + np.vectorize(__import__("math").erf)(yv / np.sqrt(2.0)))
+        k = rng.randint(lo, hi, n) + 0.5                                     # boundaries lo+.5 .. hi-.5
+        delta = np.sign(rng.randn(n)) * 10.0 ** rng.uniform(-8, -4, n)
+        if colmode:          # y[m][n] = r[n]; per-column step a[n] and offset b[n] = a (k + .5) - gelu(y) + delta
+            b4 = (a * k - g + delta).astype(np.float32)
+            ones = torch.ones(128, device="cuda")
+            outs = []
+            for M in (128, 120):
+                xc = torch.zeros((M, K), dtype=torch.int8, device="cuda")
+                wc = torch.zeros((n, K), dtype=torch.int8, device="cuda")
+                fuse = dict(s=T(a.astype(np.float32)).cuda(), S=n, gscale=0.0, b4=T(b4).cuda(), lo=lo, hi=hi, gelu=1, colmode=1)
+                y = ops.qgemm_i8_nt(xc, wc, None, torch.ones(n, device="cuda"), 1.0, T(yv.astype(np.float32)).cuda(), ones[:M], M,
+                                    0.0, fuse=fuse)
+                assert np.array_equal(y.cpu().numpy()[0], yv.astype(np.float32))
+                outs.append(fuse["codes_out"].cpu().numpy())
+            assert np.array_equal(outs[0][:120], outs[1])
+            assert len(np.unique(outs[0])) == hi - lo + 1
+        else:                # y[m][n] = a_eff[m] * (+-1) = y[m]; per-row step a[m] = (gelu(y) + b) / (k + .5) * (1 + delta)
+            b = 2.0
+            a = (g + b) / (rng.randint(0, 3, n) + 0.5) * (1.0 + delta)                 # boundaries 0.5, 1.5, 2.5 of levels -2 .. 3
+            outs = []
+            for N in (128, 112):
+                xc = torch.zeros((128, K), dtype=torch.int8, device="cuda")
+                wc = torch.zeros((N, K), dtype=torch.int8, device="cuda")
+                xc[:, 0] = torch.from_numpy(np.where(yv < 0, -1, 1).astype(np.int8)).cuda()
+                wc[:, 0] = 1
+                fuse = dict(s=T(a.astype(np.float32)).cuda(), S=128, gscale=0.0, b4=torch.full((N,), b, device="cuda"), lo=lo, hi=hi + 2,
+                            gelu=1, colmode=0)
+                ops.qgemm_i8_nt(xc, wc, None, torch.ones(N, device="cuda"), 1.0, None, T(np.abs(yv).astype(np.float32)).cuda(), 128, 0.0,
+                                fuse=fuse)
+                outs.append(fuse["codes_out"].cpu().numpy())
+            assert np.array_equal(outs[0][:, :112], outs[1])
+
+
+@pytest.mark.gpu
 def test_statsq_multi_tensor_equals_the_per_tensor_launch(ops):
     """ofq_statsq_codes_multi (all layers' weight operands in one or two launches) against ofq_statsq_codes_fwd, bit for
     bit: scale, odd int8 codes, transposed bf16 codes, offset row-dots; 45 tensors so that the table is split over two
