@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void qattn_scores_softmax_kernel(QSsArgs q) {
   float* stile = reinterpret_cast<float*>(smem_raw);
   float* row_a = reinterpret_cast<float*>(smem_raw + (2 * STAGE > TILE_BYTES ? 2 * STAGE : TILE_BYTES));
   float* row_b = row_a + BM;
-  const int tm = blockIdx.x, gby = blockIdx.y;
+  // the row tiles of one (batch, head) share its key panel, the heads of one batch element its query rows: keep them on
+  // one XCD, next to each other in time (hardware order alone spreads consecutive workgroups over the 8 L2s)
+  int tm, gby;
+  xcd_remap_grid(tm, gby);
   const int m0 = tm * BM;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -278,7 +281,10 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SBYTES + BM * 4];
   float* stile = reinterpret_cast<float*>(smem);
   float* row_w = reinterpret_cast<float*>(smem + SBYTES);
-  const int tm = blockIdx.x, gby = blockIdx.y;
+  // the row tiles of one (batch, head) share its key panel, the heads of one batch element its query rows: keep them on
+  // one XCD, next to each other in time (hardware order alone spreads consecutive workgroups over the 8 L2s)
+  int tm, gby;
+  xcd_remap_grid(tm, gby);
   const int m0 = tm * BM;
   const int b = gby / q.H, h = gby % q.H;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
