@@ -339,6 +339,19 @@ int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, flo
 /*  W = W*(1-frozen) + saved               (after optimizer.step) */
 int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n, ofq_stream_t stream);
 
+/* ---- deferred second-stage sums.  The backward kernels of the quantisers (ofq_lsq_bwd, ofq_layernorm_lsq_bwd,
+ *  ofq_layernorm_bwd, ofq_qgemm_i8_lsq_bwd, ofq_softmax_lsq_bwd, ofq_qattn_dp_softmax_bwd) finish with a small fixed-order
+ *  reduction of their per-workgroup partials into d(step) / d(offset) / d(gamma) / d(beta) -- parameter gradients
+ *  (lsq.py:593-601, torch.nn.LayerNorm under autograd) that nobody reads before the optimiser step or the gradient
+ *  all-reduce, ~95 launches of 5-15 us per DeiT-S step.  Between ofq_sum_defer(1) and ofq_sum_defer(0) these reductions are
+ *  queued on the host instead of launched; ofq_sum_flush launches everything queued, up to 40 reductions per launch, each
+ *  with the lane layout its own launch would have used (the result is the immediate one bit for bit).  The caller keeps
+ *  the workspaces of the queued calls alive and untouched until the flush, and nothing may read their ds / db outputs
+ *  before it.  ofq_sum_pending: number of queued reductions.  Host state is per process (one process per GPU). */
+void ofq_sum_defer(int on);
+int ofq_sum_pending(void);
+int ofq_sum_flush(ofq_stream_t stream);
+
 /* ---- exact (erf) GELU, y = gelu(x) elementwise (x may alias y): activation of the fp32 KD teacher's MLP
  *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */

@@ -98,6 +98,9 @@ SIGNATURES = {
     "ofq_cga_freeze_mask_multi": (i32, [vp, i64, i32, f32, vp]),
     "ofq_cga_mask_grad_save": (i32, [vp, vp, vp, vp, i64, vp]),
     "ofq_cga_restore": (i32, [vp, vp, vp, i64, vp]),
+    "ofq_sum_defer": (None, [i32]),
+    "ofq_sum_pending": (i32, []),
+    "ofq_sum_flush": (i32, [vp]),
     "ofq_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "ofq_permute_tokens": (i32, [vp, vp, vp, i64, i64, i64, vp]),
     "ofq_split_f32_bf16x3": (i32, [vp, vp, i64, i64, vp]),

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../include/ofq_hip.h"
+#include <vector>
 
 #define OFQ_WAVE 64
 
@@ -188,12 +189,12 @@ __device__ __forceinline__ float ofq_sum_run(const float* __restrict__ p, int cn
   return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 template <int CPB>
-__global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
+__device__ __forceinline__ void strided_sum_body(const SumJob& jb) {
   constexpr int RL = 1024 / CPB;
-  const SumJob jb = jobs.j[blockIdx.y];
   __shared__ float part[RL][CPB + 1];
   const int cx = threadIdx.x % CPB, py = threadIdx.x / CPB;
   const int64_t c = (int64_t)blockIdx.x * CPB + cx;
+  if ((int64_t)blockIdx.x * CPB >= jb.ncols) return;          // (a merged launch is as wide as its widest job)
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (jb.dst && c < jb.ncols) {
     const int64_t co = jb.col_div ? (c / jb.col_div) * jb.col_mul + (c % jb.col_div) * jb.cnt : c * jb.cnt;
@@ -218,6 +219,26 @@ __global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
     jb.dst[c] = s * jb.scale;
   }
 }
+template <int CPB>
+__global__ __launch_bounds__(1024) void strided_sum_kernel_t(SumJobs jobs) {
+  strided_sum_body<CPB>(jobs.j[blockIdx.y]);
+}
+// many jobs in one launch (ofq_sum_flush): the deferred second stages of several kernels
+#define OFQ_SUM_MULTI 40
+struct SumJobsMulti { SumJob j[OFQ_SUM_MULTI]; };
+template <int CPB>
+__global__ __launch_bounds__(1024) void strided_sum_multi_kernel_t(SumJobsMulti jobs) {
+  strided_sum_body<CPB>(jobs.j[blockIdx.y]);
+}
+
+// Deferral (ofq_sum_defer / ofq_sum_flush, include/ofq_hip.h): while it is on, second stages are queued instead of
+// launched -- their results are parameter gradients that nobody reads before the optimiser step (or the gradient
+// all-reduce), and a step has ~95 of these 5-15 us launches.  Each job keeps the lane layout (CPB) its own launch would
+// have used, so a flushed result equals the immediate one bit for bit.  The caller keeps the partial buffers alive
+// and unmodified until the flush.
+struct SumPending { SumJob job; int cpb; };
+struct SumDeferState { bool on = false; std::vector<SumPending> pend; };
+static inline SumDeferState& sum_defer_state() { static SumDeferState s; return s; }
 
 static inline void strided_sum_launch(const SumJobs& jobs, int64_t maxcols, int njobs, hipStream_t st) {
   // jobs with a handful of columns over thousands of partial rows (Swin: 49 window-token scales over every window of
@@ -231,13 +252,20 @@ static inline void strided_sum_launch(const SumJobs& jobs, int64_t maxcols, int 
     int64_t& mc = d ? deep_cols : rest_cols;
     if (jobs.j[i].ncols > mc) mc = jobs.j[i].ncols;
   }
+  (void)maxcols;
+  SumDeferState& ds = sum_defer_state();
+  if (ds.on) {
+    for (int i = 0; i < njobs; ++i) {
+      if (deep.j[i].dst) ds.pend.push_back({deep.j[i], 4});
+      if (rest.j[i].dst) ds.pend.push_back({rest.j[i], rest_cols > 2048 ? 64 : 16});
+    }
+    return;
+  }
   if (deep_cols > 0)
     hipLaunchKernelGGL(strided_sum_kernel_t<4>, dim3((unsigned)ceil_div(deep_cols, 4), njobs), dim3(1024), 0, st, deep);
   if (rest_cols <= 0) return;
-  (void)maxcols;
   if (rest_cols > 2048)
     hipLaunchKernelGGL(strided_sum_kernel_t<64>, dim3((unsigned)ceil_div(rest_cols, 64), njobs), dim3(1024), 0, st, rest);
   else
     hipLaunchKernelGGL(strided_sum_kernel_t<16>, dim3((unsigned)ceil_div(rest_cols, 16), njobs), dim3(1024), 0, st, rest);
 }
-

@@ -266,3 +266,39 @@ extern "C" int ofq_permute_tokens(const float* x, const int32_t* idx, float* y, 
   OFQ_LAUNCH_CHECK();
   return 0;
 }
+
+// Deferred second-stage sums (common.h: SumDeferState).  ofq_sum_defer(1) ... ofq_sum_defer(0) brackets the calls whose
+// second stage may wait; ofq_sum_flush launches everything queued so far, up to OFQ_SUM_MULTI jobs per launch and lane
+// layout.  Host state is per process (one process per GPU, launches serialised on one stream).
+extern "C" void ofq_sum_defer(int on) { sum_defer_state().on = on != 0; }
+extern "C" int ofq_sum_pending(void) { return (int)sum_defer_state().pend.size(); }
+extern "C" int ofq_sum_flush(ofq_stream_t stream) {
+  SumDeferState& ds = sum_defer_state();
+  hipStream_t st = (hipStream_t)stream;
+  const int cpbs[3] = {4, 64, 16};
+  for (int v = 0; v < 3; ++v) {
+    SumJobsMulti m = {};
+    int n = 0;
+    int64_t tiles = 0;
+    auto launch = [&]() {
+      if (n == 0) return;
+      const dim3 grid((unsigned)tiles, (unsigned)n), block(1024);
+      if (cpbs[v] == 4) hipLaunchKernelGGL(strided_sum_multi_kernel_t<4>, grid, block, 0, st, m);
+      else if (cpbs[v] == 64) hipLaunchKernelGGL(strided_sum_multi_kernel_t<64>, grid, block, 0, st, m);
+      else hipLaunchKernelGGL(strided_sum_multi_kernel_t<16>, grid, block, 0, st, m);
+      n = 0;
+      tiles = 0;
+    };
+    for (const SumPending& p : ds.pend) {
+      if (p.cpb != cpbs[v]) continue;
+      m.j[n++] = p.job;
+      const int64_t t = ceil_div(p.job.ncols, cpbs[v]);
+      if (t > tiles) tiles = t;
+      if (n == OFQ_SUM_MULTI) launch();
+    }
+    launch();
+  }
+  ds.pend.clear();
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}

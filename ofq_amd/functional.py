@@ -77,9 +77,43 @@ _DW_QUEUE = []
 _DW_TILES = [0]
 
 
+# The same holds for the second-stage reductions of the quantiser / LayerNorm backward kernels (d step, d offset, d gamma,
+# d beta): inside the training step they are queued in the library (ops.deferred_sums) and launched together with the
+# block's dW GEMMs, forty per launch instead of one launch each (~95 launches of 5-15 us per DeiT-S step).
+SUM_DEFER = os.environ.get("OFQ_NO_SUM_DEFER") is None     # A/B switch
+
+
+def _sums_deferrable(*leaves):
+    """True when the parameter gradients a backward kernel is about to produce may be written later: inside the training
+    step, and every receiving tensor is a leaf whose .grad is empty -- autograd then adopts the returned tensor as the
+    gradient without reading it (an existing .grad would be accumulated into, i.e. read, right away)."""
+    if not (DW_DEFER and SUM_DEFER):
+        return False
+    for t in leaves:
+        if t is None:
+            continue
+        if not t.is_leaf or t.grad is not None:
+            return False
+    return True
+
+
+class _Immediate:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def sum_scope(*leaves):
+    """Context for a backward kernel call: ops.deferred_sums() when its reductions may wait (see _sums_deferrable)."""
+    return ops.deferred_sums() if _sums_deferrable(*leaves) else _Immediate()
+
+
 def flush_dw():
-    """Launch every queued weight-gradient GEMM (no-op when the queue is empty)."""
+    """Launch every queued weight-gradient GEMM and second-stage reduction (no-op when the queues are empty)."""
     q = _DW_QUEUE
+    ops.sum_flush()
     try:
         while q:
             three = q[0]["xcodes2d"].shape[1] % 384 == 0
@@ -98,6 +132,10 @@ def drop_dw():
     """Forget the queue (a backward pass that raised)."""
     del _DW_QUEUE[:]
     _DW_TILES[0] = 0
+    try:
+        ops.sum_flush()           # (the queued reductions only touch buffers that are still alive: launching them is harmless)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):
@@ -414,6 +452,7 @@ class SoftmaxLsqFn(torch.autograd.Function):
         ctx.save_for_backward(prob, s)
         ctx.addend = addend
         ctx.meta = (rows, N, Np, alpha, hi, B * H * N)
+        ctx.sum_leaves = (s,)
         return y
 
     @staticmethod
@@ -421,7 +460,8 @@ class SoftmaxLsqFn(torch.autograd.Function):
         prob, s = ctx.saved_tensors
         rows, N, Np, alpha, hi, M = ctx.meta
         g = g.contiguous()
-        dS, ds = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True)
+        with sum_scope(*ctx.sum_leaves):
+            dS, ds = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, M, inplace=True)
         dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[5]) else None
         return dS, ds, None, None, None, dadd
 
@@ -697,6 +737,7 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         ctx.save_for_backward(prob, s)
         ctx.addend = addend
         ctx.aux = aux
+        ctx.sum_leaf = s
         ctx.dims = (B, H, N, C, Np)
         ctx.mark_non_differentiable(codes, rsum)
         ctx.set_materialize_grads(False)
@@ -716,12 +757,13 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         rows, alpha, hi = B * H * N, aux["alpha"], aux["hi"]
         vl = aux.get("vlink")
         dO = vl.pop("dO_for_dp", None) if vl is not None else None
-        if dO is not None:
-            dS, ds, rs = ops.qattn_dp_softmax_bwd(dO, vl["vcodes"], vl["sv"], vl["gv"], vl["bav"], prob, s, alpha, hi, B, H, N,
-                                                  dO.shape[-1] // H, Np, want_rowsum=KEEP_ZERO_ROWSUM_TERM)
-        else:
-            g = g.contiguous()
-            dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, rows, inplace=True, want_rowsum=True)
+        with sum_scope(ctx.sum_leaf):
+            if dO is not None:
+                dS, ds, rs = ops.qattn_dp_softmax_bwd(dO, vl["vcodes"], vl["sv"], vl["gv"], vl["bav"], prob, s, alpha, hi, B, H, N,
+                                                      dO.shape[-1] // H, Np, want_rowsum=KEEP_ZERO_ROWSUM_TERM)
+            else:
+                g = g.contiguous()
+                dS, ds, rs = ops.softmax_lsq_bwd(g, prob, s, rows, N, Np, N, alpha, hi, rows, inplace=True, want_rowsum=True)
         dadd = _addend_grad(dS, ctx.addend, alpha) if (ctx.addend is not None and ctx.needs_input_grad[4]) else None
         if aux["plain"]:
             d = C // H
@@ -795,6 +837,7 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, mean, rstd, weight)
         ctx.shape = shp
         ctx.affine = weight is not None
+        ctx.sum_leaves = (weight, bias)
         return y.view(shp)
 
     @staticmethod
@@ -803,7 +846,8 @@ class LayerNormFn(torch.autograd.Function):
         dy2d = dy.reshape(x2d.shape)
         if dy2d.stride(-1) != 1 or (dy2d.stride(0) & 3):
             dy2d = dy2d.contiguous()
-        dx, dg, db = ops.layernorm_bwd(dy2d, x2d, mean, rstd, weight, want_affine_grads=ctx.affine)
+        with sum_scope(*ctx.sum_leaves):
+            dx, dg, db = ops.layernorm_bwd(dy2d, x2d, mean, rstd, weight, want_affine_grads=ctx.affine)
         return dx.view(ctx.shape), dg, db, None
 
 
@@ -820,6 +864,7 @@ class AddLayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(xs, mean, rstd, weight)
         ctx.shape = shp
         ctx.affine = weight is not None
+        ctx.sum_leaves = (weight, bias)
         ctx.set_materialize_grads(False)
         return xs.view(shp), y.view(shp)
 
@@ -830,7 +875,8 @@ class AddLayerNormFn(torch.autograd.Function):
             return dxs, dxs, None, None, None
         dy2d = dy.reshape(xs.shape).contiguous()
         dres = None if dxs is None else dxs.reshape(xs.shape).contiguous()
-        dx, dg, db = ops.layernorm_bwd(dy2d, xs, mean, rstd, weight, dres2d=dres, want_affine_grads=ctx.affine)
+        with sum_scope(*ctx.sum_leaves):
+            dx, dg, db = ops.layernorm_bwd(dy2d, xs, mean, rstd, weight, dres2d=dres, want_affine_grads=ctx.affine)
         dx = dx.view(ctx.shape)
         return dx, dx, dg, db, None
 
@@ -867,6 +913,7 @@ class NormQuantFn(torch.autograd.Function):
         xin = xs if xs is not None else x2d
         ctx.save_for_backward(xin, mean, rstd, weight, bias, s, b4)
         ctx.geom, ctx.shape, ctx.has_res = geom, shp, res is not None
+        ctx.sum_leaves = (weight, bias, s, b4, baft)
         ctx.mark_non_differentiable(codes)
         ctx.set_materialize_grads(False)
         first = xs.view(shp) if xs is not None else ops.placeholder(shp, x.device)
@@ -883,7 +930,8 @@ class NormQuantFn(torch.autograd.Function):
             return dxs, dxs, None, None, None, None, None, None, None
         gq = dxq.reshape(-1, C).contiguous()
         dres = None if dxs is None else dxs.reshape(-1, C).contiguous()
-        dx, dg, db, db4, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
+        with sum_scope(*ctx.sum_leaves):
+            dx, dg, db, db4, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
         dx = dx.view(shp)
         return (dx, dx if ctx.has_res else None, dg, (db if bias is not None else None), None, ds, db4, dba, None)
 

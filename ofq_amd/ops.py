@@ -100,8 +100,43 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+# ---- deferred second-stage sums (include/ofq_hip.h: ofq_sum_defer / ofq_sum_flush) ------------------------------------
+_SUM_DEFER = [False]
+_SUM_KEEP = []           # workspaces (per-workgroup partials) of the calls whose second stage is queued
+
+
+class deferred_sums:
+    """with ops.deferred_sums(): the backward kernels called inside queue their second-stage reductions (d step, d offset,
+    d gamma, d beta: parameter gradients) instead of launching them; ops.sum_flush() launches the queue, forty reductions
+    per launch.  Inside the block every ops.workspace() call gets a private buffer that lives until the flush.  The
+    caller guarantees that nothing reads those gradient outputs before the flush (functional._sums_deferrable)."""
+
+    def __enter__(self):
+        _SUM_DEFER[0] = True
+        lib().ofq_sum_defer(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ofq_sum_defer(0)
+        _SUM_DEFER[0] = False
+        return False
+
+
+def sum_flush():
+    """Launch every queued second-stage reduction (no-op when nothing is queued) and release the kept workspaces."""
+    try:
+        if _SUM_KEEP or lib().ofq_sum_pending():
+            _chk(lib().ofq_sum_flush(_stream()), "ofq_sum_flush")
+    finally:
+        del _SUM_KEEP[:]
+
+
 def workspace(nbytes, device):
     """Per-device scratch, grown on demand.  Kernels that use it are serialised on one stream."""
+    if _SUM_DEFER[0]:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _SUM_KEEP.append(buf)
+        return buf
     key = (device.index, _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from ... import functional as F_ofq
 from ... import ops
 
 
@@ -32,6 +33,7 @@ class _LsqFn(torch.autograd.Function):
         # fused: the spec this quantiser handed to the GEMM that produces x (fusable()); when that GEMM did not store x
         # (fused["producer"] present, x is a placeholder) the backward recomputes x from the producer's integer operands
         ctx.link = link
+        ctx.sum_leaves = (s, b4, baft)
         ctx.fused = fused if (fused is not None and pre_codes is not None and "producer" in fused) else None
         if link is not None:
             link.update(x=x, s=s, b4=b4, geom=geom)
@@ -66,9 +68,11 @@ class _LsqFn(torch.autograd.Function):
         if ctx.fused is not None:
             q = ctx.fused
             n_out = q["producer"]["wcodes"].shape[0]
-            dx, ds, db4, dbaft = ops.qgemm_i8_lsq_bwd(gy.view(-1, n_out), q["producer"], q)
+            with F_ofq.sum_scope(*ctx.sum_leaves):
+                dx, ds, db4, dbaft = ops.qgemm_i8_lsq_bwd(gy.view(-1, n_out), q["producer"], q)
             return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None, None
-        dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
+        with F_ofq.sum_scope(*ctx.sum_leaves):
+            dx, ds, db4, dbaft = ops.lsq_bwd(gy, x, s, b4, g)
         return dx.view(x.shape), ds, db4, dbaft, None, None, None, None, None, None
 
 

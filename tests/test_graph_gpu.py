@@ -133,6 +133,51 @@ def test_deferred_weight_gradients_equal_immediate():
         assert abs(x - y) < 1e-4 * abs(x), (res[False][1], res[True][1])
 
 
+@pytest.mark.parametrize("variant", ["deit_qkr", "deit_plain", "swin_qkr"])
+def test_deferred_second_stage_sums_equal_immediate(variant):
+    """Inside engine's step the second-stage reductions of the quantiser / LayerNorm backward kernels (d step, d offset,
+    d gamma, d beta) are queued in the library and launched forty at a time (ops.deferred_sums, ofq_sum_flush).  Every
+    gradient of the model must equal, bit for bit, the one the immediate launches give -- a gradient that was read before
+    its reduction ran (accumulated into, copied, viewed) would show up here as garbage -- for the QKR DeiT, the plain
+    DeiT and the Swin student, over a first step and a second one taken from the updated weights."""
+    from ofq_amd import engine, ops
+    import ofq_amd.functional as Fn
+    if variant == "swin_qkr":
+        torch.manual_seed(0)
+        base = engine.build_student("swin_t", 3, 3, qk_reparam=True).cuda()
+    else:
+        base = _tiny(qk_reparam=variant == "deit_qkr", depth=2)
+    b0 = _batch(seed=9)
+    engine.setup_alpha(base, b0[0])
+    res, queued = {}, {}
+    real_flush = ops.sum_flush
+    for defer in (False, True):
+        Fn.SUM_DEFER = defer
+        seen = [0]
+
+        def counting_flush():
+            seen[0] += ops.lib().ofq_sum_pending()
+            real_flush()
+        ops.sum_flush = counting_flush
+        try:
+            model = copy.deepcopy(base).train()
+            opt = engine.make_optimizer(model, lr=1e-4, weight_decay=0.05)
+            out = []
+            for _ in range(2):
+                engine.train_step(model, opt, *b0)
+                out.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            res[defer], queued[defer] = out, seen[0]
+        finally:
+            Fn.SUM_DEFER = True
+            ops.sum_flush = real_flush
+    assert queued[False] == 0 and queued[True] >= 20, queued
+    for step in range(2):
+        ga, gb = res[False][step], res[True][step]
+        assert ga.keys() == gb.keys()
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), (variant, step, n, float((ga[n] - gb[n]).abs().max()))
+
+
 def test_graph_replay_with_cga_hooks_equals_eager():
     """Config C5: QAttention_qkreparam_4_cga model, freeze masks recomputed from the weights inside every replay, mask and
     restore folded into the AdamW launch (cga.py:953-1013).  boundaryRange 0.05 so that a good share of weights freezes."""
