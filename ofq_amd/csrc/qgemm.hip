@@ -26,6 +26,7 @@ typedef float f32x16q __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+__device__ __forceinline__ bool al16_dev(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 struct QGemmArgs {
   const void* A; const void* B; float* C;
@@ -1070,10 +1071,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// W4: 64 x 256 tile, the four waves side by side (each 64 x 64) -- for outputs with at most 64 rows (dV: the rows are one
+// head's channels), where half of a 128 x 128 tile's waves had nothing to multiply and the 208 keys took two workgroups
+// that each staged (and split) the same dO panel: 1536 workgroups on 768 slots became 768.  The code operand then fills
+// two LDS planes (columns 0-127 / 128-255).  No column-sum by-product in this form.
+template <bool W4 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void qgemm_bf16s_tn_kernel(QTnArgs p) {
-  constexpr int BM = 128, BN = 128, NS = 3;
+  constexpr int BM = W4 ? 64 : 128, BN = W4 ? 256 : 128, NS = 3;
+  constexpr int NA = W4 ? 2 : 4, NB = W4 ? 2 : 1, AKS = W4 ? 16 : 8;      // staging chunks per thread, k rows between A chunks
   constexpr int PLANE = QTN_BK * QTN_LD;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(NS + 1) * PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(NS + NB) * PLANE];
   const int ntiles = p.tiles_m * p.tiles_n;
   // XCD-aware order: block b runs on XCD b % 8; give each XCD a contiguous run of logical ids so that the tiles which
   // share one dY panel (same split, same tm, all tn) hit the same L2 instead of re-fetching the panel per XCD
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = W4 ? 0 : wid >> 1, wn = W4 ? wid : wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
   const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const bool direct = p.C != nullptr;
@@ -1093,32 +1100,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
 
   // staging maps
-  const int a_k = tid >> 5, a_t = (tid & 31) * 4;          // + 8*i rows
+  const int a_k = W4 ? tid >> 4 : tid >> 5, a_t = W4 ? (tid & 15) * 4 : (tid & 31) * 4;          // + AKS*i rows
   const int b_k = tid >> 3, b_c = (tid & 7) * 16;
   const bool a_ok = (m0 + a_t) < p.M;                      // M % 4 == 0 (host check)
-  const bool b_ok = (n0 + b_c) < p.N;                      // N % 16 == 0
+  bool b_ok[NB];                                           // N % 16 == 0
+#pragma unroll
+  for (int c = 0; c < NB; ++c) b_ok[c] = (n0 + b_c + 128 * c) < p.N;
   const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1 + (a_ok ? m0 + a_t : 0);
-  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1 + (b_ok ? n0 + b_c : 0);
+  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1 + n0 + b_c;
   // gload only issues the loads; masks, the effective step, the column sums and the split happen at the LDS store of
   // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
-  f32x4v ra[4];
-  float rs[4];
-  i32x4 rb;
-  bool rok[4], rbok = false;
+  f32x4v ra[NA];
+  float rs[NA];
+  i32x4 rb[NB];
+  bool rok[NA], rbok[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) rbok[c] = false;
   float4 csacc = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of the raw dY (bias gradient), tn == 0 tiles only
-  const bool do_csum = direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0);
+  const bool do_csum = !W4 && (direct ? (p.baft != nullptr) : (p.csum != nullptr && tn == 0));
   // token index modulo S, kept incrementally (gload runs on consecutive k-steps): the integer modulo is ~22 VALU
   // instructions, four of them per k-step were a third of this kernel's staging work
   const bool kmod_inc = p.S >= QTN_BK;
-  int kmod[4];
+  int kmod[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) kmod[i] = (t_begin * QTN_BK + a_k + 8 * i) % p.S;
+  for (int i = 0; i < NA; ++i) kmod[i] = (t_begin * QTN_BK + a_k + AKS * i) % p.S;
   auto gload = [&](int kt_) {
     const bool live = kt_ < t_end;                  // past the end: repeat the last tile, masked out of the column sums
     const int k0 = min(kt_, t_end - 1) * QTN_BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + a_k + 8 * i;
+    for (int i = 0; i < NA; ++i) {
+      const int k = k0 + a_k + AKS * i;
       const int kc = min(k, p.Ktok - 1);
       ra[i] = *reinterpret_cast<const f32x4v*>(Ap + (int64_t)kc * p.lda);
       rs[i] = p.s[kmod_inc ? kmod[i] : kc % p.S];
@@ -1127,15 +1138,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       rok[i] = a_ok && k < p.Ktok && live;
     }
     const int k = k0 + b_k;
-    rb = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb);
-    rbok = b_ok && k < p.Ktok;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      rb[c] = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb + (b_ok[c] ? 128 * c : 0));
+      rbok[c] = b_ok[c] && k < p.Ktok;
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[i]), "+v"(rs[i]));
-    asm volatile("" : "+v"(rb));
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[i]), "+v"(rs[i]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(rb[c]));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
       const unsigned msk = rok[i] ? 0xffffffffu : 0u;
       float4 v;
       v.x = __uint_as_float(__float_as_uint(ra[i][0]) & msk);
@@ -1153,21 +1168,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         uint2 w;
         w.x = lo[q];
         w.y = hi[q];
-        *reinterpret_cast<uint2*>(&smem[q * PLANE + (a_k + 8 * i) * QTN_LD + a_t * 2]) = w;
+        *reinterpret_cast<uint2*>(&smem[q * PLANE + (a_k + AKS * i) * QTN_LD + a_t * 2]) = w;
       }
     }
     // 16 int8 codes -> 16 bf16
-    const i32x4 rbm = rb & (rbok ? -1 : 0);
-    unsigned w[8];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int word = rbm[d];
-      w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
-      w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
+    for (int c = 0; c < NB; ++c) {
+      const i32x4 rbm = rb[c] & (rbok[c] ? -1 : 0);
+      unsigned w[8];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int word = rbm[d];
+        w[2 * d] = i8x2_to_bf16x2((int)(signed char)(word & 0xff), (int)(signed char)((word >> 8) & 0xff));
+        w[2 * d + 1] = i8x2_to_bf16x2((int)(signed char)((word >> 16) & 0xff), (int)(signed char)((word >> 24) & 0xff));
+      }
+      unsigned char* dst = &smem[(NS + c) * PLANE + b_k * QTN_LD + b_c * 2];
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
     }
-    unsigned char* dst = &smem[NS * PLANE + b_k * QTN_LD + b_c * 2];
-    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<uint4*>(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
   };
 
   f32x16q acc[2][2];
@@ -1197,7 +1215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bf16x8 bv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          bv[j] = tr_frag(&smem[NS * PLANE + ks * 16 * QTN_LD + fr_off + (wn * 64 + j * 32) * 2]);
+          bv[j] = tr_frag(&smem[(NS + (W4 ? wn >> 1 : 0)) * PLANE + ks * 16 * QTN_LD + fr_off + ((W4 ? wn & 1 : wn) * 64 + j * 32) * 2]);
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           bf16x8 av[2];
@@ -1250,11 +1268,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   if (direct) {
     float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
+    // transposed output (dV: C[n][m], m = the head's channels): a lane holds four consecutive m per accumulator quad, so
+    // the row piece goes out as one 16-byte store instead of four dword stores that each touch 64 different lines
+    const bool quad_ok = p.trans_out && (p.Mstore & 3) == 0 && (p.ldc & 3) == 0 && ((p.sC0 | p.sC1) & 3) == 0 && al16_dev(p.C);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + l31;
       if (n >= p.Nstore) continue;
       const float bf = p.baft ? p.baft[n + b1 * p.sBf1] : 0.f;
+      if (quad_ok) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ml = wm * 64 + i * 32 + 8 * k + 4 * lh;
+            const int m = m0 + ml;
+            if (m < p.Mstore) {
+              float4 v = make_float4(acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]);
+              if (p.baft) { v.x += red1[ml] * bf; v.y += red1[ml + 1] * bf; v.z += red1[ml + 2] * bf; v.w += red1[ml + 3] * bf; }
+              *reinterpret_cast<float4*>(&Cb[(int64_t)n * p.ldc + m]) = v;
+            }
+          }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2435,7 +2471,7 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
       hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<2>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
     }
   } else {
-    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   }
   OFQ_LAUNCH_CHECK();
   static const bool red_rows = getenv("OFQ_TN_REDUCE_ROWS") != nullptr;      // A/B switch (tools/)
@@ -4208,9 +4244,18 @@ extern "C" int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* 
   a.M = (int)d; a.N = (int)Np; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
   a.Mstore = (int)d; a.Nstore = (int)N; a.trans_out = 1; a.gscale = gscale_p;
   a.tiles_m = (int)ceil_div(d, 128); a.tiles_n = (int)ceil_div(Np, 128);
-  if (!tn_win_launch(a, B * H, (hipStream_t)stream))     // Swin windows: one wave per (window, head)
-    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+  if (tn_win_launch(a, B * H, (hipStream_t)stream)) {     // Swin windows: one wave per (window, head)
+    OFQ_LAUNCH_CHECK();
+    return 0;
+  }
+  static const bool no_w4 = getenv("OFQ_DV_NO_W4") != nullptr;       // A/B switch
+  if (d <= 64 && Np > 128 && !no_w4) {       // one head's channels x all keys: 64 x 256 tiles, four waves side by side
+    a.tiles_m = 1; a.tiles_n = (int)ceil_div(Np, 256);
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<true>, dim3((unsigned)a.tiles_n, (unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                        (hipStream_t)stream, a);
+  }
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -4251,7 +4296,7 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
     OFQ_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+  hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                      (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
@@ -4286,7 +4331,7 @@ extern "C" int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, f
   a.Mstore = (int)N; a.Nstore = (int)d; a.trans_out = 0; a.gscale = gscale_q;
   a.tiles_m = (int)ceil_div(ldS, 128); a.tiles_n = (int)ceil_div(d, 128);
   if (!tn_win_launch(a, B * H, (hipStream_t)stream))
-    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
+    hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(256), 0,
                        (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
