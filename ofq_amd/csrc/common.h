@@ -253,18 +253,21 @@ static inline void strided_sum_launch(const SumJobs& jobs, int64_t maxcols, int 
     if (jobs.j[i].ncols > mc) mc = jobs.j[i].ncols;
   }
   (void)maxcols;
+  // 64 columns per workgroup (one 256-B line per partial row) only when that still gives every CU a workgroup: the
+  // qkx recompute-backward's three jobs (2304 columns x 197 partial rows) ran as 108 workgroups, 16 us for 3.6 MB
+  const bool wide = rest_cols > 2048 && ceil_div(rest_cols, 64) * njobs >= 256;
   SumDeferState& ds = sum_defer_state();
   if (ds.on) {
     for (int i = 0; i < njobs; ++i) {
       if (deep.j[i].dst) ds.pend.push_back({deep.j[i], 4});
-      if (rest.j[i].dst) ds.pend.push_back({rest.j[i], rest_cols > 2048 ? 64 : 16});
+      if (rest.j[i].dst) ds.pend.push_back({rest.j[i], wide ? 64 : 16});
     }
     return;
   }
   if (deep_cols > 0)
     hipLaunchKernelGGL(strided_sum_kernel_t<4>, dim3((unsigned)ceil_div(deep_cols, 4), njobs), dim3(1024), 0, st, deep);
   if (rest_cols <= 0) return;
-  if (rest_cols > 2048)
+  if (wide)
     hipLaunchKernelGGL(strided_sum_kernel_t<64>, dim3((unsigned)ceil_div(rest_cols, 64), njobs), dim3(1024), 0, st, rest);
   else
     hipLaunchKernelGGL(strided_sum_kernel_t<16>, dim3((unsigned)ceil_div(rest_cols, 16), njobs), dim3(1024), 0, st, rest);

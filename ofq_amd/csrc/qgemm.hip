@@ -345,14 +345,18 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
 template <int EPI, int T = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
   static_assert(T == 2 || EPI != 0, "the linear-layer epilogue is written for 128 x 128 tiles");
-  constexpr int BM = 64 * T, BN = 64 * T;
+  // T = 3 ("tall"): 256 x 64 tile, the four waves stacked (each 64 x 64) -- P.V, whose output has one head's 64 channels:
+  // a 128 x 128 tile there leaves two of the four waves without columns and takes two workgroups per (batch, head)
+  constexpr bool TALL = T == 3;
+  constexpr int TT = TALL ? 2 : T;                       // 32 x 32 blocks per wave and direction
+  constexpr int BM = TALL ? 256 : 64 * T, BN = TALL ? 64 : 64 * T;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
   I8_T(0);
   int tm, tn, gby;
   qgemm_tile_id(p, tm, tn, gby);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = TALL ? wid : wid >> 1, wn = TALL ? 0 : wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
   const int b0 = gby / p.nb1, b1 = gby % p.nb1;
   const unsigned char* A = (const unsigned char*)p.A + b0 * p.sA0 + b1 * p.sA1;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
   // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
   // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
   // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
-  float pre_ra, pre_rb = 0.f, pre_c[T][5];
+  float pre_ra, pre_rb = 0.f, pre_c[TT][5];
   {
     const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
     pre_ra = p.s[m % p.S];
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
     if (EPI == 0) {
 #pragma unroll
-      for (int j = 0; j < T; ++j) {
-        const int nc = min(n0 + wn * 32 * T + j * 32 + l31, p.N - 1);
+      for (int j = 0; j < TT; ++j) {
+        const int nc = min(n0 + wn * 32 * TT + j * 32 + l31, p.N - 1);
         pre_c[j][0] = p.cs[nc];
         pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
         pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
@@ -385,13 +389,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     }
   }
 
-  i32x16 acc[T][T];
-  i8_mainloop<T>(p, A, B, m0, n0, smem, acc);
+  i32x16 acc[TT][TT];
+  if constexpr (TALL) i8_mainloop_g<4, 1, 4, 2, 2>(p, A, B, m0, n0, smem, acc);
+  else i8_mainloop<T>(p, A, B, m0, n0, smem, acc);
   I8_T(2);
   float* Cb = p.C + b0 * p.sC0 + b1 * p.sC1;
-  int ncol[T];
+  int ncol[TT];
 #pragma unroll
-  for (int j = 0; j < T; ++j) ncol[j] = n0 + wn * 32 * T + j * 32 + l31;
+  for (int j = 0; j < TT; ++j) ncol[j] = n0 + wn * 32 * TT + j * 32 + l31;
   // per-row epilogue terms of the 128 tile rows go through LDS once (the k-loop's last barrier has released smem):
   // row_a = effective LSQ step of the row, row_b = the row's offset term (u / rp); every lane then reads 32 of them as
   // broadcasts instead of issuing 32 dependent global loads + integer modulos
@@ -466,47 +471,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
     I8_T(5);
   } else if constexpr (EPI == 1) {
     // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
-    float aq[T], tqa[T];
+    float aq[TT], tqa[TT];
     const float zz = p.z[b1];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
+    for (int j = 0; j < TT; ++j) {
       const int nc = min(ncol[j], p.N - 1);
       aq[j] = ofq_lsq_eff_scale(p.s2[nc * p.s2s0 + b1 * p.s2s1], p.gscale2);
       tqa[j] = __fadd_rn(__fmul_rn(aq[j], p.tq[((int64_t)b0 * p.N + nc) * p.nb1 + b1]), zz);
     }
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 32 * T + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 * TT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
         const float ax = row_a[m - m0];
         const float uu = row_b[m - m0];
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < TT; ++j)
           if (ncol[j] < p.N)
             Cb[(int64_t)m * p.ldc + ncol[j]] =
                 __fadd_rn(__fmul_rn(ax, __fadd_rn(__fmul_rn(aq[j], (float)acc[i][j][e]), uu)), tqa[j]);
       }
   } else {
     // O[n,c] = ap[n] * (av[c] * I + bav[c] * rp[n])                                 (P_hat . V_hat, attention.py:219)
-    float av[T], bv2[T];
+    float av[TT], bv2[TT];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
+    for (int j = 0; j < TT; ++j) {
       const int nc = min(ncol[j], p.N - 1) + b1 * p.N;
       av[j] = ofq_lsq_eff_scale(p.s2[nc], p.gscale2);
       bv2[j] = p.z ? p.z[nc] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 32 * T + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 * TT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (m >= p.M) continue;
         const float ap = row_a[m - m0];
         const float rpm = row_b[m - m0];
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < TT; ++j)
           if (ncol[j] < p.N)
             Cb[(int64_t)m * p.ldc + ncol[j]] =
                 __fmul_rn(ap, __fadd_rn(__fmul_rn(av[j], (float)acc[i][j][e]), __fmul_rn(bv2[j], rpm)));
@@ -4018,9 +4023,13 @@ extern "C" int ofq_rowdot_f32_seg(const float* x, const float* vec, float* out, 
 template <int EPI>
 static void i8_attn_launch(QGemmArgs& a, int64_t M, int64_t N, int64_t batches, hipStream_t st) {
   static const bool no_small = getenv("OFQ_NO_SMALL_TILES") != nullptr;          // A/B switch (tools/)
+  static const bool no_tall = getenv("OFQ_NO_TALL_TILES") != nullptr;            // A/B switch
   if (M <= 64 && N <= 64 && !no_small) {
     a.tiles_m = a.tiles_n = 1;
     hipLaunchKernelGGL((qgemm_i8_nt_kernel<EPI, 1>), dim3(1u, (unsigned)batches), dim3(256), 0, st, a);
+  } else if (EPI == 2 && N <= 64 && M > 128 && !no_tall) {     // P.V of a long sequence: 256 x 64 tiles, four waves stacked
+    a.tiles_m = (int)ceil_div(M, 256); a.tiles_n = 1;
+    hipLaunchKernelGGL((qgemm_i8_nt_kernel<EPI, 3>), dim3((unsigned)a.tiles_m, (unsigned)batches), dim3(256), 0, st, a);
   } else {
     a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128);
     hipLaunchKernelGGL((qgemm_i8_nt_kernel<EPI, 2>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)batches), dim3(256), 0, st, a);
