@@ -347,7 +347,8 @@ int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n
  *  queued on the host instead of launched; ofq_sum_flush launches everything queued, up to 40 reductions per launch, each
  *  with the lane layout its own launch would have used (the result is the immediate one bit for bit).  The caller keeps
  *  the workspaces of the queued calls alive and untouched until the flush, and nothing may read their ds / db outputs
- *  before it.  ofq_sum_pending: number of queued reductions.  Host state is per process (one process per GPU). */
+ *  before it.  ofq_sum_pending: number of queued reductions; ofq_sum_defer(-1) discards the queue without launching
+ *  (a backward pass that raised).  Host state is per process (one process per GPU). */
 void ofq_sum_defer(int on);
 int ofq_sum_pending(void);
 int ofq_sum_flush(ofq_stream_t stream);

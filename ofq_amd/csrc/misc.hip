@@ -270,7 +270,15 @@ extern "C" int ofq_permute_tokens(const float* x, const int32_t* idx, float* y, 
 // Deferred second-stage sums (common.h: SumDeferState).  ofq_sum_defer(1) ... ofq_sum_defer(0) brackets the calls whose
 // second stage may wait; ofq_sum_flush launches everything queued so far, up to OFQ_SUM_MULTI jobs per launch and lane
 // layout.  Host state is per process (one process per GPU, launches serialised on one stream).
-extern "C" void ofq_sum_defer(int on) { sum_defer_state().on = on != 0; }
+extern "C" void ofq_sum_defer(int on) {
+  SumDeferState& ds = sum_defer_state();
+  if (on < 0) {            // a backward pass that failed: forget what was queued (its outputs may be gone already)
+    ds.pend.clear();
+    ds.on = false;
+    return;
+  }
+  ds.on = on != 0;
+}
 extern "C" int ofq_sum_pending(void) { return (int)sum_defer_state().pend.size(); }
 extern "C" int ofq_sum_flush(ofq_stream_t stream) {
   SumDeferState& ds = sum_defer_state();

@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int c = 0; c < NB; ++c) b_ok[c] = (n0 + b_c + 128 * c) < p.N;
   const float* Ap = p.A + b0 * p.sA0 + b1 * p.sA1 + (a_ok ? m0 + a_t : 0);
-  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1 + n0 + b_c;
+  const int8_t* Bp = p.B + b0 * p.sB0 + b1 * p.sB1;          // (+ the chunk's column, or column 0 for a chunk past N: never read past a row)
   // gload only issues the loads; masks, the effective step, the column sums and the split happen at the LDS store of
   // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
   f32x4v ra[NA];
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int k = k0 + b_k;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      rb[c] = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb + (b_ok[c] ? 128 * c : 0));
+      rb[c] = *reinterpret_cast<const i32x4*>(Bp + (int64_t)min(k, p.Ktok - 1) * p.ldb + (b_ok[c] ? n0 + b_c + 128 * c : 0));
       rbok[c] = b_ok[c] && k < p.Ktok;
     }
   };

@@ -92,7 +92,9 @@ def _sums_deferrable(*leaves):
     for t in leaves:
         if t is None:
             continue
-        if not t.is_leaf or t.grad is not None:
+        # (a leaf that does not require a gradient: autograd drops the returned tensor at once, and the queued kernel
+        # would write into memory that has been handed to somebody else by then)
+        if not t.is_leaf or not t.requires_grad or t.grad is not None:
             return False
     return True
 
@@ -132,10 +134,7 @@ def drop_dw():
     """Forget the queue (a backward pass that raised)."""
     del _DW_QUEUE[:]
     _DW_TILES[0] = 0
-    try:
-        ops.sum_flush()           # (the queued reductions only touch buffers that are still alive: launching them is harmless)
-    except Exception:  # noqa: BLE001
-        pass
+    ops.sum_drop()
 
 
 def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):

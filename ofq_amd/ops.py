@@ -131,6 +131,14 @@ def sum_flush():
         del _SUM_KEEP[:]
 
 
+def sum_drop():
+    """Forget the queued reductions without launching them (a backward pass that raised: the tensors they would write may
+    have been released already)."""
+    lib().ofq_sum_defer(-1)
+    _SUM_DEFER[0] = False
+    del _SUM_KEEP[:]
+
+
 def workspace(nbytes, device):
     """Per-device scratch, grown on demand.  Kernels that use it are serialised on one stream."""
     if _SUM_DEFER[0]:
