@@ -411,6 +411,43 @@ def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)
 
 
+@pytest.mark.parametrize("dims", [(396, 64, 64), (198, 32, 208), (396, 200, 80)])
+def test_narrow_tn_kernel_reads_stay_inside_its_operands(ops, dims):
+    """Operands narrower than a 128-column tile (the golden attention shapes: 64 channels, 32-channel heads): the staging
+    chunks past the last column / row have to be read from inside the matrix.  Both operands sit at the very END of
+    their own 32 MiB allocations (the caching allocator gives a request of that size a segment of exactly that size), so
+    a read past the last row can leave the mapping -- the way the full GPU suite once caught a dropped clamp, as an
+    order-dependent abort; the values are checked as well (qlinear.py:69 under autograd: dW of a quantised linear layer,
+    and the same kernel as dV of the attention core)."""
+    Ktok, Mo, Nc = dims
+    rs = np.random.RandomState(17)
+    big_c = torch.empty(32 << 20, dtype=torch.int8, device="cuda")
+    big_y = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    codes = big_c[-Ktok * Nc:].view(Ktok, Nc)
+    dy = big_y[-Ktok * Mo:].view(Ktok, Mo)
+    codes.copy_(torch.from_numpy(rs.randint(-2, 2, (Ktok, Nc)).astype(np.int8)))
+    dy.copy_(T(det_normalish((Ktok, Mo), 31, 1.0)))
+    S = 198
+    s = T(det_uniform((S,), 33, 0.1, 1.0)).cuda()
+    baft = T(det_uniform((Nc,), 34, -0.05, 0.05)).cuda()
+    ae = O.lsq_effective_scale(s.cpu(), 0.01)[torch.arange(Ktok) % S].double()
+    db = dy.double().sum(0).float()
+    ref = (dy.cpu().double() * ae[:, None]).t() @ codes.cpu().double() + db.cpu().double()[:, None] * baft.cpu().double()[None, :]
+    den = ((dy.cpu().double() * ae[:, None]).abs().t() @ codes.cpu().double().abs()) + 1e-30
+    for split in (1, 3):
+        dW = ops.qgemm_bf16s_tn(dy, codes, s, S, 0.01, db, baft, split=split)
+        torch.cuda.synchronize()
+        assert float(((dW.cpu().double() - ref).abs() / den).max()) < 1e-6, split
+    if Mo <= 64 and Nc > 128:        # the dV form of the same kernel (one head: d channels x Np keys), 64 x 256 tiles
+        B, H, N, d, Np = 1, 1, Ktok, Mo, Nc
+        sp = T(det_uniform((N,), 35, 0.01, 0.1)).cuda()
+        dV = ops.qattn_dv(dy.view(B, N, d), codes.view(B, H, N, Np), sp, 0.01, B, H, N, d, Np)
+        torch.cuda.synchronize()
+        ap = O.lsq_effective_scale(sp.cpu(), 0.01).double()
+        want = codes.cpu().double()[:, :N].t() @ (dy.cpu().double() * ap[:, None])
+        assert rel_err(dV.cpu().view(N, d), want.float()) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(792, 384, 384), (1188, 1536, 384), (396, 384, 1536), (500, 72, 48), (2000, 2304, 384),
                                    (700, 96, 192), (640, 384, 768), (900, 200, 144)])
 def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
