@@ -1065,6 +1065,11 @@ struct QTnArgs {
   int64_t sA0, sA1, sB0, sB1, sC0, sC1;
   int M, N, Ktok, S, split, tiles_m, tiles_n, nb1, Mstore, Nstore, trans_out;
   float gscale;
+  // stream kernel, stacked form (dqkx): the output rows of the stk_h inner batch entries (heads) are laid end to end,
+  // stk_mp rows apiece (stk_valid of them real), and tiled as ONE matrix of stk_h * stk_mp rows -- the heads share the B
+  // operand.  Row r belongs to head r / stk_mp = (r * stk_magic) >> 20 (host-verified for every row of the launch).
+  int stk_mp, stk_h, stk_valid;
+  unsigned stk_magic;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
@@ -1940,7 +1945,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
 // of the finished 128 x 384 tile) and nothing else -- no pipeline drain, no fresh memory round trip.  The one-tile-per-
 // workgroup launch of the same problem (1536 workgroups of 7 k-steps on 256 CUs: six rounds of prologue + 7 steps +
 // epilogue) took 178 us per DeiT-S block for 35 us of MFMA work.
-template <int NJ>
+template <int NJ, bool STK = false>
 __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int chunk, const int b0, const int tpw) {
   constexpr int BM = 128, BN = 128 * NJ, NS = 3;
   constexpr int LDA = QTN_LD;
@@ -1950,6 +1955,8 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   constexpr int CPR = BN / 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   __shared__ __attribute__((aligned(16))) float sred[16 * 32 * 4 + BM + BN];   // column sums of a finished tile, its offsets
+  __shared__ int srow[BM + 4];      // STK: element offset of every tile row inside the image's slab of C (-1: no such row), then
+                                    // per 32-row block: 1 when the block is one head's 32 consecutive real rows
   const int tpi = p.tiles_m * p.tiles_n;                 // tiles per inner batch entry
   const int T = tpi * p.nb1;
   const int q0 = chunk * tpw, q1 = min(T, q0 + tpw);
@@ -1987,10 +1994,19 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
     const int qc = min(q, q1 - 1);
     const int b1 = qc / tpi, t = qc - b1 * tpi;
     const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
-    la_ok = (m0 + a_t) < p.M;
-    LAs = reinterpret_cast<const char*>(p.A + b0 * p.sA0 + b1 * p.sA1 + m0);
+    if constexpr (STK) {        // this lane's column quad = rows r .. r + 3 of the stacked output: head h, key m (stk_mp % 4 == 0)
+      const int r = m0 + a_t;
+      const int h = (int)(((unsigned)r * p.stk_magic) >> 20);
+      const int m = r - h * p.stk_mp;
+      la_ok = h < p.stk_h;
+      LAs = reinterpret_cast<const char*>(p.A + b0 * p.sA0);
+      colA = la_ok ? 4u * (unsigned)(h * (int)p.sA1 + m) : 0u;
+    } else {
+      la_ok = (m0 + a_t) < p.M;
+      LAs = reinterpret_cast<const char*>(p.A + b0 * p.sA0 + b1 * p.sA1 + m0);
+      colA = la_ok ? 4u * (unsigned)a_t : 0u;
+    }
     LBs = reinterpret_cast<const char*>(p.B + b0 * p.sB0 + b1 * p.sB1 + n0);
-    colA = la_ok ? 4u * (unsigned)a_t : 0u;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) colB[j] = (n0 + b_col[j]) < p.N ? (unsigned)b_col[j] : 0u;
   };
@@ -2194,18 +2210,52 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
     // of the k-step stream and cost 60+ live VGPRs there (the kernel spilled 170 registers)
     int l31e = l31, lhe = lh;
     asm volatile("" : "+v"(l31e), "+v"(lhe));
-    float* Cs = p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m0 * p.ldc + n0;
+    float* Cs = STK ? p.C + b0 * p.sC0 + n0 : p.C + b0 * p.sC0 + b1 * p.sC1 + (int64_t)m0 * p.ldc + n0;
     const int ldc = (int)p.ldc;
     const bool full_n = (n0 + BN) <= p.Nstore;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rv = p.Mstore - (m0 + wm * 64 + i * 32);   // valid rows of this wave's 32-row block (wave-uniform)
+      int rv = p.Mstore - (m0 + wm * 64 + i * 32);         // valid rows of this wave's 32-row block (wave-uniform)
+      int blk_base = 0;
+      if constexpr (STK) {      // srow was filled before the tile's last barrier (pre()): whole block of one head -> its base
+        const int whole = __builtin_amdgcn_readfirstlane(srow[BM + wm * 2 + i]);
+        blk_base = __builtin_amdgcn_readfirstlane(srow[wm * 64 + i * 32]);
+        rv = whole ? 32 : 1;                               // (1: take the row-by-row path below)
+      }
       if (rv <= 0) continue;                               // all padding: its MFMAs were skipped, acc stayed zero
       float rsum[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         rsum[e] = p.baft ? red1[wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhe] : 0.f;
-      if (full_n && rv >= 32) {                            // interior block: straight stores
+      if (STK && full_n && rv >= 32) {                     // one head's 32 consecutive rows: uniform base, straight stores
+        float* Cb = Cs + blk_base;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn * 32 * NJ + j * 32 + l31e;
+          const float bf = p.baft ? sbf[nl] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int mr = (e & 3) + 8 * (e >> 2) + 4 * lhe;
+            Cb[mr * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+        }
+      } else if (STK) {                                    // a block that straddles two heads or holds pad rows
+        int off[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) off[e] = srow[wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhe];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int nl = wn * 32 * NJ + j * 32 + l31e;
+          const bool nok = (n0 + nl) < p.Nstore;
+          const float bf = p.baft ? sbf[nl] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if (nok && off[e] >= 0) Cs[off[e] + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            acc[i][j][e] = 0.f;
+          }
+        }
+      } else if (full_n && rv >= 32) {                     // interior block: straight stores
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int nl = wn * 32 * NJ + j * 32 + l31e;
@@ -2257,6 +2307,19 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
       // (sred is free: the previous tile's epilogue ended with an LDS barrier; this step's barrier publishes the stores)
       reinterpret_cast<float4*>(sred)[a_k * 32 + (tid & 31)] = make_float4(cs[0], cs[1], cs[2], cs[3]);
       if (p.baft && tid < BN) sred[16 * 32 * 4 + BM + tid] = bf_reg;
+      if constexpr (STK) {
+        if (tid < BM) {
+          const int m0c = ((cq % tpi) / p.tiles_n) * BM;
+          const int r = m0c + tid;
+          const int h = (int)(((unsigned)r * p.stk_magic) >> 20), m = r - h * p.stk_mp;
+          srow[tid] = (h < p.stk_h && m < p.stk_valid) ? h * (int)p.sC1 + m * (int)p.ldc : -1;
+          if ((tid & 31) == 0) {
+            const int r1 = r + 31;
+            const int h1 = (int)(((unsigned)r1 * p.stk_magic) >> 20), m1 = r1 - h1 * p.stk_mp;
+            srow[BM + (tid >> 5)] = (h1 == h && h < p.stk_h && m1 < p.stk_valid) ? 1 : 0;
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) cs[e] = 0.f;
     }
@@ -2286,7 +2349,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   }
 }
 
-template <int NJ>
+template <int NJ, bool STK = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_stream_kernel(QTnArgs p, int tpw, int stagger) {
   int chunk, b0;
   xcd_remap_grid(chunk, b0);
@@ -2299,7 +2362,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_stream_kernel(QTnArgs
     const int phase = (blockIdx.y * gridDim.x + blockIdx.x) % stagger;
     for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(70);           // ~2.2 us each (64 x 70 clocks)
   }
-  tn_wide_stream_body<NJ>(p, chunk, b0, tpw);
+  tn_wide_stream_body<NJ, STK>(p, chunk, b0, tpw);
 }
 
 // Several split-K problems in one launch.  The weight-gradient GEMMs of the linear layers have no consumer before the
@@ -4286,7 +4349,23 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
   if (C % 384 == 0 && N >= QTN_BK && !narrow_only && N * ldS < (1ll << 31) && N * C < (1ll << 31)) {
     a.tiles_n = (int)(C / 384);       // one split of a dS panel feeds all 384 columns
     static const bool no_stream = getenv("OFQ_TN_NO_STREAM") != nullptr;      // A/B switch
-    const int64_t T = (int64_t)a.tiles_m * a.tiles_n * H;                     // tiles per image
+    static const bool no_stack = getenv("OFQ_TN_NO_STACK") != nullptr;        // A/B switch
+    int64_t T = (int64_t)a.tiles_m * a.tiles_n * H;                           // tiles per image
+    // Stacked form: the H heads share the B operand (x_hat of the image), so their ldS-row outputs are tiled as one
+    // (H ldS)-row matrix: 10 tiles of 128 rows per DeiT-S image instead of 6 x 2 whose second one holds 69 rows.
+    bool stacked = false;
+    if (!no_stream && !no_stack && a.tiles_n == 1 && H > 1 && ceil_div(H * ldS, 128) < (int64_t)a.tiles_m * H && H * ldS < 2048 &&
+        H * N * ldS * 4 < (1ll << 31) && (N * H + H) * C < (1ll << 29)) {
+      const unsigned magic = (unsigned)(((1u << 20) + ldS - 1) / ldS);
+      bool ok = true;
+      for (int64_t r = 0; r < ceil_div(H * ldS, 128) * 128 + 32 && ok; ++r) ok = (int64_t)(((unsigned)r * magic) >> 20) == r / ldS;
+      if (ok) {
+        stacked = true;
+        a.stk_mp = (int)ldS; a.stk_h = (int)H; a.stk_valid = (int)N; a.stk_magic = magic;
+        a.M = (int)(H * ldS); a.Mstore = a.M; a.nb1 = 1; a.tiles_m = (int)ceil_div(H * ldS, 128);
+        T = a.tiles_m;
+      }
+    }
     if (!no_stream && T >= 2) {
       // persistent workgroups: each walks `tpw` tiles of one image (about one workgroup per CU in total)
       int64_t tpw = (B * T) / 256;
@@ -4295,8 +4374,12 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
       while (T % tpw) --tpw;                                                  // equal chunks
       int stagger = 0;                                                      // measured: 121 us without, 149 us with a 6-phase shift
       if (const char* e = getenv("OFQ_TN_STREAM_STAGGER")) stagger = atoi(e);  // A/B switch
-      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_stream_kernel<3>, dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
-                         (hipStream_t)stream, a, (int)tpw, stagger);
+      if (stacked)
+        hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, true>), dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
+                           (hipStream_t)stream, a, (int)tpw, stagger);
+      else
+        hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, false>), dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
+                           (hipStream_t)stream, a, (int)tpw, stagger);
       OFQ_LAUNCH_CHECK();
       return 0;
     }
