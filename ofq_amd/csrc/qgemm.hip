@@ -2283,7 +2283,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
         }
       }
     }
-    if (p.baft) lds_barrier();      // sred / red1 / sbf are rewritten during the next tile
+    if (p.baft || STK) lds_barrier();      // sred / red1 / sbf / srow are rewritten during the next tile (at its last k-step: its first one when K <= 32)
   };
 
   gload(Slot0());
