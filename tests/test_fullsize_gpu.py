@@ -278,3 +278,48 @@ def test_swin_shift_mask_is_cached_and_correct(ops):
     assert torch.equal(m1, swin._shift_attention_mask(56, 56, [7, 7], [3, 3], torch.device("cuda")))
     assert set(m1.unique().tolist()) == {-100.0, 0.0}
 
+
+
+def test_qkr_attention_products_full_size_on_sampled_images(ops):
+    """The attention products whose tiling follows the head structure, at the headline size (128 images, 6 heads, 197 tokens,
+    C = 384, rows padded to 208): dqkx on the head-stacked persistent kernel (five 128-row tiles of the 1248 stacked rows
+    per workgroup), dV on 64 x 256 tiles, P.V on 256 x 64 tiles -- each against an fp64 product of the fake-quantised
+    operands for four sampled images (attention.py:210 / :219 under autograd).  The pad columns of dS and of the P codes
+    hold garbage / zeros respectively, as in the step."""
+    Bf, Hf, Nf, Cf = 128, 6, 197, 384
+    d, Np = Cf // Hf, 208
+    g = torch.Generator(device="cuda").manual_seed(7)
+    dS = torch.empty(Bf, Hf, Nf, Np, device="cuda")
+    dS[..., :Nf] = torch.randn(Bf, Hf, Nf, Nf, device="cuda", generator=g) * 1e-2
+    dS[..., Nf:] = float("nan")                                    # never read into a stored row
+    xc = torch.randint(-2, 2, (Bf, Nf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    sx = torch.rand(Nf, device="cuda", generator=g) * 0.3 + 0.05
+    bax = torch.randn(Cf, device="cuda", generator=g) * 0.05
+    dq = ops.qattn_dqkx(dS, xc, sx, 0.01, bax, Bf, Hf, Nf, Cf, Np)
+    ax = O.lsq_effective_scale(sx.cpu(), 0.01).double()
+    for b in (0, 37, 90, 127):
+        xh = ax[:, None] * xc[b].cpu().double() + bax.cpu().double()[None, :]                    # (N, C)
+        want = torch.einsum("hnm,nc->mhc", dS[b, :, :, :Nf].cpu().double(), xh)                   # (N, H, C)
+        den = torch.einsum("hnm,nc->mhc", dS[b, :, :, :Nf].cpu().double().abs(), xh.abs()) + 1e-30
+        assert float(((dq[b].cpu().double() - want).abs() / den).max()) < 1e-6, b
+    # dV and P.V
+    pc = torch.zeros(Bf, Hf, Nf, Np, dtype=torch.int8, device="cuda")
+    pc[..., :Nf] = torch.randint(0, 4, (Bf, Hf, Nf, Nf), dtype=torch.int8, device="cuda", generator=g)
+    sp = torch.rand(Nf, device="cuda", generator=g) * 0.05 + 0.01
+    dO = torch.randn(Bf, Nf, Cf, device="cuda", generator=g)
+    dV = ops.qattn_dv(dO, pc, sp, 0.01, Bf, Hf, Nf, d, Np)
+    ap = O.lsq_effective_scale(sp.cpu(), 0.01).double()
+    vc = torch.randint(-2, 2, (Bf, Nf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    sv = torch.rand(Cf, device="cuda", generator=g) * 0.3 + 0.05
+    bav = torch.randn(Cf, device="cuda", generator=g) * 0.05
+    rp = pc[..., :Nf].float().sum(-1).reshape(-1).contiguous()                                   # row sums of the P codes
+    vT = ops.codes_transpose_i8(vc, Np)
+    Oo = ops.qattn_pv(pc, vT, sp, 0.01, sv, 0.01, bav, rp, Bf, Hf, Nf, d, Np)
+    av = O.lsq_effective_scale(sv.cpu(), 0.01).double()
+    for b in (0, 64, 127):
+        ph = pc[b, :, :, :Nf].cpu().double() * ap[None, :, None]                                 # (H, N, N) fake-quantised P
+        wantV = torch.einsum("hnm,nhj->mhj", ph, dO[b].cpu().double().view(Nf, Hf, d)).reshape(Nf, Cf)
+        assert rel_err(dV[b].cpu(), wantV.float()) < 1e-5, b
+        vh = (av[None, :] * vc[b].cpu().double() + bav.cpu().double()[None, :]).view(Nf, Hf, d)
+        wantO = torch.einsum("hnm,mhj->nhj", ph, vh).reshape(Nf, Cf)
+        assert rel_err(Oo[b].cpu(), wantO.float()) < 1e-6, b
