@@ -3004,7 +3004,12 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
   a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
-  const bool interior = (M % 128) == 0 && (N % 128) == 0 && 4 * (4 * (ldd > ldg ? ldd : ldg) + N) < (int64_t)0x7fffffff;
+  // The INTERIOR form (uniform row bases, no bounds selects: 145 instead of 155-170 us for qkx) is NOT used: at the full
+  // DeiT-S size it returned different dx / d(offset) values on ~50 of the 25 216 rows from launch to launch (always the tile
+  // rows 13 and 77, never with fewer tiles), which tests/test_kernels_gpu.py::test_i8_recompute_backward_is_deterministic
+  // now catches; the cause was not found in the time available (the row-base pins are not it), so the general form runs.
+  static const bool try_interior = getenv("OFQ_LSQBWD_INTERIOR") != nullptr;      // debugging switch
+  const bool interior = try_interior && (M % 128) == 0 && (N % 128) == 0 && 4 * (4 * (ldd > ldg ? ldd : ldg) + N) < (int64_t)0x7fffffff;
   auto launch = [&](auto QM, auto GE) {
     constexpr int qm = decltype(QM)::value;
     constexpr bool ge = decltype(GE)::value;

@@ -3,6 +3,7 @@ checks shapes, allocates outputs through torch's caching allocator, and enqueues
 torch's current stream.  CPU tensors are rejected: the product path has no CPU fallback.
 """
 import math
+import os
 import ctypes as C
 
 import torch
@@ -102,6 +103,7 @@ def _p(t):
 
 # ---- deferred second-stage sums (include/ofq_hip.h: ofq_sum_defer / ofq_sum_flush) ------------------------------------
 _SUM_DEFER = [False]
+_WS_POISON = os.environ.get("OFQ_WS_POISON") is not None     # test hook (tests/test_graph_gpu.py)
 _SUM_KEEP = []           # workspaces (per-workgroup partials) of the calls whose second stage is queued
 
 
@@ -143,6 +145,8 @@ def workspace(nbytes, device):
     """Per-device scratch, grown on demand.  Kernels that use it are serialised on one stream."""
     if _SUM_DEFER[0]:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if _WS_POISON:
+            buf.fill_(0xFF)               # test hook: every float of the partial buffers starts as a NaN
         _SUM_KEEP.append(buf)
         return buf
     key = (device.index, _stream())

@@ -159,6 +159,7 @@ def test_deferred_second_stage_sums_equal_immediate(variant):
     real_flush = ops.sum_flush
     for defer in (False, True):
         Fn.SUM_DEFER = defer
+        ops._WS_POISON = defer            # the private partial buffers of the queued calls start as NaNs: nothing unwritten is summed
         seen = [0]
 
         def counting_flush():
@@ -175,6 +176,7 @@ def test_deferred_second_stage_sums_equal_immediate(variant):
             res[defer], queued[defer] = out, seen[0]
         finally:
             Fn.SUM_DEFER = True
+            ops._WS_POISON = False
             ops.sum_flush = real_flush
     assert queued[False] == 0 and queued[True] >= 20, queued
     for step in range(2):

@@ -411,6 +411,36 @@ def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)
 
 
+@pytest.mark.parametrize("colmode", [0, 1])
+def test_i8_recompute_backward_is_deterministic(ops, colmode):
+    """ofq_qgemm_i8_lsq_bwd at the DeiT-S token count, five launches on the same operands: outputs AND the per-workgroup
+    partials in the workspace must be bit-identical (an experimental epilogue once made the step-gradient partials of the
+    column-mode form vary from launch to launch at rounding level -- the fast / exact choice of a group has to be a
+    function of the data alone; lsq.py:593-601 under autograd)."""
+    M, N, K, Tn = 128 * 197, 384, 384, 197
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qa = torch.randint(-4, 4, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    qw = (2 * torch.randint(-4, 4, (N, K), device="cuda", generator=g) + 1).to(torch.int8)
+    s = torch.rand(Tn, device="cuda", generator=g) * 0.05 + 0.02
+    cs = torch.rand(N, device="cuda", generator=g) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    r = torch.randn(N, device="cuda", generator=g) * 0.1
+    qS = N if colmode else Tn
+    q = {"s": torch.rand(qS, device="cuda", generator=g) * 0.5 + 0.3, "S": qS, "gscale": 0.01, "b4": bias * 0.5, "lo": -4, "hi": 3,
+         "gelu": False, "rowmul": 1, "coldiv": N, "colmode": colmode}
+    prod = {"xcodes": qa, "wcodes": qw, "bias": bias, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": s, "act_S": Tn, "act_gscale": 0.01}
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    nbytes = ops.lib().ofq_qgemm_i8_lsq_bwd_ws_bytes(M, N, colmode) - 256
+    runs = []
+    for _ in range(5):
+        out = ops.qgemm_i8_lsq_bwd(gy, prod, q)
+        torch.cuda.synchronize()
+        runs.append(([x.clone() for x in out], ops.workspace(16, gy.device)[:nbytes].clone()))
+    for out, ws in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][0], out))
+        assert torch.equal(runs[0][1], ws)
+
+
 @pytest.mark.parametrize("dims", [(396, 64, 64), (198, 32, 208), (396, 200, 80)])
 def test_narrow_tn_kernel_reads_stay_inside_its_operands(ops, dims):
     """Operands narrower than a 128-column tile (the golden attention shapes: 64 channels, 32-channel heads): the staging
