@@ -137,8 +137,12 @@ def drop_dw():
     ops.sum_drop()
 
 
-def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):
-    """Queue dW = dy2d^T @ (a_eff * codes + baft) and db = colsum(dy2d); returns the (not yet written) output tensors."""
+def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out, db_to_autograd=True):
+    """Queue dW = dy2d^T @ (a_eff * codes + baft) and db = colsum(dy2d); returns the (not yet written) output tensors.
+    db_to_autograd False: the caller will NOT hand db to autograd (a layer without a bias, or whose bias takes no gradient).
+    The kernel still writes it (the column sums feed the offset term of dW), so the queue keeps the tensor alive until the
+    flush -- dropped by the caller it would be freed at once, its memory handed to the next small tensor of the backward
+    pass (at 128 images: the value quantiser's three gradients) and overwritten there when the queue is flushed."""
     M, N = dy2d.shape[1], xcodes2d.shape[1]
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dy2d.device)
     db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
@@ -148,11 +152,11 @@ def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out):
     # the outputs are queued as raw addresses: autograd must hold the only reference to dW / db, or AccumulateGrad would
     # clone them (still unwritten) instead of adopting them as .grad; they stay alive as .grad / in autograd's input buffers
     q.append({"dy2d": dy2d, "xcodes2d": xcodes2d, "lsq_s": lsq_s, "S": S, "gscale": gscale, "baft": baft,
-              "dW": dW.data_ptr(), "db": db.data_ptr()})
+              "dW": dW.data_ptr(), "db": db.data_ptr(), "db_keep": None if db_to_autograd else db})
     _DW_TILES[0] += ops.tn_tiles(M, N)
     if _DW_TILES[0] >= DW_FLUSH_TILES:
         flush_dw()
-    return dW, db
+    return dW, (db if db_to_autograd else None)
 
 
 class CodesLinearFn(torch.autograd.Function):
@@ -228,7 +232,8 @@ class CodesLinearFn(torch.autograd.Function):
                      and (not ctx.has_bias or b_leaf is not None))
             if DW_DEFER and DW_GROUP and adopt and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"],
                                                                     dy2d.stride(0), xc2.stride(0)):
-                dW, db = queue_dw(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], aux["baft"], slot)
+                dW, db = queue_dw(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], aux["baft"], slot,
+                                  db_to_autograd=bool(ctx.has_bias and ctx.needs_input_grad[2]))
             else:
                 dW, db = ops.qgemm_bf16s_tn(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], None, aux["baft"],
                                             compute_db=True, out=slot)

@@ -323,3 +323,39 @@ def test_qkr_attention_products_full_size_on_sampled_images(ops):
         vh = (av[None, :] * vc[b].cpu().double() + bav.cpu().double()[None, :]).view(Nf, Hf, d)
         wantO = torch.einsum("hnm,mhj->nhj", ph, vh).reshape(Nf, Cf)
         assert rel_err(Oo[b].cpu(), wantO.float()) < 1e-6, b
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_full_size_training_step_is_deterministic(graph):
+    """The headline step (DeiT-S W2A2 QKR, 128 images) taken three times from the same weights and batch: every gradient (read through
+    AdamW's first moment) must come out bit for bit the same -- eagerly and from the captured graph.  All split-K / two-stage reductions here have a
+    fixed order and nothing uses atomics, so any difference is a kernel bug (this is how a sporadically wrong form of the
+    recompute backward was found: ~50 of 25 216 rows, only at this size)."""
+    import copy
+    from ofq_amd import engine
+    torch.manual_seed(0)
+    base = engine.build_student("deit_small_distilled_patch16_224", 2, 2, qk_reparam=True).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    imgs = torch.randn(128, 3, 224, 224, device="cuda", generator=g)
+    tgt = torch.randint(0, 1000, (128,), device="cuda", generator=g)
+    soft = torch.randn(128, 1000, device="cuda", generator=g)
+    engine.setup_alpha(base, imgs[:16])
+    runs = []
+    for _ in range(3):
+        model = copy.deepcopy(base).train()
+        opt = engine.make_optimizer(model, lr=0.0, weight_decay=0.0)
+        if graph:
+            step = engine.GraphedTrainStep(model, opt)
+            for _i in range(3):                      # two eager warm-ups, then the capture + first replay
+                step(imgs, tgt, soft)
+        else:
+            engine.train_step(model, opt, imgs, tgt, soft)
+        torch.cuda.synchronize()
+        # (first moments of AdamW: a fixed function of the gradients of the steps taken; the captured step keeps its
+        # gradients in graph-private memory)
+        runs.append({n: opt.state[p]["exp_avg"].detach().clone() for n, p in model.named_parameters() if p in opt.state})
+        del model, opt
+    for other in runs[1:]:
+        assert runs[0].keys() == other.keys()
+        bad = [n for n in runs[0] if not torch.equal(runs[0][n], other[n])]
+        assert not bad, (len(bad), bad[:5])
