@@ -325,20 +325,23 @@ def test_qkr_attention_products_full_size_on_sampled_images(ops):
         assert rel_err(Oo[b].cpu(), wantO.float()) < 1e-6, b
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_full_size_training_step_is_deterministic(graph):
-    """The headline step (DeiT-S W2A2 QKR, 128 images) taken three times from the same weights and batch: every gradient (read through
+@pytest.mark.parametrize("cfg", [("deit_small_distilled_patch16_224", 2, True, 128, False), ("deit_small_distilled_patch16_224", 2, True, 128, True),
+                                 ("deit_tiny_distilled_patch16_224", 4, False, 256, False), ("swin_t", 3, True, 128, False)],
+                         ids=["deit_s_qkr_eager", "deit_s_qkr_graph", "deit_t_plain_256", "swin_t_qkr"])
+def test_full_size_training_step_is_deterministic(cfg):
+    """The headline step (DeiT-S W2A2 QKR, 128 images; also DeiT-T W4A4 plain at 256 and Swin-T W3A3 QKR at 128) taken three times from the same weights and batch: every gradient (read through
     AdamW's first moment) must come out bit for bit the same -- eagerly and from the captured graph.  All split-K / two-stage reductions here have a
     fixed order and nothing uses atomics, so any difference is a kernel bug (this is how a sporadically wrong form of the
     recompute backward was found: ~50 of 25 216 rows, only at this size)."""
     import copy
     from ofq_amd import engine
+    name, bits, qkr, nimg, graph = cfg
     torch.manual_seed(0)
-    base = engine.build_student("deit_small_distilled_patch16_224", 2, 2, qk_reparam=True).cuda()
+    base = engine.build_student(name, bits, bits, qk_reparam=qkr).cuda()
     g = torch.Generator(device="cuda").manual_seed(11)
-    imgs = torch.randn(128, 3, 224, 224, device="cuda", generator=g)
-    tgt = torch.randint(0, 1000, (128,), device="cuda", generator=g)
-    soft = torch.randn(128, 1000, device="cuda", generator=g)
+    imgs = torch.randn(nimg, 3, 224, 224, device="cuda", generator=g)
+    tgt = torch.randint(0, 1000, (nimg,), device="cuda", generator=g)
+    soft = torch.randn(nimg, 1000, device="cuda", generator=g)
     engine.setup_alpha(base, imgs[:16])
     runs = []
     for _ in range(3):
