@@ -8,5 +8,5 @@ O=gpurun_out/r03_tests; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/tests.txt 2>&1; echo "tests rc=$?"; tail -15 $O/tests.txt
 if [ "${1:-}" = "nocache" ]; then
   PYTORCH_NO_CUDA_MEMORY_CACHING=1 timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_modules_gpu.py tests/test_prod_gpu.py \
-    tests/test_fullsize_gpu.py -m gpu -q -x > $O/tests_nocache.txt 2>&1; echo "nocache rc=$?"; tail -3 $O/tests_nocache.txt
+    tests/test_fullsize_gpu.py -m gpu -q -x -k 'not graph' > $O/tests_nocache.txt 2>&1; echo "nocache rc=$?"; tail -3 $O/tests_nocache.txt
 fi
