@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""ofq_qgemm_i8_lsq_bwd at the DeiT-S token count, 60 launches on the same operands: counts launches whose outputs differ
+from the first one (0 for the shipped general form; OFQ_LSQBWD_INTERIOR=1 selects the withdrawn interior form: 59 of 59)."""
+import sys, torch
+sys.path.insert(0, ".")
+from ofq_amd import ops
+M, K, Tn = 128 * 197, 384, 197
+for N, rowmul in ((2304, 6), (384, 1)):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qa = torch.randint(-2, 2, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    qw = (2 * torch.randint(-2, 2, (N, K), device="cuda", generator=g) + 1).to(torch.int8)
+    s = torch.rand(Tn, device="cuda", generator=g) * 0.05 + 0.02
+    cs = torch.rand(N, device="cuda", generator=g) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    r = torch.randn(N, device="cuda", generator=g) * 0.1
+    q = {"s": torch.rand(Tn * rowmul, device="cuda", generator=g) * 0.5 + 0.3, "S": Tn * rowmul, "gscale": 0.01, "b4": bias * 0.5, "lo": -2, "hi": 1,
+         "gelu": False, "rowmul": rowmul, "coldiv": N // rowmul, "colmode": 0}
+    prod = {"xcodes": qa, "wcodes": qw, "bias": None, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": s, "act_S": Tn, "act_gscale": 0.01}
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    ref = None; bad = 0
+    for it in range(60):
+        out = ops.qgemm_i8_lsq_bwd(gy, prod, q)
+        if ref is None: ref = [x.clone() for x in out]
+        elif not all(torch.equal(a, b) for a, b in zip(ref, out)): bad += 1
+    torch.cuda.synchronize()
+    print(N, rowmul, "launches differing from the first:", bad, "of 59")
