@@ -362,3 +362,41 @@ def test_full_size_training_step_is_deterministic(cfg):
         assert runs[0].keys() == other.keys()
         bad = [n for n in runs[0] if not torch.equal(runs[0][n], other[n])]
         assert not bad, (len(bad), bad[:5])
+
+
+def test_full_size_deferred_launches_equal_immediate_ones():
+    """The headline step with everything launched where it is produced (no dW queue, no queued reductions) against the
+    default (dW GEMMs grouped per block, second-stage reductions flushed with them), 128 images: the weight and linear-bias
+    gradients agree to 2e-6 (another split-K factor), every other gradient bit for bit -- nothing a queued kernel writes later may land on
+    memory that has been handed to another tensor in between (which is what happened to the value quantiser's three
+    gradients before the queue kept its un-adopted column-sum buffers alive)."""
+    import copy
+    from ofq_amd import engine
+    import ofq_amd.functional as Fn
+    torch.manual_seed(0)
+    base = engine.build_student("deit_small_distilled_patch16_224", 2, 2, qk_reparam=True, depth=4).cuda()
+    g = torch.Generator(device="cuda").manual_seed(12)
+    imgs = torch.randn(128, 3, 224, 224, device="cuda", generator=g)
+    tgt = torch.randint(0, 1000, (128,), device="cuda", generator=g)
+    soft = torch.randn(128, 1000, device="cuda", generator=g)
+    engine.setup_alpha(base, imgs[:16])
+    res = {}
+    for deferred in (False, True):
+        Fn.DW_GROUP, Fn.SUM_DEFER = deferred, deferred
+        try:
+            model = copy.deepcopy(base).train()
+            opt = engine.make_optimizer(model, lr=0.0, weight_decay=0.0)
+            engine.train_step(model, opt, imgs, tgt, soft)
+            torch.cuda.synchronize()
+            res[deferred] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            Fn.DW_GROUP, Fn.SUM_DEFER = True, True
+    a, b = res[False], res[True]
+    assert a.keys() == b.keys()
+    by_dw_kernel = (".weight", "proj.bias", "fc1.bias", "fc2.bias", ".v.bias", "head.bias", "head_dist.bias")
+    for n in a:
+        if n.endswith(by_dw_kernel):          # products of the dW GEMMs (the bias gradient is their column-sum by-product)
+            err = float((a[n] - b[n]).abs().max() / (a[n].abs().max() + 1e-30))
+            assert err < 2e-6, (n, err)
+        else:
+            assert torch.equal(a[n], b[n]), (n, float((a[n] - b[n]).abs().max()))
