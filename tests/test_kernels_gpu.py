@@ -965,6 +965,8 @@ def test_qattn_dxq_wide_kernel_vs_fp64(ops, N):
     ("col", 2 * 198, 192, 64, 198, 1, 1, 0, -2, 1),            # v-like: per-channel step; N not a multiple of 128
     ("row_wide_range", 16 * 256, 512, 32, 256, 0, 1, 0, -8, 7),  # 2M elements, gradients over 9 decades: the division
     ("col_wide_range", 16 * 256, 256, 32, 256, 1, 1, 0, -2, 1),  # shortcut (ofq_lsq_bwd_fast) against the IEEE sequence
+    ("qkx_full", 128 * 197, 6 * 384, 384, 197, 0, 6, 0, -2, 1),  # the headline step's qkx tensor: 25 216 tokens x 6 heads
+    ("v_full", 128 * 197, 384, 384, 197, 1, 1, 0, -2, 1),        # and its v tensor (per-channel step)
 ])
 def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
     """ofq_qgemm_i8_lsq_bwd (layer output recomputed from the integer codes, consumer quantiser's backward in registers)
