@@ -507,13 +507,15 @@ def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
     assert rel_err(dW.cpu(), dW2.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("cls", [3, 2])
+@pytest.mark.parametrize("cls", [3, 2, 128])
 def test_qgemm_tn_group_equals_single_launches(ops, cls):
     """ofq_qgemm_bf16s_tn_group (the deferred weight gradients of a block in one launch) == one ofq_qgemm_bf16s_tn call
     per job with the same split, bit for bit (same partials, same reduction order), dW and db; different token counts,
     step-vector lengths and leading dimensions per job, with and without the offset term."""
     shapes = ([(792, 384, 384), (792, 1536, 384), (594, 384, 1536), (1188, 2304, 384), (396, 128, 768)] if cls == 3 else
               [(792, 576, 192 + 64), (640, 192, 768 + 256), (500, 72, 272)])
+    if cls == 128:      # one DeiT-S block of the headline step: 128 x 197 tokens, the five layers the engine queues together
+        shapes = [(25216, 384, 1536), (25216, 1536, 384), (25216, 384, 384), (25216, 384, 384), (25216, 2304, 384)]
     rs = np.random.RandomState(6)
     jobs, refs = [], []
     for i, (Ktok, Mo, Nc) in enumerate(shapes):
@@ -521,7 +523,7 @@ def test_qgemm_tn_group_equals_single_launches(ops, cls):
         dyb = (T(det_normalish((Ktok, lda), 191 + i, 1.0)) * T(det_uniform((Ktok, 1), 192 + i, 1e-3, 10.0))).cuda()
         dy = dyb[:, :Mo]
         codes = torch.from_numpy(rs.randint(-8, 8, (Ktok, Nc)).astype(np.int8)).cuda()
-        S = 198 if Ktok % 198 == 0 else Ktok
+        S = 198 if Ktok % 198 == 0 else (197 if Ktok % 197 == 0 else Ktok)
         s = T(det_uniform((S,), 193 + i, 0.1, 1.0)).cuda()
         baft = T(det_uniform((Nc,), 194 + i, -0.05, 0.05)).cuda() if i != 1 else None
         for split in (3,):
@@ -570,7 +572,8 @@ def test_qattn_dqkx_persistent_stream_any_tiles_per_workgroup(ops, monkeypatch):
         assert torch.equal(o, dq.cpu())
 
 
-@pytest.mark.parametrize("dims", [(3, 6, 198, 64, 208, 3), (2, 3, 198, 64, 208, 15), (2, 2, 250, 32, 256, 3), (2, 4, 100, 48, 112, 7)])
+@pytest.mark.parametrize("dims", [(3, 6, 198, 64, 208, 3), (2, 3, 198, 64, 208, 15), (2, 2, 250, 32, 256, 3), (2, 4, 100, 48, 112, 7),
+                                  (128, 6, 197, 64, 208, 3)])
 def test_qattn_dp_softmax_bwd_fused_equals_the_two_kernels(ops, dims):
     """ofq_qattn_dp_softmax_bwd (dP GEMM + softmax-LSQ backward, dP never in memory) against ofq_qattn_dp followed by
     ofq_softmax_lsq_bwd: dS, the step gradient ds and the row sums; and against fp64 of the same formulas
@@ -1020,7 +1023,7 @@ def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [("qkr", 3, 6, 198, 384, 2), ("qkr_small", 2, 3, 70, 96, 4), ("plain", 3, 3, 198, 64, 4),
+@pytest.mark.parametrize("cfg", [("qkr", 3, 6, 198, 384, 2), ("qkr_full", 128, 6, 197, 384, 2), ("qkr_small", 2, 3, 70, 96, 4), ("plain", 3, 3, 198, 64, 4),
                                  ("plain_256", 1, 2, 256, 32, 3),
                                  ("qkr_window", 64, 3, 49, 96, 3), ("plain_window", 32, 6, 49, 32, 3), ("qkr_win_tiny", 4, 2, 7, 32, 2),
                                  ("plain_win64", 6, 2, 64, 16, 4)])
