@@ -400,3 +400,66 @@ def test_full_size_deferred_launches_equal_immediate_ones():
             assert err < 2e-6, (n, err)
         else:
             assert torch.equal(a[n], b[n]), (n, float((a[n] - b[n]).abs().max()))
+
+
+def test_full_size_images_equal_the_same_images_alone(ops):
+    """Every kernel below treats an image (a token row, a (batch, head) pair) independently of the rest of the batch, so
+    running it on the 128-image tensors and on three of those images alone must give the same values for those images, bit
+    for bit -- whatever tiling, persistent-workgroup schedule, XCD order or head stacking the launch size selects.  This ties
+    the full-size launches to the small ones that are compared with the reference's goldens (qlinear.py:66-73,
+    attention.py:200-219 and their autograd)."""
+    Bf, Hf, Nf, Cf = 128, 6, 197, 384
+    d, Np = Cf // Hf, 208
+    pick = [0, 77, 127]
+    g = torch.Generator(device="cuda").manual_seed(21)
+    rows = lambda t: t.view(Bf, Nf, -1)[pick].reshape(len(pick) * Nf, -1).contiguous()          # token rows of the picked images
+
+    # int8 forward with the consumer's codes (qkx form: per-(token, head) steps), and its recompute backward
+    qa = torch.randint(-2, 2, (Bf * Nf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    qw = (2 * torch.randint(-2, 2, (Hf * Cf, Cf), device="cuda", generator=g) + 1).to(torch.int8)
+    s = torch.rand(Nf, device="cuda", generator=g) * 0.05 + 0.02
+    cs = torch.rand(Hf * Cf, device="cuda", generator=g) * 0.05
+    r = torch.randn(Hf * Cf, device="cuda", generator=g) * 0.1
+    qs = torch.rand(Nf * Hf, device="cuda", generator=g) * 0.5 + 0.3
+    b4 = torch.randn(Hf * Cf, device="cuda", generator=g) * 0.05
+    spec = lambda: {"s": qs, "S": Nf * Hf, "gscale": 0.01, "b4": b4, "lo": -2, "hi": 1, "gelu": False, "rowmul": Hf, "coldiv": Cf, "colmode": 0}
+    gy = torch.randn(Bf * Nf, Hf * Cf, device="cuda", generator=g)
+    out = {}
+    for tag, A, G in (("full", qa, gy), ("part", rows(qa), rows(gy))):
+        f = spec()
+        assert ops.qgemm_i8_nt(A, qw, None, cs, 0.25, r, s, Nf, 0.01, fuse=f, store_y=False) is None
+        prod = {"xcodes": A, "wcodes": qw, "bias": None, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": s, "act_S": Nf, "act_gscale": 0.01}
+        dy = ops.qgemm_i8_lsq_bwd(G, prod, f)[0]
+        out[tag] = (f["codes_out"], dy)
+    assert torch.equal(rows(out["full"][0]), out["part"][0]) and torch.equal(rows(out["full"][1]), out["part"][1])
+
+    # dX of a linear layer (fc1's: K = 1536 out features)
+    wT = ops.codes_transpose_bf16((2 * torch.randint(-2, 2, (4 * Cf, Cf), device="cuda", generator=g) + 1).to(torch.int8))
+    ks = torch.rand(4 * Cf, device="cuda", generator=g)
+    dY = torch.randn(Bf * Nf, 4 * Cf, device="cuda", generator=g)
+    assert torch.equal(rows(ops.qgemm_bf16s_nt(dY, wT, ks, 0.25)), ops.qgemm_bf16s_nt(rows(dY), wT, ks, 0.25))
+
+    # attention products per (image, head)
+    img = lambda t: t[pick].contiguous()
+    dS = torch.zeros(Bf, Hf, Nf, Np, device="cuda")
+    dS[..., :Nf] = torch.randn(Bf, Hf, Nf, Nf, device="cuda", generator=g) * 1e-2
+    xc = torch.randint(-2, 2, (Bf, Nf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    qc = torch.randint(-2, 2, (Bf, Nf, Hf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    sx = torch.rand(Nf, device="cuda", generator=g) * 0.3 + 0.05
+    sq = torch.rand(Nf * Hf, device="cuda", generator=g) * 0.3 + 0.05
+    bax = torch.randn(Cf, device="cuda", generator=g) * 0.05
+    nb = len(pick)
+    assert torch.equal(img(ops.qattn_dqkx(dS, xc, sx, 0.01, bax, Bf, Hf, Nf, Cf, Np)), ops.qattn_dqkx(img(dS), img(xc), sx, 0.01, bax, nb, Hf, Nf, Cf, Np))
+    assert torch.equal(img(ops.qattn_dxq(dS, qc, sq, 0.01, Bf, Hf, Nf, Cf, Np)), ops.qattn_dxq(img(dS), img(qc), sq, 0.01, nb, Hf, Nf, Cf, Np))
+    pc = torch.zeros(Bf, Hf, Nf, Np, dtype=torch.int8, device="cuda")
+    pc[..., :Nf] = torch.randint(0, 4, (Bf, Hf, Nf, Nf), dtype=torch.int8, device="cuda", generator=g)
+    sp = torch.rand(Nf, device="cuda", generator=g) * 0.05 + 0.01
+    dO = torch.randn(Bf, Nf, Cf, device="cuda", generator=g)
+    assert torch.equal(img(ops.qattn_dv(dO, pc, sp, 0.01, Bf, Hf, Nf, d, Np)), ops.qattn_dv(img(dO), img(pc), sp, 0.01, nb, Hf, Nf, d, Np))
+    vc = torch.randint(-2, 2, (Bf, Nf, Cf), dtype=torch.int8, device="cuda", generator=g)
+    sv = torch.rand(Cf, device="cuda", generator=g) * 0.3 + 0.05
+    bav = torch.randn(Cf, device="cuda", generator=g) * 0.05
+    rp = pc[..., :Nf].float().sum(-1)
+    o_full = ops.qattn_pv(pc, ops.codes_transpose_i8(vc, Np), sp, 0.01, sv, 0.01, bav, rp.reshape(-1).contiguous(), Bf, Hf, Nf, d, Np)
+    o_part = ops.qattn_pv(img(pc), ops.codes_transpose_i8(img(vc), Np), sp, 0.01, sv, 0.01, bav, img(rp).reshape(-1).contiguous(), nb, Hf, Nf, d, Np)
+    assert torch.equal(img(o_full), o_part)
