@@ -463,3 +463,50 @@ def test_full_size_images_equal_the_same_images_alone(ops):
     o_full = ops.qattn_pv(pc, ops.codes_transpose_i8(vc, Np), sp, 0.01, sv, 0.01, bav, rp.reshape(-1).contiguous(), Bf, Hf, Nf, d, Np)
     o_part = ops.qattn_pv(img(pc), ops.codes_transpose_i8(img(vc), Np), sp, 0.01, sv, 0.01, bav, img(rp).reshape(-1).contiguous(), nb, Hf, Nf, d, Np)
     assert torch.equal(img(o_full), o_part)
+
+
+def test_full_size_token_rows_equal_the_same_rows_alone(ops):
+    """The row-wise kernels (LayerNorm fused with the consumer's LSQ, forward and backward; the plain LSQ pair; LayerNorm with
+    the residual add) on 128 x 197 token rows and on three images' rows alone: same codes, same statistics, same dx, bit for
+    bit (deit_vision_transformer.py:132-150, lsq.py:571-602)."""
+    Bf, Nf, Cf = 128, 197, 384
+    pick = [3, 64, 127]
+    g = torch.Generator(device="cuda").manual_seed(22)
+    rows = lambda t: t.view(Bf, Nf, -1)[pick].reshape(len(pick) * Nf, -1).contiguous()
+    x = torch.randn(Bf * Nf, Cf, device="cuda", generator=g)
+    res = torch.randn(Bf * Nf, Cf, device="cuda", generator=g)
+    gam = torch.rand(Cf, device="cuda", generator=g) + 0.5
+    bet = torch.randn(Cf, device="cuda", generator=g) * 0.1
+    s = torch.rand(Nf, device="cuda", generator=g) * 0.3 + 0.2
+    b4 = torch.randn(Cf, device="cuda", generator=g) * 0.05
+    gq = torch.randn(Bf * Nf, Cf, device="cuda", generator=g)
+    dres = torch.randn(Bf * Nf, Cf, device="cuda", generator=g)
+
+    def geom(nimg):
+        return ops.LsqGeom(nimg, Nf, Cf, Cf, 0, -2, 1, nimg * Cf, 0, Cf, Cf)
+    full = ops.layernorm_lsq_fwd(x, gam, bet, 1e-6, s, b4, geom(Bf), res2d=res)
+    part = ops.layernorm_lsq_fwd(rows(x), gam, bet, 1e-6, s, b4, geom(len(pick)), res2d=rows(res))
+    # (the gradient scale 1/sqrt(M Qp) counts the batch: the effective step of 3 and of 128 images may differ in the last bit, so
+    # the codes are compared through the statistics and the sums, which do not see it, and must agree on all but a few ties)
+    assert torch.equal(rows(full[1]), part[1]) and torch.equal(full[2].view(Bf, Nf)[pick].reshape(-1), part[2])
+    assert torch.equal(full[3].view(Bf, Nf)[pick].reshape(-1), part[3])
+    assert float((rows(full[0]) != part[0]).float().mean()) < 1e-5
+    gfull = ops.LsqGeom(Bf, Nf, Cf, Cf, 0, -2, 1, 7777, 0, Cf, Cf)            # same M on both sides: same effective steps
+    gpart = ops.LsqGeom(len(pick), Nf, Cf, Cf, 0, -2, 1, 7777, 0, Cf, Cf)
+    cf = ops.layernorm_lsq_fwd(x, gam, bet, 1e-6, s, b4, gfull, res2d=res)
+    cp = ops.layernorm_lsq_fwd(rows(x), gam, bet, 1e-6, s, b4, gpart, res2d=rows(res))
+    assert torch.equal(rows(cf[0]), cp[0])
+    bf = ops.layernorm_lsq_bwd(gq, cf[1], cf[2], cf[3], gam, bet, s, b4, gfull, dres2d=dres)
+    bp = ops.layernorm_lsq_bwd(rows(gq), cp[1], cp[2], cp[3], gam, bet, s, b4, gpart, dres2d=rows(dres))
+    assert torch.equal(rows(bf[0]), bp[0])
+    # plain LayerNorm with the residual add, and the elementwise LSQ pair on its output
+    y, xs, mean, rstd = ops.layernorm_fwd(x, gam, bet, 1e-6, res2d=res)
+    yp, xsp, meanp, rstdp = ops.layernorm_fwd(rows(x), gam, bet, 1e-6, res2d=rows(res))
+    assert torch.equal(rows(y), yp) and torch.equal(rows(xs), xsp)
+    dxf = ops.layernorm_bwd(gq, xs, mean, rstd, gam, dres2d=dres)[0]
+    dxp = ops.layernorm_bwd(rows(gq), xsp, meanp, rstdp, gam, dres2d=rows(dres))[0]
+    assert torch.equal(rows(dxf), dxp)
+    qf = ops.lsq_fwd(y, s, b4, b4, gfull, want_codes=True)
+    qp = ops.lsq_fwd(yp, s, b4, b4, gpart, want_codes=True)
+    assert torch.equal(rows(qf[0]), qp[0]) and torch.equal(rows(qf[1]), qp[1])
+    assert torch.equal(rows(ops.lsq_bwd(gq, y, s, b4, gfull)[0]), ops.lsq_bwd(rows(gq), yp, s, b4, gpart)[0])
