@@ -510,3 +510,26 @@ def test_full_size_token_rows_equal_the_same_rows_alone(ops):
     qp = ops.lsq_fwd(yp, s, b4, b4, gpart, want_codes=True)
     assert torch.equal(rows(qf[0]), qp[0]) and torch.equal(rows(qf[1]), qp[1])
     assert torch.equal(rows(ops.lsq_bwd(gq, y, s, b4, gfull)[0]), ops.lsq_bwd(rows(gq), yp, s, b4, gpart)[0])
+
+
+def test_full_size_fc1_epilogue_codes_equal_the_elementwise_quantiser(ops):
+    """fc1 at the headline size (25 216 tokens, 384 -> 1536): the codes of fc2's input quantiser that the GEMM epilogue emits
+    (level decided on the cheap GELU, exact redo inside the error margin) against ofq_lsq_fwd with the GELU prologue on the
+    stored fp32 output -- 38.7 M levels, all equal (qlinear.py:128-134)."""
+    M, N, K, T = 128 * 197, 1536, 384, 197
+    g = torch.Generator(device="cuda").manual_seed(23)
+    qa = torch.randint(-2, 2, (M, K), dtype=torch.int8, device="cuda", generator=g)
+    qw = (2 * torch.randint(-2, 2, (N, K), device="cuda", generator=g) + 1).to(torch.int8)
+    s = torch.rand(T, device="cuda", generator=g) * 0.1 + 0.05
+    cs = torch.rand(N, device="cuda", generator=g) * 0.1 + 0.02
+    bias = torch.randn(N, device="cuda", generator=g) * 0.3
+    r = torch.randn(N, device="cuda", generator=g) * 0.3
+    qs = torch.rand(T, device="cuda", generator=g) * 0.3 + 0.1
+    b4 = torch.randn(N, device="cuda", generator=g) * 0.05
+    fuse = {"s": qs, "S": T, "gscale": 0.01, "b4": b4, "lo": 0, "hi": 3, "gelu": True, "rowmul": 1, "coldiv": N, "colmode": 0}
+    y = ops.qgemm_i8_nt(qa, qw, bias, cs, 0.25, r, s, T, 0.01, fuse=fuse)
+    geom = ops.LsqGeom(128, T, N, N, 0, 0, 3, 1, 1, N, N)
+    geom.gscale = 0.01
+    _, codes = ops.lsq_fwd(y, qs, b4, None, geom, want_codes=True, need_values=False)
+    assert torch.equal(fuse["codes_out"].view(torch.uint8), codes.view(torch.uint8).view(M, N))
+    assert 0.02 < float((codes.view(torch.uint8) > 0).float().mean()) < 0.98           # (not everything clipped to one level)
