@@ -165,6 +165,30 @@ int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, co
 int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha, int accumulate,
                        int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                        ofq_stream_t stream);
+/*  stream-K form of the same product, for shapes whose 128 x 384 tiles do not fill the chip (M = 25 344 tokens: 198 row
+ *            tiles on 256 CUs): `num_wgs` workgroups (pass the CU count) share the tiles x k-steps of the launch evenly, each walking its share as one continuous k-step stream;
+ *            a tile cut by a share boundary is finished by the workgroup holding its k = 0 piece, which adds the other
+ *            holders' fp32 partials (published through `ws`) in workgroup order -- bit-identical from launch to launch,
+ *            a different association of the same sums than ofq_qgemm_bf16s_nt.  Up to two K-segments:
+ *              C[m,n] (+)= sum_seg alpha_seg * sum_k (A_seg[m,k] * k_scale_seg[k]) * B_seg[n,k]
+ *            -- the input gradients that two layers send to one tensor (attention.py:180 and :200: v and W_qk both read
+ *            x_hat) as ONE GEMM over the concatenated contraction; with two segments alpha is applied to the k-scale
+ *            (callers pass powers of two: same bits as applying it last).  Every K % 32 == 0, N > 128, M * lda * 4 < 2^32.
+ *            The launch uses the largest divisor of the tile count between 3/4 num_wgs and num_wgs as its workgroup count
+ *            when there is one (whole tiles only: then every bit equals ofq_qgemm_bf16s_nt's), num_wgs workgroups with cut
+ *            tiles otherwise; num_wgs < 0 forces exactly -num_wgs workgroups.
+ *            `ws`: ofq_qgemm_bf16s_nt_sk_ws_bytes(|num_wgs|) bytes, ZEROED once by the caller before its first use and then
+ *            owned by this entry point (calls sharing it must be ordered on one stream).  ofq_qgemm_bf16s_nt_sk_pays: 1 when
+ *            the stream-K launch is expected to beat the one-tile-per-workgroup launch for the shape. */
+typedef struct ofq_nt_seg {
+  const float* A; const void* B_bf16; const float* k_scale;
+  int64_t K, lda, ldb;
+  float alpha;
+} ofq_nt_seg;
+size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs);
+int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs);
+int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumulate, int64_t M, int64_t N, int64_t ldc,
+                          int num_wgs, void* ws, size_t ws_bytes, ofq_stream_t stream);
 /*  dX GEMM fused with the backward of the layer's own input quantiser (qlinear.py:66-69: x -> move_b4 -> LSQ -> move_aft
  *  -> F.linear): dX_hat = alpha * (dY * k_scale) @ B never leaves the kernel; its epilogue applies ofq_lsq_bwd's
  *  arithmetic (per-token step lsq_s[m % S], offset b4[n], optional GELU prologue) and writes dx[M][N] (ld ldx), and

@@ -23,6 +23,10 @@ class GemmDesc(C.Structure):
                 ("split_k", C.c_int32), ("alpha", f32), ("accumulate", C.c_int32), ("tile_hint", C.c_int32)]
 
 
+class NtSeg(C.Structure):
+    _fields_ = [("A", vp), ("B_bf16", vp), ("k_scale", vp), ("K", i64), ("lda", i64), ("ldb", i64), ("alpha", f32)]
+
+
 class TnJob(C.Structure):
     _fields_ = [("dY", vp), ("codes", vp), ("dW", vp), ("lsq_s", vp), ("db", vp), ("baft", vp),
                 ("S", i64), ("Ktok", i64), ("M", i64), ("N", i64), ("lda", i64), ("ldb", i64),
@@ -53,6 +57,9 @@ SIGNATURES = {
     "ofq_qgemm_i8_lsq_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, vp, i64, vp, i64,
                                    vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
+    "ofq_qgemm_bf16s_nt_sk_ws_bytes": (sz, [i32]),
+    "ofq_qgemm_bf16s_nt_sk_pays": (i32, [i64, i64, i64, i32]),
+    "ofq_qgemm_bf16s_nt_sk": (i32, [C.POINTER(NtSeg), i32, vp, i32, i64, i64, i64, i32, vp, sz, vp]),
     "ofq_qgemm_bf16s_nt_lsq_ws_bytes": (sz, [i64, i64]),
     "ofq_qgemm_bf16s_nt_lsq": (i32, [vp, vp, vp, f32, vp, vp, i64, f32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i64, i64, i64,
                                      i64, i64, vp, sz, vp]),

@@ -3496,6 +3496,504 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   return 0;
 }
 
+// ---- stream-K form of the wide input-gradient kernel ------------------------------------------------------------------
+// The one-tile-per-workgroup launch above leaves the chip badly filled on the linear layers of a ViT: M = 25 344 token rows
+// are 198 row tiles for 256 CUs (77 %), N = 1536 makes 792 tiles = 3.09 per CU, and every workgroup pays its own first
+// memory round trip and its 196 KB store burst at the same moment as all the others (measured: ~19 us of a 37 us launch at
+// K = 384 are launch edges).  Here `gridDim.x` workgroups (one per CU) share the launch's tiles x k-steps UNITS evenly: workgroup
+// w walks the units [U w / G, U (w+1) / G) in order, i.e. a run of consecutive (tile, k-range) pieces.  A tile that lies
+// inside one run is stored directly.  A tile cut by a run boundary is finished by its OWNER, the workgroup that holds its
+// k = 0 piece (the tail of that workgroup's run): the other holders (the heads of the following workgroups' runs -- done
+// early) publish their fp32 partial tile to their slot of the workspace (write-through stores, drained, then a flag), the
+// owner adds them in workgroup order and stores.  The cut points are a function of (M, N, K, G) only and the order of
+// the additions is fixed, so results are bit-identical from launch to launch; they are NOT bit-identical to the
+// one-tile-per-workgroup kernel (another association of the same fp32 sums) unless no tile is cut.
+// Up to two K-SEGMENTS: C = sum_seg alpha_seg * (A_seg * ks_seg) . B_seg^T -- the input gradients that two layers send to the
+// same tensor (v and W_qk of the QKR attention both consume x_hat) as one GEMM over the concatenated contraction.
+// Flags: one int per workgroup, zero before the first launch (caller), set by the publisher, reset by the owner.  Every
+// spin is bounded: a timeout raises the error word behind the flags and the kernel finishes with wrong numbers, not a hang.
+struct QNtSkSeg {
+  const float* A; const unsigned short* B; const float* s;
+  unsigned lda4, ldb2;       // row pitch of A / B in bytes
+  int nkt;                   // k-steps of QBS_BK in this segment
+  float alpha;
+};
+struct QNtSkArgs {
+  QNtSkSeg seg[2];
+  float* C; int64_t ldc;
+  int M, N, nkt, tiles_n, accumulate;
+  unsigned long long units;  // tiles * nkt / 2: the workgroups share PAIRS of k-steps (every piece starts on LDS stage 0)
+  float* ws; int* flags;     // [G][8 * 3 * 512 * 4] partial tiles; flags[w], error word flags[4096]
+};
+#define QNT_SK_SPIN_LIMIT (1 << 21)
+
+template <int NJ, int NSEG>
+__global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p) {
+  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int PLANE = BM * QBS_LD;
+  constexpr int STAGE = NS * PLANE + BN * QBS_LD;
+  constexpr int NB = NJ;
+  constexpr int SLOT_F4 = 8 * NJ * 512;                  // float4 per partial-tile slot
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int G = gridDim.x, w = blockIdx.x;
+  const int nkt = p.nkt;                                  // even (host check): units are PAIRS of k-steps
+  // this workgroup's run of k-steps, in the order tile 0 steps 0 .. nkt-1, tile 1 ...: an even number, from an even step
+  const unsigned u_begin = 2u * (unsigned)((p.units * (unsigned long long)w) / (unsigned long long)G);
+  const unsigned u_end = 2u * (unsigned)((p.units * (unsigned long long)(w + 1)) / (unsigned long long)G);
+  const unsigned kqa4 = (unsigned)(tid & 7) * 16u, kqb2 = (unsigned)(tid & 3) * 16u;   // byte offset of this lane's chunk in a k-step
+  const int kqa = (tid & 7) * 4, kqb = (tid & 3) * 8;
+
+  f32x16q acc[2][NJ];
+  f32x4v ra[2][2], rks[2];
+  i32x4 rb[NB];
+  float rkm[2] = {1.f, 1.f};                              // alpha of the segment a slot's panel belongs to (NSEG > 1)
+  bool rhs[2] = {false, false};                           // that segment has a k-scale vector
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+
+  // ---- load cursors: the (tile, k-step) the NEXT dY-panel loads / weight loads fetch.  They run three / two steps ahead of
+  // the MFMAs straight through piece and tile boundaries (a boundary costs its epilogue, not a pipeline restart) and stop on
+  // the run's last step.  Tile bases are uniform (scalar registers); a lane adds one 32-bit offset per row, recomputed when
+  // a cursor enters a new tile (rows clamped to the matrix: rows past M / N only feed elements that are never stored).
+  unsigned la_u = u_begin, lb_u = u_begin;
+  int la_kt = (int)(u_begin % (unsigned)nkt), lb_kt = la_kt;
+  int la_tile = (int)(u_begin / (unsigned)nkt), lb_tile = la_tile;
+  unsigned voA[NSEG][2], voB[NSEG][NB];
+  auto set_a_tile = [&](int tile) {
+    const int m0 = (tile / p.tiles_n) * BM;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned row = (unsigned)min(m0 + ((tid + 512 * i) >> 3), p.M - 1);
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg) voA[sg][i] = row * p.seg[sg].lda4 + kqa4;
+    }
+  };
+  auto set_b_tile = [&](int tile) {
+    const int n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const unsigned row = (unsigned)min(n0 + ((tid + 512 * i) >> 2), p.N - 1);
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg) voB[sg][i] = row * p.seg[sg].ldb2 + kqb2;
+    }
+  };
+  set_a_tile(la_tile);
+  set_b_tile(lb_tile);
+  auto adv_a = [&]() {
+    if (la_u + 1 < u_end) {
+      ++la_u;
+      if (++la_kt == nkt) {
+        la_kt = 0;
+        set_a_tile(++la_tile);
+      }
+    }
+  };
+  auto adv_b = [&]() {
+    if (lb_u + 1 < u_end) {
+      ++lb_u;
+      if (++lb_kt == nkt) {
+        lb_kt = 0;
+        set_b_tile(++lb_tile);
+      }
+    }
+  };
+  // uniform part of the addresses of tile step kt: segment base + k offset
+  auto seg_of = [&](int kt) -> int { return (NSEG > 1 && kt >= p.seg[0].nkt) ? 1 : 0; };
+  auto a_base = [&](int kt, int sg) -> const char* {
+    return reinterpret_cast<const char*>(p.seg[sg].A) + (size_t)(kt - (sg ? p.seg[0].nkt : 0)) * (QBS_BK * 4);
+  };
+  auto s_base = [&](int kt, int sg) -> const char* {
+    return reinterpret_cast<const char*>(p.seg[sg].s) + (size_t)(kt - (sg ? p.seg[0].nkt : 0)) * (QBS_BK * 4);
+  };
+  auto b_base = [&](int kt, int sg) -> const char* {
+    return reinterpret_cast<const char*>(p.seg[sg].B) + (size_t)(kt - (sg ? p.seg[0].nkt : 0)) * (QBS_BK * 2);
+  };
+  // prologue-style (un-interleaved) loads / staging: the first three steps of the run only
+  auto gload = [&](auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const int sg = seg_of(la_kt);
+    const char* ab = a_base(la_kt, sg);
+    rhs[sl] = p.seg[sg].s != nullptr;
+    // no scale vector: the load still happens (any valid address) and the value is replaced at the staging
+    rks[sl] = *reinterpret_cast<const f32x4v*>(rhs[sl] ? s_base(la_kt, sg) + kqa4 : ab + voA[NSEG > 1 ? sg : 0][0]);
+    if constexpr (NSEG > 1) rkm[sl] = p.seg[sg].alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[sl][i] = *reinterpret_cast<const f32x4v*>(ab + voA[NSEG > 1 ? sg : 0][i]);
+    adv_a();
+  };
+  auto gload_b = [&]() {
+    const int sg = seg_of(lb_kt);
+    const char* bb = b_base(lb_kt, sg);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const i32x4*>(bb + voB[NSEG > 1 ? sg : 0][i]);
+    adv_b();
+  };
+  // scale of slot sl's panel: ks (or 1), times the segment's alpha when there are two segments (alpha is a power of two in
+  // every caller, 1 / 2^bits: folding it here or applying it in the epilogue gives the same bits)
+  auto slot_scale = [&](auto SLOT, float (&ksv)[4]) {
+    constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = rhs[sl] ? rks[sl][e] : 1.f;
+      if constexpr (NSEG > 1) v *= rkm[sl];
+      ksv[e] = v;
+    }
+  };
+  auto lstore = [&](unsigned char* sb, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
+    float ksv[4];
+    slot_scale(SLOT, ksv);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid + 512 * i) >> 3;
+      const f32x2v k01 = {ksv[0], ksv[1]}, k23 = {ksv[2], ksv[3]};
+      const f32x2v a01 = {ra[sl][i][0], ra[sl][i][1]}, a23 = {ra[sl][i][2], ra[sl][i][3]};
+      unsigned lo[NS], hi[NS];
+      split_pair_bf16<NS>(a01 * k01, lo);
+      split_pair_bf16<NS>(a23 * k23, hi);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        uint2 wv;
+        wv.x = lo[q];
+        wv.y = hi[q];
+        *reinterpret_cast<uint2*>(&sb[q * PLANE + row * QBS_LD + kqa * 2]) = wv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[i]));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = (tid + 512 * i) >> 2;
+      *reinterpret_cast<i32x4*>(&sb[NS * PLANE + row * QBS_LD + kqb * 2]) = rb[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // one k-step of the stream: the MFMAs of the step staged in `cur`; behind them, in small pieces, the staging of the next
+  // step (register slot SLOT -> `nxt`), the weight loads at the B cursor (two steps ahead) and the dY-panel loads at the A
+  // cursor (three ahead).  Same piece list as qgemm_bf16s_nt_wide_kernel.
+  constexpr int NM = 12 * NJ, NPA = 17, NP = 2 * NPA + NB + NB + 3;
+  auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+    constexpr int sl = decltype(SLOT)::value;
+    const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
+    const unsigned char* b = &cur[NS * PLANE + (wn * 32 * NJ + l31) * QBS_LD + lh * 16];
+    static_assert(QBS_BK == 32, "two MFMA steps per k-step");
+    bf16x8 av[NS][2], bv[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[0][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD);
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD);
+    __builtin_amdgcn_sched_barrier(0);
+    float ksv[4], x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
+    unsigned lo[NS], hi[NS];
+    const int sgb = seg_of(lb_kt), sga = seg_of(la_kt);
+    const char* bb2 = b_base(lb_kt, sgb);
+    const char* ab3 = a_base(la_kt, sga);
+    const bool has_s3 = p.seg[sga].s != nullptr;
+    const char* sb3 = has_s3 ? s_base(la_kt, sga) + kqa4 : ab3;
+    const float alpha3 = p.seg[sga].alpha;
+    auto piece = [&](auto P_) {
+      constexpr int P = decltype(P_)::value;
+      if constexpr (P < 2 * NPA) {
+        constexpr int i = P / NPA, r = P % NPA;
+        if constexpr (r == 0 && i == 0) {          // first touch of the slot: the wait for its loads lands here
+          asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
+          slot_scale(SLOT, ksv);
+        }
+        if constexpr (r < 14) {
+          constexpr int pr = r / 7, rr = r % 7;
+          if constexpr (rr < 6) {
+            constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
+            if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
+            if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+          } else {
+            valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
+          }
+        } else {
+          constexpr int q = r - 14;
+          const int row = (tid + 512 * i) >> 3;
+          uint2 wv;
+          wv.x = lo[q];
+          wv.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = wv;
+        }
+      } else if constexpr (P < 2 * NPA + NB) {
+        constexpr int i = P - 2 * NPA;
+        const int row = (tid + 512 * i) >> 2;
+        asm volatile("" : "+v"(rb[i]));
+        *reinterpret_cast<i32x4*>(&nxt[NS * PLANE + row * QBS_LD + kqb * 2]) = rb[i];
+      } else if constexpr (P < 2 * NPA + 2 * NB) {
+        constexpr int i = P - 2 * NPA - NB;
+        rb[i] = *reinterpret_cast<const i32x4*>(bb2 + voB[NSEG > 1 ? sgb : 0][i]);
+      } else {
+        constexpr int wq = P - 2 * NPA - 2 * NB;
+        if constexpr (wq == 0) {
+          rks[sl] = *reinterpret_cast<const f32x4v*>(has_s3 ? sb3 : sb3 + voA[NSEG > 1 ? sga : 0][0]);
+          rhs[sl] = has_s3;
+          if constexpr (NSEG > 1) rkm[sl] = alpha3;
+        } else {
+          ra[sl][wq - 1] = *reinterpret_cast<const f32x4v*>(ab3 + voA[NSEG > 1 ? sga : 0][wq - 1]);
+        }
+      }
+    };
+    static_assert(NS == 3, "three planes");
+    static_for<NM>([&](auto G_) {
+      constexpr int Gi = decltype(G_)::value;
+      constexpr int ks = Gi / (6 * NJ), q = (Gi / (2 * NJ)) % NS, i = (Gi / NJ) % 2, j = Gi % NJ;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (ks == 0) {
+        if constexpr (Gi < NJ) bv[1][Gi] = *reinterpret_cast<const bf16x8*>(b + Gi * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+      }
+      constexpr int P0 = Gi * NP / NM, P1 = (Gi + 1) * NP / NM;
+      static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    lds_barrier();
+    adv_b();
+    adv_a();
+  };
+
+#ifdef NTSK_CLOCK_PROBE      // tools/nt_sk_sweep.py: shader clock the chip holds while G workgroups run this kernel
+  const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  gload(Slot0());
+  gload_b();
+  gload(Slot1());
+  lstore(smem, Slot0());
+  gload_b();
+  gload(Slot0());
+  lds_barrier();
+
+  unsigned u = u_begin;
+  while (u < u_end) {
+    const int tile = (int)(u / (unsigned)nkt);
+    const int kb = (int)(u - (unsigned)tile * (unsigned)nkt);
+    const int ke = min(nkt, kb + (int)(u_end - u));
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    for (int n2 = (ke - kb) >> 1; n2 > 0; --n2) {
+      step(smem, smem + STAGE, Slot1());
+      step(smem + STAGE, smem, Slot0());
+    }
+
+    int l31e = l31, lhe = lh, tide = tid;
+    asm volatile("" : "+v"(l31e), "+v"(lhe), "+v"(tide));      // keep the epilogue's lane offsets out of the k-loop's registers
+    if (kb != 0) {
+      // ---- not the owner: publish the partial tile (register order, one float4 per lane and store: coalesced) ----
+      // (the address is a VGPR pair: a scalar base would be restored from spill lanes by v_readlane right in front of the
+      // asm statement, and the hazard recogniser does not pad a VALU-written SGPR in front of an opaque memory instruction)
+      const char* slot = reinterpret_cast<const char*>(p.ws) + (size_t)w * (SLOT_F4 * 16) + (size_t)tide * 16u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            const char* sp = slot + (size_t)((i * NJ + j) * 4 + q) * (512 * 16);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(sp), "v"(v) : "memory");
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.flags + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (ke != nkt) {
+        // ---- owner of a cut tile: add the partials of the following workgroups, in order ----
+        const unsigned tile_end = (unsigned)(tile + 1) * (unsigned)nkt;
+        for (int x = w + 1; x < G; ++x) {
+          const unsigned ux = 2u * (unsigned)((p.units * (unsigned long long)x) / (unsigned long long)G);
+          if (ux >= tile_end) break;
+          if (tid == 0) {
+            int it = 0;
+            while (__hip_atomic_load(p.flags + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              if (++it > QNT_SK_SPIN_LIMIT) {
+                __hip_atomic_store(p.flags + 4096, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(8);
+            }
+            __hip_atomic_store(p.flags + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const f32x4v* src = reinterpret_cast<const f32x4v*>(p.ws) + (size_t)x * SLOT_F4 + tide;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              f32x4v v[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = __builtin_nontemporal_load(src + ((i * NJ + j) * 4 + q) * 512);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[q][e];
+            }
+        }
+      }
+      // ---- store the finished tile ----
+      const float alpha = NSEG > 1 ? 1.f : p.seg[0].alpha;
+      const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
+      if (interior) {
+        float* Cs = p.C + (int64_t)m0 * p.ldc + n0;
+        const int ldc = (int)p.ldc;
+        const int nl0 = wn * 32 * NJ + l31e;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int eb = 0; eb < 4; ++eb) {
+            const int mlb = (wm * 64 + i * 32 + 8 * eb + 4 * lhe) * ldc + nl0;
+            float old[4][NJ];
+            if (p.accumulate) {
+#pragma unroll
+              for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) old[ee][j] = Cs[mlb + ee * ldc + j * 32];
+            }
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) {
+                const float v = acc[i][j][eb * 4 + ee] * alpha;
+                Cs[mlb + ee * ldc + j * 32] = p.accumulate ? v + old[ee][j] : v;
+              }
+          }
+      } else {
+        int ncc[NJ];
+        bool nok[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = n0 + wn * 32 * NJ + j * 32 + l31e;
+          nok[j] = n < p.N;
+          ncc[j] = min(n, p.N - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int eb = 0; eb < 4; ++eb) {
+            float old[4][NJ];
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+              const int mc = min(m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lhe, p.M - 1);
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) old[ee][j] = p.accumulate ? p.C[(int64_t)mc * p.ldc + ncc[j]] : 0.f;
+            }
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+              const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lhe;
+#pragma unroll
+              for (int j = 0; j < NJ; ++j)
+                if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * alpha + old[ee][j];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    u += (unsigned)(ke - kb);
+  }
+#ifdef NTSK_CLOCK_PROBE
+  if (w == G / 2 && tid == 0) {
+    p.flags[4098] = (int)(__builtin_readcyclecounter() - pc0);
+    p.flags[4099] = (int)(__builtin_amdgcn_s_memrealtime() - pr0);
+  }
+#endif
+}
+
+// workspace: [QNT_SK_FLAG_BYTES of flags: one int per workgroup, then the error word (and the probe words)] [one partial-tile
+// slot per workgroup]; the flags sit in front so that their place does not depend on the number of workgroups of a launch
+#define QNT_SK_FLAG_BYTES 32768
+#define QNT_SK_SLOT_BYTES (8 * 3 * 512 * 16)
+extern "C" size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs) {
+  if (num_wgs < 0) num_wgs = -num_wgs;
+  return num_wgs == 0 || num_wgs > 4096 ? 0 : QNT_SK_FLAG_BYTES + (size_t)num_wgs * QNT_SK_SLOT_BYTES;
+}
+
+// Number of workgroups for `tiles` tiles of `nkt` k-steps on a chip of `num_wgs` CUs.  Measured on MI355X (tools/nt_sk_sweep.py):
+// the chip is power-bound in this kernel -- 2.04 GHz with 99 workgroups, 1.74 with 198, 1.72 with 256 -- and a cut tile costs
+// its holders ~20 us (196 KB published write-through, the owner's acquire + read + store all behind the last k-step), so
+// 256 workgroups with cuts only tie with 198 whole tiles (K = 2304: 122.0 vs 120.8 us).  Hence: whole tiles whenever a
+// divisor of the tile count fills at least three quarters of the chip (no tile is cut: the k order of every tile, and so
+// every bit of the result, is that of the one-tile-per-workgroup kernel), cuts otherwise.
+static int nt_sk_grid(int64_t tiles, int num_wgs) {
+  for (int64_t g = num_wgs; 4 * g >= 3 * (int64_t)num_wgs && g >= 1; --g)
+    if (tiles % g == 0) return (int)g;
+  return (int)(tiles < num_wgs ? tiles : num_wgs);
+}
+
+// 1: the streaming launch is expected to beat the one-tile-per-workgroup launch (a workgroup gets at least 24 k-steps: what
+// it saves are the launch edges between consecutive tiles; a 12-step launch of 198 tiles is 29.6 us either way), 0: not
+extern "C" int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs) {
+  if (num_wgs <= 1 || N <= 128 || (K % (2 * QBS_BK)) != 0) return 0;
+  const int nj = N > 256 ? 3 : 2;
+  const int64_t tiles = ceil_div(M, 128) * ceil_div(N, 128 * nj);
+  const int g = nt_sk_grid(tiles, num_wgs);
+  if (tiles * (K / QBS_BK) < 24 * (int64_t)g) return 0;
+  if (tiles % g == 0) return 1;
+  const int64_t rounds = ceil_div(tiles, num_wgs);                      // cuts: only when the whole-tile launch fills badly
+  return (double)tiles / (double)(rounds * num_wgs) < 0.85 ? 1 : 0;
+}
+
+extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumulate, int64_t M, int64_t N, int64_t ldc,
+                                     int num_wgs, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+  const bool forced = num_wgs < 0;               // exactly -num_wgs workgroups (tests, tools/nt_sk_sweep.py)
+  if (forced) num_wgs = -num_wgs;
+  if (!segs || (nseg != 1 && nseg != 2) || !C || !ws || M <= 0 || N <= 128 || num_wgs <= 0 || num_wgs > 4096) return OFQ_EINVAL;
+  if (ws_bytes < ofq_qgemm_bf16s_nt_sk_ws_bytes(num_wgs)) return OFQ_ENOWS;
+  if (M >= (1ll << 30) || N >= (1ll << 30) || !al16(ws)) return OFQ_EINVAL;
+  QNtSkArgs a = {};
+  int nkt = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const ofq_nt_seg& sg = segs[i];
+    if (!sg.A || !sg.B_bf16 || sg.K <= 0 || (sg.K % QBS_BK) || (sg.lda & 3) || (sg.ldb & 7) || !al16(sg.A) || !al16(sg.B_bf16) ||
+        (sg.k_scale && !al16(sg.k_scale)) || M * sg.lda * 4 >= (1ll << 32) || N * sg.ldb * 2 >= (1ll << 32))
+      return OFQ_EINVAL;
+    a.seg[i].A = sg.A; a.seg[i].B = (const unsigned short*)sg.B_bf16; a.seg[i].s = sg.k_scale;
+    a.seg[i].lda4 = (unsigned)(sg.lda * 4); a.seg[i].ldb2 = (unsigned)(sg.ldb * 2);
+    a.seg[i].nkt = (int)(sg.K / QBS_BK); a.seg[i].alpha = sg.alpha;
+    nkt += a.seg[i].nkt;
+  }
+  const int nj = N > 256 ? 3 : 2;
+  const int64_t tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128 * nj);
+  if (tiles_m * tiles_n * nkt >= (1ll << 31) || (nkt & 1)) return OFQ_EINVAL;      // units are pairs of k-steps
+  a.C = C; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.nkt = nkt; a.tiles_n = (int)tiles_n; a.accumulate = accumulate;
+  a.units = (unsigned long long)(tiles_m * tiles_n) * (unsigned long long)(nkt / 2);
+  a.flags = (int*)ws;
+  a.ws = (float*)((char*)ws + QNT_SK_FLAG_BYTES);
+  int g = forced ? num_wgs : nt_sk_grid(tiles_m * tiles_n, num_wgs);
+  if ((unsigned long long)g > a.units) g = (int)a.units;
+  const dim3 grid((unsigned)g), block(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (nj == 3) {
+    if (nseg == 1) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 2>), grid, block, 0, st, a);
+  } else {
+    if (nseg == 1) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 2>), grid, block, 0, st, a);
+  }
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // Wide form of the plane-product GEMM (the fp32 KD teacher's linear layers, ofq_gemm_bf16x3x3_nt): 128 x 384 tile, eight
 // waves of 64 x 96, k-steps of 16 through a double-buffered LDS ring (one stage: three planes of A, 128 x 16, and three
 // planes of B, 384 x 16: 74 KB), two register prefetch slots.  Per k-step a wave issues 9 (6) plane products x 6 blocks =

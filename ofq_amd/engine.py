@@ -237,6 +237,7 @@ def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
     finally:
         F_ofq.DW_DEFER = False
     F_ofq.flush_dw()
+    F_ofq.assert_step_queues_empty()            # nothing parked, queued or deferred may outlive the backward pass
     if dp is not None:
         dp.finish_gradient_sync()
     if cga is not None:

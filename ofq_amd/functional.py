@@ -62,6 +62,32 @@ def _shared_grad(acc, shape, device):
     return buf, True, None
 
 
+# accumulators (see CodesLinearFn.backward) that hold a parked input-gradient GEMM: must be empty when a backward pass ends
+_DX_PENDING = []
+
+
+def assert_no_pending_dx():
+    """A parked input-gradient GEMM whose partner never arrived would leave its gradient unwritten: fail loudly."""
+    if _DX_PENDING:
+        n = len(_DX_PENDING)
+        del _DX_PENDING[:]
+        raise RuntimeError("ofq_amd: %d parked input-gradient GEMM(s) were never launched (a consumer of a shared input "
+                           "did not run its backward)" % n)
+
+
+def assert_step_queues_empty():
+    """End of a training step's backward pass (engine._step_body, after flush_dw): no parked input-gradient GEMM, no queued
+    weight-gradient GEMM, no deferred second-stage reduction -- each of them stands for gradient memory that autograd already
+    handed on unwritten."""
+    assert_no_pending_dx()
+    if _DW_QUEUE or _DW_TILES[0]:
+        drop_dw()
+        raise RuntimeError("ofq_amd: weight-gradient GEMMs were still queued after flush_dw()")
+    if ops.sum_pending():
+        ops.sum_drop()
+        raise RuntimeError("ofq_amd: second-stage reductions were still deferred after flush_dw()")
+
+
 # ---- deferred weight gradients -----------------------------------------------------------------------------------------
 # dW of a linear layer has no consumer inside the backward pass (StatsQ's backward is the identity, so it goes straight to
 # the parameter's .grad, or to AllWqkFn at the very end).  Inside engine's training step (DW_DEFER set around
@@ -214,9 +240,34 @@ class CodesLinearFn(torch.autograd.Function):
             dx = ops.placeholder(ctx.in_shape, dy2d.device)
         elif ctx.needs_input_grad[0]:
             K_in0 = ctx.in_shape[-1]
-            buf, accumulate, dx = _shared_grad(aux.get("xgrad_acc"), ctx.in_shape, dy2d.device)
-            ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"], out=buf.view(-1, K_in0),
-                               accumulate=accumulate)
+            acc = aux.get("xgrad_acc")
+            buf, accumulate, dx = _shared_grad(acc, ctx.in_shape, dy2d.device)
+            seg = (dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"])
+            # Several linear layers read this input (v and W_qk of the QKR attention, attention.py:180, :200): their input
+            # gradients are ONE GEMM over the concatenated contraction, [dY_v | dY_qkx] . [W_v ; W_qk].  Every layer but the
+            # last to arrive leaves its operands in `acc` (the tuple keeps dY alive); the last one launches.  A layer parks
+            # only when the buffer already holds a gradient (accumulate): the first writer must write.
+            npend = 0 if acc is None else len(acc.get("lin_pending", ()))
+            total = 1 if acc is None else acc.get("lin_total", 1)
+            if (accumulate and total > 1 and npend + 1 < total - acc.get("lin_done", 0)
+                    and ops.nt_concat_ok(dy2d, aux["wcodesT"], acc.get("lin_pending"))):
+                acc.setdefault("lin_pending", []).append(seg)
+                _DX_PENDING.append(acc)
+            elif npend:
+                segs = acc.pop("lin_pending") + [seg]
+                _DX_PENDING[:] = [a_ for a_ in _DX_PENDING if a_ is not acc]
+                if ops.nt_concat_ok(dy2d, aux["wcodesT"], segs[:-1]):
+                    ops.qgemm_bf16s_nt_sk(segs[::-1], buf.view(-1, K_in0), accumulate=accumulate)
+                else:
+                    for a_, b_, ks_, al_ in segs:
+                        ops.qgemm_bf16s_nt(a_, b_, ks_, al_, out=buf.view(-1, K_in0), accumulate=accumulate)
+                        accumulate = True
+                acc["lin_done"] = acc.get("lin_done", 0) + len(segs)
+            else:
+                ops.qgemm_bf16s_nt(dy2d, aux["wcodesT"], aux["w_scale"], aux["w_mult"], out=buf.view(-1, K_in0),
+                                   accumulate=accumulate)
+                if acc is not None:
+                    acc["lin_done"] = acc.get("lin_done", 0) + 1
         need_db = (ctx.has_bias and ctx.needs_input_grad[2]) or aux["baft"] is not None
         dW = db = None
         N_out, K_in = dy2d.shape[1], ctx.in_shape[-1]

@@ -133,6 +133,11 @@ def sum_flush():
         del _SUM_KEEP[:]
 
 
+def sum_pending():
+    """Queued second-stage reductions / kept workspaces (host-side counters, no device sync)."""
+    return len(_SUM_KEEP) + int(lib().ofq_sum_pending())
+
+
 def sum_drop():
     """Forget the queued reductions without launching them (a backward pass that raised: the tensors they would write may
     have been released already)."""
@@ -431,12 +436,93 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
     return dy, ds, db4, dbaft
 
 
-def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3):
-    """out[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k],  A fp32, B bf16 integer codes"""
+# ---- stream-K input-gradient GEMM (ofq_qgemm_bf16s_nt_sk) ----------------------------------------------------------------
+NT_SK = os.environ.get("OFQ_NT_SK", "1") != "0"          # A/B switch: "0" = always the one-tile-per-workgroup kernel
+_NT_SK_FORCE = os.environ.get("OFQ_NT_SK") == "force"   # test hook: stream-K for every shape it accepts
+_sk_ws = {}
+_cus = {}
+
+
+def num_cus(device):
+    n = _cus.get(device.index)
+    if n is None:
+        n = _cus[device.index] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return n
+
+
+def _sk_workspace(device):
+    """Partial-tile slots + flags of the stream-K kernel: one per (device, stream), zeroed once (the kernel leaves the
+    flags zero), never shared with ops.workspace() users."""
+    key = (device.index, _stream())
+    buf = _sk_ws.get(key)
+    if buf is None:
+        buf = _sk_ws[key] = torch.zeros(int(lib().ofq_qgemm_bf16s_nt_sk_ws_bytes(num_cus(device))), dtype=torch.uint8, device=device)
+    return buf
+
+
+def nt_sk_error(device):
+    """The stream-K kernels' error word (a bounded spin ran out): 0 = never.  Host sync; tests and debugging only."""
+    buf = _sk_ws.get((device.index, _stream()))
+    if buf is None:
+        return 0
+    return int(buf[:32768].view(torch.int32)[4096].item())
+
+
+def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
+    """out[m,n] (+)= sum over segs of alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]; segs = [(A, B_bf16, k_scale, alpha), ...] (1 or 2)"""
+    M, N = out.shape
+    dev = out.device
+    arr = (_lib.NtSeg * len(segs))()
+    K = 0
+    for i, (A, B, ks, alpha) in enumerate(segs):
+        arr[i].A, arr[i].B_bf16, arr[i].k_scale = A.data_ptr(), B.data_ptr(), _p(ks)
+        arr[i].K, arr[i].lda, arr[i].ldb, arr[i].alpha = A.shape[1], A.stride(0), B.stride(0), alpha
+        K += A.shape[1]
+    ws = _sk_workspace(dev)
+    g = num_cus(dev) if wgs is None else -int(wgs)        # wgs: exactly that many workgroups (<= the CU count; tests)
+    with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+        _chk(lib().ofq_qgemm_bf16s_nt_sk(arr, len(segs), out.data_ptr(), int(accumulate), M, N, out.stride(0), g, ws.data_ptr(),
+                                         ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_sk")
+    return out
+
+
+NT_CONCAT = os.environ.get("OFQ_NO_NT_CONCAT") is None     # A/B switch: "v + W_qk input gradients as one GEMM"
+
+
+def nt_concat_ok(A, B_bf16, parked):
+    """May the input-gradient GEMM of (A, B) run as a further K-segment of the parked ones?  (same M and N, whole pairs of
+    32-wide k-steps, two segments at most, 32-bit row offsets)"""
+    if not (NT_SK and NT_CONCAT):
+        return False
+    M, K = A.shape
+    N = B_bf16.shape[0]
+    if N <= 128 or K % 32 or M * A.stride(0) * 4 >= 2 ** 32 or N * B_bf16.stride(0) * 2 >= 2 ** 32:
+        return False
+    ktot = K
+    for (a, b, _, _) in (parked or ()):
+        if a.shape[0] != M or b.shape[0] != N:
+            return False
+        ktot += a.shape[1]
+    return len(parked or ()) <= 1 and (not parked or ktot % 64 == 0)
+
+
+def nt_sk_pays(M, N, K, device):
+    if not NT_SK:
+        return False
+    if _NT_SK_FORCE:
+        return N > 128 and K % 64 == 0
+    return bool(lib().ofq_qgemm_bf16s_nt_sk_pays(M, N, K, num_cus(device)))
+
+
+def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3, sk=None):
+    """out[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k],  A fp32, B bf16 integer codes
+    sk: None = stream-K where it pays (ofq_qgemm_bf16s_nt_sk_pays), False / True = never / always"""
     M, K = A.shape
     N = B_bf16.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if nsplit == 3 and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
+        return qgemm_bf16s_nt_sk([(A, B_bf16, k_scale, alpha)], out, accumulate)
     with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
                                       nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),

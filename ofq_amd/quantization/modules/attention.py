@@ -264,7 +264,8 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
             if qspec is not None and "qkx" in _ql.RECOMPUTE_SITES:
                 qspec["store_y"] = False
             # x_hat has three consumers (v GEMM, W_qk GEMM, scores): their backward passes accumulate into one buffer
-            xacc = {} if (attn_codes and torch.is_grad_enabled()) else None
+            # (lin_total: the two linear layers among them run their input gradients as one GEMM, functional.CodesLinearFn)
+            xacc = {"lin_total": 2} if (attn_codes and torch.is_grad_enabled()) else None
             v = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, self.v.weight, self.v_quant,
                              self.v.bias, fuse=vspec, xgrad_acc=xacc)            # :179-181
         else:

@@ -411,6 +411,69 @@ def test_qgemm_bf16_split_backward(ops, mnk, nsplit):
     assert rel_err(out2.cpu(), 2 * ref.float()) < (1e-5 if nsplit == 3 else 1e-4)
 
 
+def _nt_operands(M, N, K, seed):
+    rs = np.random.RandomState(seed)
+    dy = (T(det_normalish((M, K), seed, 1.0)) * T(det_uniform((M, 1), seed + 1, 1e-4, 10.0))).cuda()     # wide dynamic range
+    ks = T(det_uniform((K,), seed + 2, 0.01, 0.1)).cuda()
+    wcodes = torch.from_numpy((2 * rs.randint(-8, 8, (K, N)) + 1).astype(np.int8)).cuda()                # [o][c], o = k here
+    return dy, ks, wcodes
+
+
+@pytest.mark.parametrize("mnk", [(1024, 384, 384), (792, 1536, 384), (640, 384, 2304), (1000, 192, 768), (515, 400, 128), (130, 1100, 64)])
+def test_streaming_dx_gemm_equals_the_tile_per_workgroup_kernel(ops, mnk):
+    """ofq_qgemm_bf16s_nt_sk (reference: autograd of F.linear, qlinear.py:69).  With a workgroup count that divides the
+    tile count no tile is cut: the k order of every tile is the classic kernel's and the results are the same bits.
+    With cut tiles (any other count) another association of the same fp32 sums: fp64 accuracy as good as the classic
+    kernel's, and launch-to-launch bit-identical (the owner adds the partials in workgroup order)."""
+    M, N, K = mnk
+    dy, ks, wcodes = _nt_operands(M, N, K, 91)
+    wT = ops.codes_transpose_bf16(wcodes)
+    ref = 0.25 * ((dy.double() * ks.double()) @ wcodes.double())
+    den = ((dy.double() * ks.double()).abs() @ wcodes.double().abs()) * 0.25 + 1e-30
+    classic = ops.qgemm_bf16s_nt(dy, wT, ks, 0.25, sk=False)
+    tiles = ((M + 127) // 128) * ((N + (383 if N > 256 else 255)) // (384 if N > 256 else 256))
+    for wgs in sorted({tiles, max(tiles // 2, 1), 1, min(7, tiles * K // 64), min(256, tiles * K // 64), 100}):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], out, wgs=wgs)
+        err = float(((out.double() - ref).abs() / den).max())
+        assert err < 2e-7, (wgs, err)
+        if tiles % wgs == 0:
+            assert torch.equal(out, classic), wgs
+        for _ in range(3):
+            again = torch.full((M, N), float("nan"), device="cuda")
+            ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], again, wgs=wgs)
+            assert torch.equal(out, again), wgs
+        base = classic.clone()
+        ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], base, accumulate=True, wgs=wgs)
+        assert rel_err(base.cpu(), 2 * ref.float().cpu()) < 1e-5
+    assert ops.nt_sk_error(dy.device) == 0
+
+
+@pytest.mark.parametrize("mnkk", [(792, 384, 384, 2304), (600, 384, 2304, 384), (515, 192, 192, 1152), (300, 400, 64, 64)])
+def test_two_segment_dx_gemm_is_the_sum_of_the_two_gemms(ops, mnkk):
+    """[dY_v | dY_qkx] . [W_v ; W_qk]: the input gradients v and W_qk send to x_hat (attention.py:180, :200) as one launch."""
+    M, N, K0, K1 = mnkk
+    dy0, ks0, w0 = _nt_operands(M, N, K0, 17)
+    dy1, ks1, w1 = _nt_operands(M, N, K1, 23)
+    t0, t1 = ops.codes_transpose_bf16(w0), ops.codes_transpose_bf16(w1)
+    ref = 0.25 * ((dy0.double() * ks0.double()) @ w0.double()) + 0.5 * ((dy1.double() * ks1.double()) @ w1.double())
+    den = 0.25 * ((dy0.double() * ks0.double()).abs() @ w0.double().abs()) + 0.5 * ((dy1.double() * ks1.double()).abs() @ w1.double().abs()) + 1e-30
+    tiles = ((M + 127) // 128) * ((N + (383 if N > 256 else 255)) // (384 if N > 256 else 256))
+    first = None
+    for wgs in (tiles, 256, 5):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.qgemm_bf16s_nt_sk([(dy0, t0, ks0, 0.25), (dy1, t1, None if K1 == 64 else ks1, 0.5)], out, wgs=min(wgs, tiles * (K0 + K1) // 64))
+        if K1 == 64:      # second segment without a k-scale vector
+            ref_ = 0.25 * ((dy0.double() * ks0.double()) @ w0.double()) + 0.5 * (dy1.double() @ w1.double())
+            den_ = 0.25 * ((dy0.double() * ks0.double()).abs() @ w0.double().abs()) + 0.5 * (dy1.double().abs() @ w1.double().abs()) + 1e-30
+        else:
+            ref_, den_ = ref, den
+        assert float(((out.double() - ref_).abs() / den_).max()) < 5e-7, wgs      # fp32 accumulation over 2688 products
+        first = out if first is None else first
+        assert rel_err(out.cpu(), first.cpu()) < 3e-6          # cut and whole tiles: two associations of the same sums
+    assert ops.nt_sk_error(dy0.device) == 0
+
+
 @pytest.mark.parametrize("colmode", [0, 1])
 def test_i8_recompute_backward_is_deterministic(ops, colmode):
     """ofq_qgemm_i8_lsq_bwd at the DeiT-S token count, five launches on the same operands: outputs AND the per-workgroup
