@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the captured step with more than one rank as well (default there: eager launches; the capture "
-                         "of RCCL collectives is validated with one rank only, tests/test_graph_gpu.py)")
+                    help="with several ranks: capture the RCCL collectives inside the step's graph as well (default there: "
+                         "captured compute with the bucket all-reduces issued eagerly between two graphs; the capture of "
+                         "collectives is validated with one rank only, tests/test_graph_gpu.py)")
     ap.add_argument("--teacher-gemm", default="bf16x9", choices=["f32", "bf16x9", "bf16x6"],
                     help="with --with-teacher: fp32-MFMA GEMMs, or the weights pre-split into bf16 planes (9 / 6 plane products)")
     ap.add_argument("--stock-teacher", action="store_true",
@@ -297,14 +298,18 @@ def main():
         return engine.train_step(model, opt, images, target, soft_targets(), loss_fn, dp=dp, cga=cga)
 
     eager_step = step
-    # one rank: graph replay.  Several ranks: the step is GPU-bound at 128 img/GPU either way (the launch queue never runs dry,
-    # profiles/r02_graph_gaps_graph_vs_eager.txt), and RCCL collectives inside a hipGraph could only be exercised with one rank on the
-    # one-GPU development boxes, so the multi-rank default is the eager path; --graph turns the replay on there too.
-    use_graph = not args.no_graph and (world == 1 or args.graph)
+    # one rank: graph replay of the whole step.  Several ranks: graph replay of the compute with the bucket all-reduces issued
+    # eagerly between two graphs (RCCL collectives inside a hipGraph could only be exercised with one rank on the one-GPU
+    # development boxes: --graph), so that the host issues a handful of launches per step instead of ~850 next to RCCL's proxy
+    # threads; --no-graph is the eager path (collectives overlapped with backward, 20 ms of Python per step).
+    use_graph = not args.no_graph
+    # with the data-parallel wrapper (several ranks, or --force-dp): "split" = captured compute + eager collectives
+    # (engine.GraphedTrainStep) unless --graph asks for the collectives inside the graph
+    graph_mode = "full" if (dp is None or args.graph) else "split"
     n_warm = args.warmup
     if use_graph:
         # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures
-        gstep = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=cga, warmup=2, alias_inputs=True)
+        gstep = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=cga, warmup=2, alias_inputs=True, mode=graph_mode)
         n_warm = max(args.warmup, gstep.warmup + 1)          # the capture must not fall into the timed region
 
         def step():
@@ -329,6 +334,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if dp is not None and dp.sync_statsq:
+        dp.check_statsq_pending()                     # --sync-statsq: the asserted no-op (outside the timed region: a host sync)
     loss_value = float(loss.detach())                 # (the static loss tensor of the graph: read before any further step)
     # roofline pass: the same --steps steps again, live, with HIP events around every matrix-core kernel launch (on the
     # stream the kernels are launched on); rank 0 reports the dominant class
@@ -403,7 +410,8 @@ def main():
                                          ("fp32 teacher forward in the step (%s)" % ("stock PyTorch-ROCm" if args.stock_teacher else "HIP kernels, GEMMs " + args.teacher_gemm))
                                          if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
-                          "launch": "hipGraph replay" if use_graph else "eager (one ctypes launch per kernel)",
+                          "launch": ("eager (one ctypes launch per kernel)" if not use_graph else "hipGraph replay" if graph_mode == "full"
+                                     else "hipGraph replay of the compute, bucket all-reduces eager between two graphs"),
                           "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

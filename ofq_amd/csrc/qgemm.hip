@@ -529,10 +529,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
 // for the stored-activation pair; the extra int8 GEMM (K = C) is free next to that.
 // QMODE 1: per-row step, index ((m * qrowmul + n / qcoldiv) % qS); QMODE 2: per-column step.
 // Partials: lrow[m][2 * tiles_n] (row mode: sum of dsc over each 64-column half tile), lcol[tiles_m][nacc][N].
-// INTERIOR (launch-time: M and N multiples of 128 and the tile offsets fit 32 bits, every DeiT-S shape): no bounds
-// selects, rows addressed through a uniform base plus one 32-bit lane offset.
-typedef __attribute__((address_space(1))) char* GlobalBytes;
-template <int QMODE, bool GELU, bool INTERIOR = false>
+// (An "interior" instantiation -- no bounds selects, rows addressed through a uniform scalar base plus one 32-bit lane offset,
+// 145 instead of 153 us for qkx -- existed in round 3 and was removed in round 4: at the full DeiT-S size it returned exact
+// zeros for 16-lane groups of dy on tile rows 13 / 77 (accumulator element 5 of the first row block, upper half-wave: the
+// gradients requested BEFORE the k-loop) in ~50 of 25 216 rows, differently from launch to launch, and kept doing so with its
+// loads, selects and stores replaced one by one by this form's; reading its ISA against this one's (same barriers, same
+// s_waitcnt structure around the LDS reuse and the gradient loads, different register allocation: its row offsets live in
+// v[136:137] and are overwritten by the last gradient loads) did not show the cause.  This form is held to bit-identical
+// repeats at full size by tests/test_fullsize_gpu.py::test_recompute_backward_stress.)
+template <int QMODE, bool GELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qgemm_i8_lsqbwd_kernel(QGemmArgs p) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
@@ -567,27 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int ncl[2] = {min(ncol[0], p.N - 1), min(ncol[1], p.N - 1)};
   const bool cok[2] = {ncol[0] < p.N, ncol[1] < p.N};
   float g0[16][2], g1[16][2];
-  // gradient loads and dy stores of the INTERIOR form address rows through a uniform base (scalar registers) plus one
-  // 32-bit lane offset -- this epilogue is issue-bound at two waves per SIMD
-  const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
-  const unsigned lane_g = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldlx + (unsigned)(n0 + wn_s * 64 + l31));
-  const unsigned lane_c = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
-  const float* G_t = G + (int64_t)(m0 + wm_s * 64) * p.ldlx;
-  float* C_t = p.C + (int64_t)(m0 + wm_s * 64) * p.ldc;
   auto gload = [&](float (&g)[16][2], int i) {
-    if (INTERIOR) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        // the row base is pinned in scalar registers (else it is folded into 64-bit VALU adds per element); the pointer is
-        // rebuilt in the global address space, or the loads become flat_load
-        uintptr_t rp = reinterpret_cast<uintptr_t>(G_t + (int64_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldlx);
-        asm volatile("" : "+s"(rp));
-        const GlobalBytes rowp = reinterpret_cast<GlobalBytes>(rp);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) g[e][j] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(rowp + lane_g + 128 * j);
-      }
-      return;
-    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = min(m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, p.M - 1);
@@ -640,14 +625,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
         const int mr = wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
-        const bool mok = INTERIOR || (m0 + mr) < p.M;
+        const bool mok = (m0 + mr) < p.M;
         const float ae = row_a[mr];
         const float alr = row_b[mr], rar = row_c[mr];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           yv[ee][j] = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
           xin[ee][j] = __fadd_rn(GELU ? ofq_gelu(yv[ee][j]) : yv[ee][j], qb[j]);
-          gev[ee][j] = (INTERIOR || (mok && cok[j])) ? g[e][j] : 0.f;
+          gev[ee][j] = (mok && cok[j]) ? g[e][j] : 0.f;
           alv[ee][j] = QMODE == 2 ? qsc[j] : alr;
           ofq_lsq_bwd_fast(xin[ee][j], gev[ee][j], alv[ee][j], QMODE == 2 ? qrc[j] : rar, lo, hi, fl, dq[ee][j], dsc[ee][j]);
         }
@@ -662,17 +647,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
         const int m = m0 + wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
-        uintptr_t rp = reinterpret_cast<uintptr_t>(C_t + (int64_t)(i * 32 + ee + 8 * eg) * p.ldc);        // uniform
-        if (INTERIOR) asm volatile("" : "+s"(rp));
-        const GlobalBytes rowp = reinterpret_cast<GlobalBytes>(rp);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           cb4[j] += dq[ee][j];
           cba[j] += gev[ee][j];
           if (QMODE == 2) cds[j] += dsc[ee][j]; else rds[i * 16 + e] += dsc[ee][j];
           const float dy = GELU ? dq[ee][j] * ofq_gelu_grad(yv[ee][j]) : dq[ee][j];
-          if (INTERIOR) *reinterpret_cast<__attribute__((address_space(1))) float*>(rowp + lane_c + 128 * j) = dy;
-          else if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
+          if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
         }
       }
     }
@@ -3004,17 +2985,10 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
   a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
-  // The INTERIOR form (uniform row bases, no bounds selects: 145 instead of 155-170 us for qkx) is NOT used: at the full
-  // DeiT-S size it returned different dx / d(offset) values on ~50 of the 25 216 rows from launch to launch (always the tile
-  // rows 13 and 77, never with fewer tiles), which tests/test_kernels_gpu.py::test_i8_recompute_backward_is_deterministic
-  // now catches; the cause was not found in the time available (the row-base pins are not it), so the general form runs.
-  static const bool try_interior = getenv("OFQ_LSQBWD_INTERIOR") != nullptr;      // debugging switch
-  const bool interior = try_interior && (M % 128) == 0 && (N % 128) == 0 && 4 * (4 * (ldd > ldg ? ldd : ldg) + N) < (int64_t)0x7fffffff;
   auto launch = [&](auto QM, auto GE) {
     constexpr int qm = decltype(QM)::value;
     constexpr bool ge = decltype(GE)::value;
-    if (interior) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, false>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge>), grid, block, 0, st, a);
   };
   if (q_colmode) {
     if (q_gelu) launch(std::integral_constant<int, 2>(), std::true_type());

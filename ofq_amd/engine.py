@@ -214,6 +214,13 @@ def invalidate_weight_codes(model):
 
 def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
     """Everything of one step that touches the device (train.py:893-933); GraphedTrainStep captures exactly this."""
+    loss = _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp)
+    _step_update(optimizer, dp, cga)
+    return loss
+
+
+def _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp):
+    """zero_grad, StatsQ refresh, forward, loss, backward (with dp: the bucket hooks -- collectives, or packing only)."""
     if dp is not None:
         dp.zero_grad()
     else:
@@ -229,6 +236,7 @@ def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
             invalidate_weight_codes(model)      # the operands are captured by the autograd graph; the cache itself ends here
     loss = loss_fn(out, target, soft_target)
     F_ofq.DW_DEFER = True                       # weight-gradient GEMMs are queued and launched a block at a time
+    F_ofq.begin_backward()
     try:
         loss.backward()
     except BaseException:
@@ -238,6 +246,11 @@ def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
         F_ofq.DW_DEFER = False
     F_ofq.flush_dw()
     F_ofq.assert_step_queues_empty()            # nothing parked, queued or deferred may outlive the backward pass
+    return loss
+
+
+def _step_update(optimizer, dp, cga):
+    """finish the gradient all-reduce, [CGA mask], AdamW, [CGA restore] (train.py:927-933, cga.py:953-1013)."""
     if dp is not None:
         dp.finish_gradient_sync()
     if cga is not None:
@@ -245,7 +258,6 @@ def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
     optimizer.step()
     if cga is not None:
         cga.after_step(optimizer)
-    return loss
 
 
 def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
@@ -278,10 +290,21 @@ class GraphedTrainStep:
     The first `warmup` calls run eagerly (real training steps: lazily created state -- optimizer moments, workspaces,
     CGA masks -- must exist before the capture); the next call captures and replays."""
 
-    def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2, alias_inputs=False):
+    def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2, alias_inputs=False, mode="full"):
         if not hasattr(optimizer, "advance_for_replay"):
             raise RuntimeError("GraphedTrainStep needs ofq_amd.optim.FusedAdamW (per-step scalars in device memory)")
+        if mode not in ("full", "split"):
+            raise ValueError("mode must be 'full' or 'split'")
         self.model, self.optimizer, self.dp, self.cga = model, optimizer, dp, cga
+        # mode "split" (the default of bench.py / train.py with several ranks): captured compute, eager collectives --
+        #   graph A = zero_grad + StatsQ refresh + forward + loss + backward + the packing of the gradient buckets,
+        #   then the bucket all-reduces issued eagerly on RCCL's stream (DataParallel.all_reduce_packed),
+        #   graph B = [CGA masks] + AdamW [+ CGA restore].
+        # No collective is ever captured (RCCL inside a hipGraph has only been exercised with one rank here), the host issues
+        # two graph launches and one collective per bucket per step instead of ~850 kernel launches, and the all-reduce is
+        # exposed (90.8 MB of gradients over xGMI: well under a millisecond of a 22 ms step) instead of overlapped.
+        self.mode = mode if (dp is not None and dp.sync) else "full"
+        self.graph_b = None
         self.loss_fn = loss_fn or KDLossSoftandHard()
         self.warmup = int(warmup)
         self.alias_inputs = bool(alias_inputs)   # True: the tensors of the capturing call ARE the static inputs (bench.py feeds
@@ -313,13 +336,29 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         mode = "global"
         if self.dp is not None and self.dp.sync:
-            # with a process group alive, RCCL's watchdog thread polls the events of earlier collectives: let it retire
-            # them (it looks every 100 ms), and let only this thread's calls count as capture errors
-            import time
-            time.sleep(0.35)
+            # with a process group alive, RCCL's watchdog thread polls the events of earlier collectives: let only this
+            # thread's calls count as capture errors -- and, when collectives are captured, let the watchdog retire the
+            # earlier ones first (it looks every 100 ms)
             mode = "thread_local"
-        with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
-            self.loss = _step_body(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+            if self.mode == "full":
+                import time
+                time.sleep(0.35)
+        if self.mode == "split":
+            self.dp.pack_only = True
+            try:
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
+                    self.loss = _step_compute(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp)
+                    self.dp.finish_gradient_sync()         # packs what the hooks have not packed; starts nothing
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
+                    _step_update(self.optimizer, None, self.cga)
+            finally:
+                self.dp.pack_only = False
+            self.graph_b = gb
+        else:
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
+                self.loss = _step_body(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
+            self.graph_b = None
         self.graph = g
         self.captures += 1
         # the gradient tensors the replays write (static addresses in the graph's pool)
@@ -338,13 +377,16 @@ class GraphedTrainStep:
             self.dp.sync_buffers()
         # the signedness latch of a still-unsigned image quantiser: decide on the host, as the eager forward would
         flipped = False
-        for m, q in self._unsigned_latches():
+        unsigned = self._unsigned_latches()
+        for m, q in unsigned:
             before = q.latched()
             q._latch(q.latch_input(images, getattr(m, "move_b4").bias))
             flipped |= q.latched() != before
-        if self.dp is not None and self.dp.sync and self.dp.world > 1 and self._latches:
+        if self.dp is not None and self.dp.sync and self.dp.world > 1 and unsigned:
             # every rank must take the same decision (re-capture or replay): one rank's batch may flip the latch while the
-            # others' do not -- and sync_buffers() hands rank 0's flag to everybody on the next call anyway
+            # others' do not -- and sync_buffers() hands rank 0's flag to everybody on the next call anyway.  Only while a
+            # latch is still open (the decisions are taken together, so the ranks agree on that too): latch_input() syncs with
+            # the host on those steps anyway, and afterwards the step gains no collective and no host sync from this
             import torch.distributed as dist
             f = torch.tensor([1.0 if flipped else 0.0], device=images.device)
             dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.dp.group)
@@ -363,6 +405,9 @@ class GraphedTrainStep:
                     dst.copy_(src)
         self.optimizer.advance_for_replay()
         self.graph.replay()
+        if self.graph_b is not None:
+            self.dp.all_reduce_packed()
+            self.graph_b.replay()
         if self._static_grads and self._static_grads[0][0].grad is not self._static_grads[0][1]:
             for p, g in self._static_grads:            # an eager step in between re-pointed p.grad: show the replay's
                 p.grad = g

@@ -80,6 +80,14 @@ def assert_step_queues_empty():
     weight-gradient GEMM, no deferred second-stage reduction -- each of them stands for gradient memory that autograd already
     handed on unwritten."""
     assert_no_pending_dx()
+    # a queued kernel wrote to the address of the tensor autograd was given: the leaf's .grad must BE that tensor (adopted),
+    # not a clone AccumulateGrad made of it while it was still unwritten
+    # (leaves of a synchronised DataParallel are exempt: its bucket launch copies their gradients into the bucket slices)
+    bad = [1 for leaf, addr in _ADOPT_CHECK
+           if leaf.grad is not None and leaf.grad.data_ptr() != addr and id(leaf) not in _parallel._GRAD_SLOTS]
+    del _ADOPT_CHECK[:]
+    if bad:
+        raise RuntimeError("ofq_amd: %d deferred gradient(s) were cloned by autograd instead of adopted" % len(bad))
     if _DW_QUEUE or _DW_TILES[0]:
         drop_dw()
         raise RuntimeError("ofq_amd: weight-gradient GEMMs were still queued after flush_dw()")
@@ -109,6 +117,44 @@ _DW_TILES = [0]
 SUM_DEFER = os.environ.get("OFQ_NO_SUM_DEFER") is None     # A/B switch
 
 
+# Leaves that own a queued (= handed to autograd, not yet written) gradient.  A second gradient for such a leaf (module
+# called twice, tied weights, shared quantiser) is ADDED to the first one by autograd the moment its node returns -- so the
+# first one has to be written by then: whoever is about to produce a gradient for a leaf in this set flushes the queues
+# first (_settle) and takes the immediate path.  Emptied by every flush.
+_QUEUED_LEAVES = set()
+# ... and leaves that have been given a queued gradient at any time in the running backward pass.  Autograd keeps the
+# gradients of a leaf with several producers in the input buffer of its AccumulateGrad node until the last one has arrived
+# (`leaf.grad` stays None meanwhile) and ADDS each newcomer to the buffer at once: a second gradient must therefore never be
+# queued, also when the first one has been flushed in between.  Lives for one backward pass (begin_backward).
+_DEFERRED_ONCE = set()
+_ADOPT_CHECK = []          # (leaf, address the queued kernel wrote): verified at the end of the step
+
+
+def begin_backward():
+    """engine._step_body, right before loss.backward()."""
+    _QUEUED_LEAVES.clear()
+    _DEFERRED_ONCE.clear()
+    del _ADOPT_CHECK[:]
+
+
+def _settle(*leaves):
+    """Before an immediate gradient for `leaves` goes back to autograd: launch the queues if one of them still waits there."""
+    if any(t is not None and id(t) in _QUEUED_LEAVES for t in leaves):
+        flush_dw()
+
+
+def _claim(*leaves):
+    """True (and the leaves marked) when their gradients may be queued; False after settling when one of them already owns a
+    queued gradient, or the same leaf appears twice."""
+    ids = [id(t) for t in leaves if t is not None]
+    if any(i in _DEFERRED_ONCE for i in ids) or len(set(ids)) != len(ids):
+        _settle(*leaves)
+        return False
+    _QUEUED_LEAVES.update(ids)
+    _DEFERRED_ONCE.update(ids)
+    return True
+
+
 def _sums_deferrable(*leaves):
     """True when the parameter gradients a backward kernel is about to produce may be written later: inside the training
     step, and every receiving tensor is a leaf whose .grad is empty -- autograd then adopts the returned tensor as the
@@ -120,9 +166,12 @@ def _sums_deferrable(*leaves):
             continue
         # (a leaf that does not require a gradient: autograd drops the returned tensor at once, and the queued kernel
         # would write into memory that has been handed to somebody else by then)
-        if not t.is_leaf or not t.requires_grad or t.grad is not None:
+        if not t.is_leaf or not t.requires_grad:
             return False
-    return True
+        if t.grad is not None:       # the new gradient will be accumulated into .grad: that one must not be waiting in a queue
+            _settle(*leaves)
+            return False
+    return _claim(*leaves)
 
 
 class _Immediate:
@@ -136,6 +185,12 @@ class _Immediate:
 def sum_scope(*leaves):
     """Context for a backward kernel call: ops.deferred_sums() when its reductions may wait (see _sums_deferrable)."""
     return ops.deferred_sums() if _sums_deferrable(*leaves) else _Immediate()
+
+
+def has_queued_work():
+    """Anything for flush_dw() to launch?  (host-side counters only: never loads the library, parallel.DataParallel asks
+    from its gradient hooks, also on the CPU / gloo path)"""
+    return bool(_DW_QUEUE) or bool(ops._SUM_KEEP) or (ops._lib_handle is not None and ops._lib_handle.ofq_sum_pending() != 0)
 
 
 def flush_dw():
@@ -154,12 +209,14 @@ def flush_dw():
         drop_dw()                 # never carry raw output addresses of a failed step into the next one
         raise
     _DW_TILES[0] = 0
+    _QUEUED_LEAVES.clear()        # everything that was queued is on the stream now
 
 
 def drop_dw():
     """Forget the queue (a backward pass that raised)."""
     del _DW_QUEUE[:]
     _DW_TILES[0] = 0
+    _QUEUED_LEAVES.clear()
     ops.sum_drop()
 
 
@@ -279,16 +336,25 @@ class CodesLinearFn(torch.autograd.Function):
             # a queued result is still unwritten when autograd accumulates it: that is only sound when accumulating means
             # adopting the tensor (no gradient there yet), never adding to one
             w_leaf, b_leaf = aux.get("w_leaf"), ctx.bias_leaf
-            adopt = ((w_leaf is None or w_leaf.grad is None) and (b_leaf is None or b_leaf.grad is None)
-                     and (not ctx.has_bias or b_leaf is not None))
-            if DW_DEFER and DW_GROUP and adopt and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"],
-                                                                    dy2d.stride(0), xc2.stride(0)):
+            # (a weight that is not a leaf -- W_qk -- may wait only when the node that consumes its gradient flushes the
+            # queue before reading it: WqkFn / AllWqkFn say so through aux["w_flushes"])
+            adopt = ((w_leaf.grad is None if w_leaf is not None else bool(aux.get("w_flushes")))
+                     and (b_leaf is None or b_leaf.grad is None) and (not ctx.has_bias or b_leaf is not None))
+            if (DW_DEFER and DW_GROUP and adopt and ops.tn_groupable(dy2d.shape[0], N_out, K_in, aux["act_S"],
+                                                                     dy2d.stride(0), xc2.stride(0))
+                    and _claim(w_leaf, b_leaf)):
                 dW, db = queue_dw(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], aux["baft"], slot,
                                   db_to_autograd=bool(ctx.has_bias and ctx.needs_input_grad[2]))
+                if w_leaf is not None:
+                    _ADOPT_CHECK.append((w_leaf, dW.data_ptr()))
+                if b_leaf is not None and db is not None:
+                    _ADOPT_CHECK.append((b_leaf, db.data_ptr()))
             else:
+                _settle(w_leaf, b_leaf)
                 dW, db = ops.qgemm_bf16s_tn(dy2d, xc2, aux["act_s"], aux["act_S"], aux["act_gscale"], None, aux["baft"],
                                             compute_db=True, out=slot)
         else:
+            _settle(aux.get("w_leaf"), ctx.bias_leaf)
             db = ops.colsum(dy2d) if need_db else None
             dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
         return dx, dW, (db if ctx.has_bias else None), None
@@ -314,7 +380,8 @@ def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=N
            "w_mult": 1.0 / float(2 ** wquant.num_bits), "baft": baft.detach() if baft is not None else None,
            "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc,
            # StatsQ's backward is the identity (statsq.py:148), so dW of a leaf weight IS its .grad: see parallel.grad_slot
-           "w_leaf": weight if (weight.is_leaf and weight.requires_grad) else None}
+           "w_leaf": weight if (weight.is_leaf and weight.requires_grad) else None,
+           "w_flushes": bool(getattr(weight, "_ofq_flushes", False))}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 
@@ -333,7 +400,7 @@ class WqkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_dw()
+        flush_dw()                         # (the promise behind wqk(): a queued W_qk gradient is written before it is read)
         Wq, Wk = ctx.saved_tensors
         H = ctx.H
         C = Wq.shape[1]
@@ -410,6 +477,7 @@ def all_wqk(attns):
         ws += [a.q.weight, a.k.weight]
     outs = AllWqkFn.apply(a0.num_heads, *ws)
     for a, w in zip(attns, outs):
+        w._ofq_flushes = True              # AllWqkFn.backward flushes the dW queue before it reads this tensor's gradient
         a._wqk_pre = w
     if STEP_CACHE_ACTIVE:
         # the StatsQ operands of the 12 W_qk in one launch (their per-block launches are as latency-bound as the GEMMs)

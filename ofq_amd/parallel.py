@@ -90,9 +90,16 @@ class DataParallel(torch.nn.Module):
         self._arrival = None               # parameter arrival order of the first synchronised backward (then: buckets rebuilt)
         self._rebuilt = False
         self._buffers_settled = False
+        # pack_only: the gradient hooks pack each bucket (and point p.grad at its slices) but start no collective;
+        # all_reduce_packed() then reduces every bucket eagerly.  This is how engine.GraphedTrainStep(mode="split") keeps
+        # RCCL out of its captured graphs: [graph: forward + backward + packing] -> eager all-reduces -> [graph: optimiser].
+        self.pack_only = False
         if broadcast and self.sync:
             self.broadcast_parameters()
         self._build_buckets(bucket_mb)
+        if self.sync_statsq:               # allocated here, not inside a stream capture (where it would be re-zeroed by every replay)
+            p0 = next(self.module.parameters())
+            self._statsq_pending = torch.zeros((), dtype=torch.float32, device=p0.device)
 
     # -- rank 0's parameters and buffers win (train.py:727: DDP's constructor broadcast)
     @torch.no_grad()
@@ -198,7 +205,7 @@ class DataParallel(torch.nn.Module):
         all-reduce (its stream waits for the kernels queued so far, then runs next to the rest of backward) and point
         every p.grad at its slice, which will hold the averaged value once the work completes."""
         fn = sys.modules.get(__package__ + ".functional")
-        if fn is not None:
+        if fn is not None and fn.has_queued_work():
             fn.flush_dw()             # deferred weight-gradient GEMMs (functional.queue_dw) write into these gradients
         have = [(v, p.grad) for v, p in zip(b.views, b.params) if p.grad is not None]
         if len(have) < len(b.params):
@@ -211,6 +218,9 @@ class DataParallel(torch.nn.Module):
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(b.views, b.params):
             p.grad = v
+        if self.pack_only:
+            b.work = "packed"
+            return
         if self._avg:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:
@@ -239,6 +249,9 @@ class DataParallel(torch.nn.Module):
             for b in self.buckets:
                 if b.work is None:                      # bucket with parameters that got no gradient this step
                     self._launch(b)
+            if self.pack_only:                          # the collectives are the caller's (all_reduce_packed)
+                self._reset()
+                return
             if self.sync_statsq:
                 self._statsq_all_reduce()
             for b in self.buckets:
@@ -267,6 +280,23 @@ class DataParallel(torch.nn.Module):
                 return
         self._reset()
 
+    def all_reduce_packed(self):
+        """The bucket all-reduces of a pack_only step, issued together (RCCL's stream waits for the packing kernels queued
+        so far; the current stream then waits for the four collectives), then the StatsQ-scale check if it is on."""
+        if not self.sync:
+            return
+        works = []
+        for b in self.buckets:
+            if self._avg:
+                works.append(dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            else:
+                b.flat.div_(self.world)
+                works.append(dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.sync_statsq:
+            self._statsq_all_reduce()
+        for w in works:
+            w.wait()
+
     def _statsq_all_reduce(self):
         """all-reduce(mean) of every StatsQ scale vector of this step's forward; must leave them unchanged."""
         vecs = [m._s_dev.reshape(-1) for m in self.module.modules() if getattr(m, "_s_dev", None) is not None]
@@ -280,17 +310,20 @@ class DataParallel(torch.nn.Module):
             dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group)
             mean.div_(self.world)
         dev = (mean - local).abs().max()                 # stays on the device ...
-        self._statsq_pending = dev if self._statsq_pending is None else torch.maximum(self._statsq_pending, dev)
+        if self._statsq_pending is None:                 # (a persistent scalar: a captured step max-accumulates into the
+            self._statsq_pending = torch.zeros((), dtype=dev.dtype, device=dev.device)     # same memory in every replay)
+        self._statsq_pending.copy_(torch.maximum(self._statsq_pending, dev))
         self._steps += 1
         if self._steps % self.statsq_check_every == 0 and not _capturing(local):
-            self.check_statsq_pending()                   # ... and is looked at every few steps
+            self.check_statsq_pending()                   # ... and is looked at every few steps (replays: by the host loop)
 
     def check_statsq_pending(self):
         """Host check of the deviations accumulated by _statsq_all_reduce (a synchronisation point).  Averaging identical
         values over a power-of-two number of ranks is exact; otherwise the mean may differ from the value in its last bit."""
         if self._statsq_pending is None:
             return 0.0
-        dev, self._statsq_pending = float(self._statsq_pending), None
+        dev = float(self._statsq_pending)
+        self._statsq_pending.zero_()
         if dev > 0.0 and (self.world & (self.world - 1)) == 0:
             raise RuntimeError("ofq_amd DataParallel: StatsQ scales differ between ranks by %g -- the replicas' weights "
                                "have diverged" % dev)
@@ -306,9 +339,10 @@ class DataParallel(torch.nn.Module):
             h.remove()
         self._hooks = []
         for b in self.buckets:
-            for p in b.params:
+            for p, v in zip(b.params, b.views):
                 hit = _GRAD_SLOTS.get(id(p))
-                if hit is not None and hit[0]() is p:
+                # (only this wrapper's entries: a newer wrapper on the same module has replaced them with its own views)
+                if hit is not None and hit[0]() is p and hit[1].data_ptr() == v.data_ptr():
                     del _GRAD_SLOTS[id(p)]
 
     def __del__(self):

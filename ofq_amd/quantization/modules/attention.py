@@ -281,6 +281,7 @@ def qkr_attention_core(self, x, scale, addend=None, pre_quant=None):
         Wqk_fp = getattr(self, "_wqk_pre", None)          # all blocks' W_qk in one batched GEMM (functional.all_wqk)
         if Wqk_fp is None:
             Wqk_fp = WqkFn.apply(self.q.weight, self.k.weight, H)
+            Wqk_fp._ofq_flushes = True      # WqkFn.backward flushes the dW queue before it reads this tensor's gradient
         if use_codes:
             qkx = codes_linear(xq, xcodes, xgeom, xin.input_quant_fn, xin.move_aft.bias, Wqk_fp, self.qk_quant, None,
                                fuse=qspec, xgrad_acc=xacc)

@@ -280,8 +280,10 @@ def main_worker(local_rank, args, cga, spawned):
     first, last = (args.epochs, args.epochs + args.freeze_for_n_epochs) if cga else (start_epoch, args.epochs + args.cooldown_epochs)
     graphed = None
     multi_rank = dp is not None and getattr(dp, "world", 1) > 1
-    if not args.no_graph and hasattr(optimizer, "advance_for_replay") and (not multi_rank or args.graph):
-        graphed = engine.GraphedTrainStep(model, optimizer, loss_fn, dp=dp, cga=hooks)
+    if not args.no_graph and hasattr(optimizer, "advance_for_replay"):
+        # several ranks: captured compute, eager bucket all-reduces between two graphs (--graph: collectives captured too)
+        graphed = engine.GraphedTrainStep(model, optimizer, loss_fn, dp=dp, cga=hooks,
+                                          mode="split" if (multi_rank and not args.graph) else "full")
     no_soft = torch.zeros(args.batch_size, args.num_classes, device=dev)
     for epoch in range(first, last):                                                        # cga.py:760 / train.py:816
         model.train()
@@ -307,6 +309,8 @@ def main_worker(local_rank, args, cga, spawned):
                 loss = engine.train_step(model, optimizer, x, y, soft, loss_fn, dp=dp, cga=hooks)
             if bi % args.log_interval == 0 or bi == len(loader) - 1:
                 torch.cuda.synchronize()                                                    # train.py:944
+                if dp is not None and dp.sync_statsq:
+                    dp.check_statsq_pending()     # --sync-statsq: raises when the replicas' StatsQ scales have drifted apart
                 bt = time.time() - end
                 lv = loss.detach().clone()
                 if world > 1:

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import rel_err
+
 pytestmark = pytest.mark.gpu
 
 
@@ -54,7 +56,7 @@ def _lr_at(i):
     return 5e-4 * (1.0 - 0.07 * i)          # a schedule: the captured AdamW launches must pick up every change
 
 
-def _run(base, steps, graphed, batches, cga=False, dp_factory=None, qk_reparam=True):
+def _run(base, steps, graphed, batches, cga=False, dp_factory=None, qk_reparam=True, mode="full"):
     from ofq_amd import engine
     from ofq_amd.quantization.utils import KDLossSoftandHard
     model = copy.deepcopy(base).train()
@@ -62,7 +64,7 @@ def _run(base, steps, graphed, batches, cga=False, dp_factory=None, qk_reparam=T
     opt = engine.make_optimizer(model, lr=_lr_at(0), weight_decay=0.05)
     hooks = engine.CGAHooks(model, 3, 0.05, qk_reparam=qk_reparam) if cga else None
     loss_fn = KDLossSoftandHard()
-    gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=hooks, warmup=2) if graphed else None
+    gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, cga=hooks, warmup=2, mode=mode) if graphed else None
     losses = []
     for i in range(steps):
         for g in opt.param_groups:
@@ -186,6 +188,46 @@ def test_deferred_second_stage_sums_equal_immediate(variant):
             assert torch.equal(ga[n], gb[n]), (variant, step, n, float((ga[n] - gb[n]).abs().max()))
 
 
+def test_a_block_used_twice_in_one_step_gets_the_sum_of_both_gradients():
+    """Tied weights / a module called twice: every leaf of the second block receives TWO gradients in one backward pass.
+    The deferred launches (queued dW GEMMs, queued second-stage sums) hand autograd tensors that are written later, which is
+    only sound for a gradient that is adopted, never for one that is added to another: the second gradient of a leaf must
+    take the immediate path (functional._claim).  Gradients inside engine's step == gradients of a plain backward pass."""
+    from ofq_amd import engine
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    import ofq_amd.functional as Fn
+    base = _tiny(qk_reparam=True, depth=2)
+    b0 = _batch(seed=5)
+    engine.setup_alpha(base, b0[0])
+    base.blocks[1] = base.blocks[0]                      # the same parameters, quantisers and biases, twice per forward
+    loss_fn = KDLossSoftandHard()
+    grads = {}
+    for mode in ("plain", "step"):
+        model = copy.deepcopy(base).train()
+        assert model.blocks[1] is model.blocks[0]
+        if mode == "plain":
+            out, _ = model(b0[0])
+            loss_fn(out, b0[1], b0[2]).backward()
+        else:
+            opt = engine.make_optimizer(model, lr=0.0, weight_decay=0.0)
+            queued = [0]
+            real = Fn.queue_dw
+
+            def counting(*a, **k):
+                queued[0] += 1
+                return real(*a, **k)
+            Fn.queue_dw = counting
+            try:
+                engine.train_step(model, opt, *b0)
+            finally:
+                Fn.queue_dw = real
+            assert queued[0] == 1, queued           # fc2 (the tiny model's one groupable layer): first visit deferred, second not
+        grads[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads["plain"].keys() == grads["step"].keys()
+    for n, g in grads["plain"].items():
+        assert rel_err(grads["step"][n].cpu(), g.cpu()) < 1e-5, n
+
+
 def test_graph_replay_with_cga_hooks_equals_eager():
     """Config C5: QAttention_qkreparam_4_cga model, freeze masks recomputed from the weights inside every replay, mask and
     restore folded into the AdamW launch (cga.py:953-1013).  boundaryRange 0.05 so that a good share of weights freezes."""
@@ -274,6 +316,46 @@ def test_data_parallel_over_rccl_one_rank_equals_plain_step_and_graph():
         assert copied < 0.6 * total, (copied, total)
         assert not [n for n in packed if n.endswith(("fc1.weight", "fc2.weight", "proj.weight", "attn.v.weight"))
                     and "blocks" in n], packed
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_graph_step_with_eager_collectives_equals_the_eager_step():
+    """engine.GraphedTrainStep(mode="split"), the several-rank default of bench.py / train.py: graph A = zero_grad + StatsQ
+    refresh + forward + loss + backward + bucket packing, then the bucket all-reduces issued eagerly on RCCL's stream, then
+    graph B = CGA masks + AdamW + restore (train.py:474, :727, :927-933; cga.py:953-1013).  One rank over RCCL (a 1-GPU box)
+    against the eager DataParallel step and the plain step: losses, parameters and AdamW state bit for bit over seven steps
+    with the CGA hooks on, a changing learning rate, alternating batches and the stem quantiser's signedness latch flipping in
+    the fifth step (re-capture of both graphs); no collective may sit inside either graph."""
+    from ofq_amd import engine, parallel
+    dist = _init_pg()
+    try:
+        base = _tiny(qk_reparam_type=1)
+        pos, neg = _batch(seed=4, nonneg=True), _batch(seed=5)
+        engine.setup_alpha(base, pos[0])
+        seq = [pos, pos, pos, pos, neg, neg, pos]
+
+        def mk(model):
+            return parallel.DataParallel(model, bucket_mb=1.0, force_sync=True, sync_statsq=True)
+        lp, sp, _, _ = _run(base, len(seq), False, seq, cga=True)
+        le, se, _, _ = _run(base, len(seq), False, seq, cga=True, dp_factory=mk)
+        calls = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(torch.cuda.is_current_stream_capturing())
+            return real(t, *a, **k)
+        dist.all_reduce = spy
+        try:
+            lg, sg, gs, mg = _run(base, len(seq), True, seq, cga=True, dp_factory=mk, mode="split")
+        finally:
+            dist.all_reduce = real
+        assert gs.mode == "split" and gs.graph_b is not None and gs.captures == 2
+        assert calls and not any(calls), "a collective was issued inside a stream capture"
+        assert lp == le == lg, (lp, le, lg)
+        _same(se, sg)
+        _same(sp, sg)
+        assert mg.patch_embed.proj.input_quant_fn.latched()
     finally:
         dist.destroy_process_group()
 

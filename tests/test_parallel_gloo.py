@@ -106,6 +106,31 @@ def _worker(rank, world, port, q):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert torch.equal(lo, hi)
+    # pack_only + all_reduce_packed (the two halves engine.GraphedTrainStep(mode="split") puts around its eager collectives):
+    # the hooks only pack -- gradients are the LOCAL ones, already views of the buckets -- then one call reduces every bucket;
+    # the result is the overlapped path's
+    dp.zero_grad()
+    (((dp(xs) - ys) ** 2).mean() + 0.0 * net.extra.sum()).backward()
+    dp.finish_gradient_sync()
+    g_sync = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad]).clone()
+    dp.pack_only = True
+    dp.zero_grad()
+    (((dp(xs) - ys) ** 2).mean() + 0.0 * net.extra.sum()).backward()
+    dp.finish_gradient_sync()
+    dp.pack_only = False
+    g_local = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad]).clone()
+    for b in dp.buckets:
+        for p in b.params:
+            assert p.grad.untyped_storage().data_ptr() == b.flat.untyped_storage().data_ptr()
+    net4 = copy.deepcopy(net)
+    for p in net4.parameters():
+        p.grad = None
+    (((net4(xs) - ys) ** 2).mean() + 0.0 * net4.extra.sum()).backward()
+    g_own = torch.cat([p.grad.reshape(-1) for p in net4.parameters() if p.requires_grad])
+    assert torch.allclose(g_local, g_own, rtol=1e-6, atol=1e-8)          # nothing was reduced yet
+    dp.all_reduce_packed()
+    g_packed = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
+    assert torch.equal(g_packed, g_sync)
     # StatsQ statistic is a pure function of the (identical) weights: max - min over ranks must be exactly 0
     class Holder(nn.Module):
         pass

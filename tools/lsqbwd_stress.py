@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ofq_qgemm_i8_lsq_bwd at the DeiT-S token count, 60 launches on the same operands: counts launches whose outputs differ
-from the first one (0 for the shipped general form; OFQ_LSQBWD_INTERIOR=1 selects the withdrawn interior form: 59 of 59)."""
+from the first one (0 for the shipped form; the interior form that was removed in round 4 gave 59 of 59)."""
 import sys, torch
 sys.path.insert(0, ".")
 from ofq_amd import ops
