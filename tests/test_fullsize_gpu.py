@@ -335,7 +335,7 @@ def _qkx_recompute_case(ops, Bf=128):
     cs = torch.rand(Hf * Cf, device="cuda", generator=g) * 0.05
     r = torch.randn(Hf * Cf, device="cuda", generator=g) * 0.1
     qs = torch.rand(Nf * Hf, device="cuda", generator=g) * 0.5 + 0.3
-    b4 = torch.randn(Cf, device="cuda", generator=g) * 0.1
+    b4 = torch.randn(Hf * Cf, device="cuda", generator=g) * 0.1
     q = {"s": qs, "S": Nf * Hf, "gscale": 0.01, "b4": b4, "lo": -2, "hi": 1, "gelu": False, "rowmul": Hf, "coldiv": Cf, "colmode": 0}
     prod = {"xcodes": qa, "wcodes": qw, "bias": None, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": s, "act_S": Nf, "act_gscale": 0.01}
     gy = torch.randn(Bf * Nf, Hf * Cf, device="cuda", generator=g)

@@ -1,0 +1,176 @@
+"""Full-depth parity of BASELINE.json's config 4 (Swin-T W3A3, QKR window attention) and of the CGA fine-tune (config 5) at
+real dimensions, on the HIP path against the CPU oracle.
+
+Swin-T: all 12 blocks (stages of 2 / 2 / 6 / 2 at dims 96 / 192 / 384 / 768, heads 3 / 6 / 12 / 24, windows of 7 x 7 tokens,
+every other block shifted) and the three PatchMerging layers with their quantised `reduction` (swin.py:40-60, :441-470;
+swin_attention_and_mlp.py:253-461), two images, TEACHER-FORCED like tests/test_depth12_gpu.py: each HIP block / merging layer
+gets the oracle's input of that layer; output, input gradient and every parameter gradient against the oracle's.  The same
+caveat holds (a 3-bit 12-block network is discontinuous: a value within fp32 noise of a rounding tie takes the neighbouring
+level under another summation order and touches the tokens of its window): tokens touched by a flip are counted and bounded,
+the others must agree to 1e-3, and at least half of the blocks must be flip-free in the output and every gradient.
+
+CGA (cga.py:450-469, :953-1013) at DeiT-S size: the freeze masks of all 48 quantised weight matrices against the oracle's
+freeze_outside_boundary_weight_idx, bit for bit, and the frozen weights across a real step; the Swin branch (cga.py:957-964,
+`reduction` included) on the full Swin-T."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ofq_oracle as O
+from test_depth12_gpu import _l2, _token_flips, TOL
+
+pytestmark = pytest.mark.gpu
+
+SWIN_T = dict(depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window=[7, 7], patch=4, wbits=3, abits=3, qkr=True)
+
+
+def _build_swin(seed=0):
+    from ofq_amd import engine
+    model = engine.build_student("swin_t", 3, 3, qk_reparam=True, seed=42).cuda()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():                      # biases / offsets off zero (see tests/test_depth12_gpu.py)
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "norm" not in n:
+                p.add_(0.05 * torch.randn(p.shape, generator=g).cuda())
+    img = torch.randn(2, 3, 224, 224, generator=g).cuda()
+    engine.setup_alpha(model, img)
+    return model, img
+
+
+def _oracle_block(x, p, cfg, si, li):
+    """one SwinTransformerBlock of O.swin_forward (swin.py:206-230 with the Q-modules)"""
+    C = x.shape[-1]
+    shift = [0 if li % 2 == 0 else w // 2 for w in cfg["window"]]
+    h = F.layer_norm(x, (C,), p["norm1.weight"], p["norm1.bias"], 1e-5)
+    x = x + O.swin_window_attention(h, O._sub(p, "attn."), cfg["num_heads"][si], cfg["window"], shift, cfg["wbits"], cfg["abits"],
+                                    cfg["qkr"])
+    h = F.layer_norm(x, (C,), p["norm2.weight"], p["norm2.bias"], 1e-5)
+    return x + O.qmlp(h, O._sub(p, "mlp."), cfg["wbits"], cfg["abits"])
+
+
+def _oracle_layers(img, sd, cfg):
+    """O.swin_forward unrolled: [(kind, prefix, stage, layer, input of that layer)] for every block and merging layer."""
+    x = O.qconv_patch_embed_nhwc(img, O._sub(sd, "features.0.0."), cfg["patch"])
+    x = F.layer_norm(x, (x.shape[-1],), sd["features.0.2.weight"], sd["features.0.2.bias"], 1e-5)
+    out, fi = [], 1
+    for si, depth in enumerate(cfg["depths"]):
+        for li in range(depth):
+            pre = "features.%d.%d." % (fi, li)
+            out.append(("block", pre, si, li, x))
+            x = _oracle_block(x, O._sub(sd, pre), cfg, si, li)
+        fi += 1
+        if si < len(cfg["depths"]) - 1:
+            pre = "features.%d." % fi
+            out.append(("merge", pre, si, 0, x))
+            x = O.swin_patch_merging(x, O._sub(sd, pre), cfg["wbits"], cfg["abits"])
+            fi += 1
+    return out
+
+
+def test_every_block_and_merging_layer_of_swin_t_teacher_forced():
+    model, img = _build_swin()
+    model.train()
+    cfg = SWIN_T
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        layers = _oracle_layers(img.cpu(), sd, cfg)
+    assert sum(k == "block" for k, *_ in layers) == 12 and sum(k == "merge" for k, *_ in layers) == 3
+    mods = dict(model.named_modules())
+    gen = torch.Generator().manual_seed(7)
+    clean, rows = 0, []
+    for kind, pre, si, li, xin in layers:
+        hip = mods[pre[:-1]]
+        p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "clip_val" not in k) for k, v in O._sub(sd, pre).items()}
+        xo = xin.clone().requires_grad_(True)
+        yo = _oracle_block(xo, p, cfg, si, li) if kind == "block" else O.swin_patch_merging(xo, p, cfg["wbits"], cfg["abits"])
+        up = torch.randn(yo.shape, generator=gen)
+        (yo * up).sum().backward()
+        hip.zero_grad(set_to_none=True)
+        xh = xin.cuda().requires_grad_(True)
+        yh = hip((xh, None))
+        yh = yh[0] if isinstance(yh, tuple) else yh
+        (yh * up.cuda()).sum().backward()
+        flips, l2_rest = _token_flips(yh, yo)
+        ntok = yo.numel() // yo.shape[-1]
+        assert flips <= max(ntok // 10, 49) and l2_rest < TOL and _l2(yh, yo) < 2e-2, (pre, flips, l2_rest, _l2(yh, yo))
+        errs = {"dx": _l2(xh.grad, xo.grad)}
+        big = max(float(v.grad.abs().max()) for k, v in p.items() if v.grad is not None)
+        for n, q in hip.named_parameters():
+            if q.grad is None:
+                continue
+            ref = p[n].grad
+            assert ref is not None, (pre, n)
+            if "move_" in n and float(ref.abs().max()) < 1e-4 * big:
+                continue                      # offsets whose gradient is identically zero in exact arithmetic: noise
+            errs[n] = _l2(q.grad, ref)
+        ok = flips == 0 and max(errs.values()) < TOL
+        clean += int(ok and kind == "block")
+        rows.append((pre, flips, l2_rest, _l2(yh, yo), max(errs.values()), max(errs, key=errs.get)))
+        if kind == "merge":                   # LayerNorm + one quantised linear layer: no attention to spread a flip
+            assert flips <= 8 and _l2(yh, yo) < 5e-3, rows[-1]
+    print("\nSwin-T W3A3 QKR: layer, tokens touched by a flip, l2(y) on the rest, l2(y) overall, worst gradient l2 (which)")
+    for r in rows:
+        print("   %-16s %4d  %.2e  %.2e  %.2e  %s" % r)
+    assert clean >= 6, rows
+
+
+@pytest.mark.parametrize("model_type", ["deit", "swin"])
+def test_cga_masks_and_frozen_weights_at_full_size(model_type):
+    """Config C5 at its real size: CGAHooks + FusedAdamW on every quantised weight matrix of DeiT-S W2A2 (qk_reparam_type=1:
+    48 tensors) / Swin-T W3A3 (cga.py:957-964: fc1, fc2, v, proj and the PatchMerging `reduction`s), 8 images.  The masks a
+    step uses are the oracle's freeze_outside_boundary_weight_idx (cga.py:450-469) of the weights the step started from, bit
+    for bit on every tensor; every frozen weight leaves the step bit-identical, every other quantised weight with a
+    gradient moves."""
+    from ofq_amd import engine
+    if model_type == "deit":
+        name, bits, nexp = "deit_small_distilled_patch16_224", 2, 48
+    else:
+        name, bits, nexp = "swin_t", 3, 51
+    br = 0.005
+    torch.manual_seed(0)
+    model = engine.build_student(name, bits, bits, qk_reparam=True, qk_reparam_type=1).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    imgs = torch.randn(8, 3, 224, 224, device="cuda", generator=g)
+    tgt = torch.randint(0, 1000, (8,), device="cuda", generator=g)
+    soft = torch.randn(8, 1000, device="cuda", generator=g)
+    engine.setup_alpha(model, imgs)
+    model.train()
+    opt = engine.make_optimizer(model, lr=1e-3, weight_decay=0.05)
+    hooks = engine.CGAHooks(model, bits, br, qk_reparam=True, model_type=model_type)
+    assert len(hooks.mods) == nexp, len(hooks.mods)
+    if model_type == "swin":
+        assert sum(k.endswith("reduction") for k, _ in hooks.mods) == 3
+    engine.train_step(model, opt, imgs, tgt, soft, cga=hooks)         # creates the AdamW state; masks of the initial weights
+    before = {k: m.weight.detach().clone() for k, m in hooks.mods}
+    want = {k: O.cga_freeze_idx(w.cpu(), bits, br) for k, w in before.items()}
+    seen = {}
+    real = hooks.after_step
+
+    def spy(optimizer=None):
+        seen.update({k: hooks.state[k][0].detach().clone() for k, _ in hooks.mods})
+        return real(optimizer)
+    hooks.after_step = spy
+    engine.train_step(model, opt, imgs, tgt, soft, cga=hooks)
+    torch.cuda.synchronize()
+    frozen_total = 0
+    for k, m in hooks.mods:
+        frz = seen[k].float().cpu().reshape(want[k].shape)
+        # bit for bit -- up to the known limit of the StatsQ scale: the row mean |W| is correctly rounded on
+        # the GPU (fp64 sum) and cascade-summed by torch-CPU, so s can differ in its last bit, and a weight whose W / s lies
+        # within that bit of an edge of the +-boundaryRange band lands on the other side (measured: 1 element of Swin-T's
+        # 27.5 M, none of DeiT-S's 21.2 M); any other disagreement is an error
+        diff = frz != want[k]
+        if bool(diff.any()):
+            W = before[k].cpu()
+            sc = 2 * W.abs().mean(dim=1, keepdim=True)
+            b4 = torch.clamp(W / sc, -1.0, 1.0 - 1e-6) * float(2 ** (bits - 1)) - 0.5
+            frac = (b4 - torch.floor(b4))[diff]                 # distance of the level coordinate from the integer below
+            edge = torch.minimum((frac - (0.5 - br)).abs(), (frac - (0.5 + br)).abs())
+            edge = torch.minimum(edge, torch.minimum((frac - (1.5 - br)).abs(), (frac + (0.5 - br)).abs()))
+            assert int(diff.sum()) <= 2 and float(edge.max()) < 1e-5, (k, int(diff.sum()), float(edge.max()))
+        f = (frz != 0).cuda()
+        frozen_total += int(f.sum())
+        assert torch.equal(m.weight.detach()[f], before[k][f]), k          # frozen: bit-identical across the step
+        moved = (m.weight.detach()[~f] != before[k][~f]).float().mean().item()
+        assert moved > 0.9, (k, moved)                                      # the others took their AdamW update
+    assert frozen_total > 0
