@@ -3911,7 +3911,7 @@ extern "C" size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs) {
 static int nt_sk_grid(int64_t tiles, int num_wgs) {
   for (int64_t g = num_wgs; 4 * g >= 3 * (int64_t)num_wgs && g >= 1; --g)
     if (tiles % g == 0) return (int)g;
-  return (int)(tiles < num_wgs ? tiles : num_wgs);
+  return num_wgs;                 // cut tiles (also when there are fewer tiles than CUs: late Swin stages, 98 tiles of 96 k-steps)
 }
 
 // 1: the streaming launch is expected to beat the one-tile-per-workgroup launch (a workgroup gets at least 24 k-steps: what
