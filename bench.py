@@ -16,7 +16,7 @@ Prints ONE JSON line on rank 0, with two extra objects:
                   measured live over a second pass of the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak
                   (`frac`); every algorithmic FMA of the split kernels is three bf16 MFMA FMAs, so the matrix pipe is busy
                   3x that fraction (`mfma_pipe_frac`); `mfma_util_pmc` / `traffic` come from the committed rocprofv3 PMC
-                  passes of the same kernel sources (profiles/r03_traffic.json)
+                  passes of the same kernel sources (profiles/r04_traffic.json)
   cpu_baseline  — oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path) timed on this box's
                   host cores on a bounded sample (DeiT-S W2A2 QKR, batch 8, a few steps), rank 0 at N = 1 only
 """
@@ -37,7 +37,7 @@ PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
          "qgemm_i8": 5000.0,       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
          "qattn_scores_softmax": 5000.0,   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
          "qattn_dp_softmax_bwd": 2500.0}   # (fused dP GEMM + softmax backward: VALU / HBM-bound)
-PROFILE_JSON = "r03_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
+PROFILE_JSON = "r04_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
 
 
 def parse():

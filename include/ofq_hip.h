@@ -382,6 +382,18 @@ int ofq_sum_flush(ofq_stream_t stream);
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
 int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
 
+/*  KD loss of the shipped recipes (KDLossSoftandHard, src/quantization/utils.py:59-77, train.py:906-913), value and gradients:
+ *            loss = mean_b(-sum_k softmax(teacher_b)[k] log_softmax(dist_b)[k]) + mean_b(-log_softmax(cls_b)[target_b]);
+ *            dcls / ddist [B][K] = d loss / d logits (contiguous), row_ws: 2 B floats.  ofq_kd_loss_bwd: out = grad_loss[0] * saved. */
+int ofq_kd_loss_fwd(const float* cls_logits, const float* dist_logits, const float* teacher_logits, const int64_t* target,
+                    float* loss, float* dcls, float* ddist, float* row_ws, int64_t B, int64_t K, int64_t ld_cls, int64_t ld_dist,
+                    int64_t ld_teacher, ofq_stream_t stream);
+int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, float* out_cls, float* out_dist, int64_t n,
+                    ofq_stream_t stream);
+/*  token assembly of the (distilled) ViT (deit.py:32-44): out[b] = cat(cls, [dist,] patches[b]) + pos; patches [B][T - ntok][C]
+ *            (ntok = 2 with a distillation token, 1 with dist_token NULL), cls / dist [C], pos [T][C], out [B][T][C]; C % 4 == 0. */
+int ofq_assemble_tokens(const float* patches, const float* cls_token, const float* dist_token, const float* pos, float* out,
+                        int64_t B, int64_t T, int64_t C, ofq_stream_t stream);
 /* ---- token permutation y[b][i][:] = x[b][idx[i]][:] (x, y: [B][N][C] fp32, C % 4 == 0, x != y; idx: int32[N], a
  *  permutation of 0..N-1).  Swin's shifted-window partition and its inverse when nothing is padded
  *  (src/swin.py:103-131 pad -> roll -> view -> permute -> reshape, :160-170 the way back): ONE row gather each way; the

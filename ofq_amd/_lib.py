@@ -110,6 +110,9 @@ SIGNATURES = {
     "ofq_sum_flush": (i32, [vp]),
     "ofq_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "ofq_permute_tokens": (i32, [vp, vp, vp, i64, i64, i64, vp]),
+    "ofq_kd_loss_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "ofq_kd_loss_bwd": (i32, [vp, vp, vp, vp, vp, i64, vp]),
+    "ofq_assemble_tokens": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "ofq_split_f32_bf16x3": (i32, [vp, vp, i64, i64, vp]),
     "ofq_gemm_bf16x3x3_nt": (i32, [vp, vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, vp]),
     "ofq_input_pipeline_u8": (i32, [vp, vp, i64, i64, i64, i64, vp, vp, i32, i32, f32, f32, i32, i32, i32, i32, vp, vp, vp]),

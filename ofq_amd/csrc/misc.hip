@@ -240,6 +240,132 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t st
   return 0;
 }
 
+// ---- KD loss of the shipped recipes, forward and gradients in one pass ------------------------------------------------------------
+// KDLossSoftandHard (src/quantization/utils.py:59-77, `--kd_hard_and_soft 1`):
+//   loss = mean_b( -sum_k softmax(t_b)[k] * log_softmax(d_b)[k] ) + mean_b( -log_softmax(c_b)[y_b] )
+// with c / d the student's class / distillation logits, t the teacher's logits, y the labels.  One wave per row: three
+// (max, sum exp) pairs, the two row losses, and the gradients of the MEAN loss with respect to c and d as autograd forms them:
+//   dc[k] = (softmax(c)[k] - [k == y]) / B          dd[k] = (softmax(d)[k] * sum_j p_t[j] - p_t[k]) / B.
+// The row losses go to `rows` [2][B]; kd_loss_reduce_kernel adds them in index order (one thread: B is the batch) -- fixed order,
+// no atomics.  Replaces ~20 ATen launches per step (two log_softmax, softmax, nll, three divisions, sums, their backwards).
+__global__ __launch_bounds__(256) void kd_loss_rows_kernel(const float* __restrict__ c, const float* __restrict__ d,
+                                                           const float* __restrict__ t, const int64_t* __restrict__ y,
+                                                           float* __restrict__ dc, float* __restrict__ dd, float* __restrict__ rows,
+                                                           int B, int K, int64_t ldc, int64_t ldd, int64_t ldt) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* cr = c + (int64_t)b * ldc;
+  const float* dr = d + (int64_t)b * ldd;
+  const float* tr = t + (int64_t)b * ldt;
+  float mc = -INFINITY, md = -INFINITY, mt = -INFINITY;
+  for (int k = lane; k < K; k += 64) {
+    mc = fmaxf(mc, cr[k]);
+    md = fmaxf(md, dr[k]);
+    mt = fmaxf(mt, tr[k]);
+  }
+  mc = ofq_wave_max(mc); md = ofq_wave_max(md); mt = ofq_wave_max(mt);
+  float zc = 0.f, zd = 0.f, zt = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    zc += expf(cr[k] - mc);
+    zd += expf(dr[k] - md);
+    zt += expf(tr[k] - mt);
+  }
+  zc = ofq_wave_sum(zc); zd = ofq_wave_sum(zd); zt = ofq_wave_sum(zt);
+  const float lzc = logf(zc), lzd = logf(zd);
+  const int yb = (int)y[b];
+  float soft = 0.f, psum = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float p = expf(tr[k] - mt) / zt;
+    soft += p * ((dr[k] - md) - lzd);
+    psum += p;
+  }
+  soft = ofq_wave_sum(soft);
+  psum = ofq_wave_sum(psum);
+  const float invB = 1.f / (float)B;
+  for (int k = lane; k < K; k += 64) {
+    const float p = expf(tr[k] - mt) / zt;
+    dd[(int64_t)b * K + k] = (expf((dr[k] - md) - lzd) * psum - p) * invB;
+    dc[(int64_t)b * K + k] = (expf((cr[k] - mc) - lzc) - (k == yb ? 1.f : 0.f)) * invB;
+  }
+  if (lane == 0) {
+    rows[b] = -soft;
+    rows[B + b] = (yb >= 0 && yb < K) ? -((cr[yb] - mc) - lzc) : 0.f;
+  }
+}
+__global__ void kd_loss_reduce_kernel(const float* __restrict__ rows, float* __restrict__ loss, int B) {
+  float s = 0.f, h = 0.f;
+  for (int b = 0; b < B; ++b) {
+    s += rows[b];
+    h += rows[B + b];
+  }
+  loss[0] = s / (float)B + h / (float)B;
+}
+// g (device scalar: the gradient arriving at the loss) times the two saved gradients
+__global__ __launch_bounds__(256) void kd_loss_scale_kernel(const float* __restrict__ g, const float* __restrict__ dc,
+                                                            const float* __restrict__ dd, float* __restrict__ oc,
+                                                            float* __restrict__ od, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float gv = g[0];
+    oc[i] = dc[i] * gv;
+    od[i] = dd[i] * gv;
+  }
+}
+extern "C" int ofq_kd_loss_fwd(const float* cls_logits, const float* dist_logits, const float* teacher_logits, const int64_t* target,
+                               float* loss, float* dcls, float* ddist, float* row_ws, int64_t B, int64_t K, int64_t ld_cls,
+                               int64_t ld_dist, int64_t ld_teacher, ofq_stream_t stream) {
+  if (!cls_logits || !dist_logits || !teacher_logits || !target || !loss || !dcls || !ddist || !row_ws || B <= 0 || K <= 0 ||
+      B >= (1ll << 24) || K >= (1ll << 24))
+    return OFQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(kd_loss_rows_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, st, cls_logits, dist_logits, teacher_logits,
+                     target, dcls, ddist, row_ws, (int)B, (int)K, ld_cls, ld_dist, ld_teacher);
+  OFQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kd_loss_reduce_kernel, dim3(1), dim3(1), 0, st, row_ws, loss, (int)B);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, float* out_cls, float* out_dist,
+                               int64_t n, ofq_stream_t stream) {
+  if (!grad_loss || !dcls || !ddist || !out_cls || !out_dist || n <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(kd_loss_scale_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_loss, dcls, ddist,
+                     out_cls, out_dist, n);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- token assembly of the distilled ViT (deit.py:32-44 / deit_vision_transformer.py: cat(cls, dist, patches) + pos_embed) --------
+// out[b][t][:] = (t == 0 ? cls : t == 1 && dist ? dist : patches[b][t - ntok][:]) + pos[t][:]     one pass instead of a cat and an add;
+// the backward is a view (patches), and ONE column sum over the batch for pos_embed whose first rows are the class /
+// distillation tokens' gradients (ofq_colsum on the (B, T*C) view).
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ patches, const float* __restrict__ tok0,
+                                                              const float* __restrict__ tok1, const float* __restrict__ pos,
+                                                              float* __restrict__ out, int64_t total4, int T, int C4, int ntok) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  const int64_t bt = i / C4;
+  const int t = (int)(bt % T);
+  const int64_t b = bt / T;
+  const float4 p = reinterpret_cast<const float4*>(pos)[(int64_t)t * C4 + c4];
+  const float4 v = t < ntok ? reinterpret_cast<const float4*>(t == 0 ? tok0 : tok1)[c4]
+                            : reinterpret_cast<const float4*>(patches)[(b * (T - ntok) + (t - ntok)) * C4 + c4];
+  reinterpret_cast<float4*>(out)[i] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+}
+extern "C" int ofq_assemble_tokens(const float* patches, const float* cls_token, const float* dist_token, const float* pos, float* out,
+                                   int64_t B, int64_t T, int64_t C, ofq_stream_t stream) {
+  const int ntok = dist_token ? 2 : 1;
+  if (!patches || !cls_token || !pos || !out || B <= 0 || T <= ntok || C <= 0 || (C & 3) ||
+      ((((uintptr_t)patches | (uintptr_t)cls_token | (uintptr_t)dist_token | (uintptr_t)pos | (uintptr_t)out)) & 15))
+    return OFQ_EINVAL;
+  const int64_t total4 = B * T * (C / 4);
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, (hipStream_t)stream, patches, cls_token,
+                     dist_token, pos, out, total4, (int)T, (int)(C / 4), ntok);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // y[b][i][:] = x[b][idx[i]][:]: the token permutation of Swin's shifted-window partition / reverse (swin.py:103-131
 // pad-free case: roll + view + permute + reshape collapse into one row gather; the backward is the gather with the inverse
 // permutation).  HBM-bound, 8 B/elt; one float4 per thread, C % 4 == 0.

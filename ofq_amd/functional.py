@@ -1072,3 +1072,46 @@ def norm_quant(norm, spec, x, res=None):
         return None
     xs, xq, codes = NormQuantFn.apply(x, res, norm.weight, norm.bias, norm.eps, qz.s, spec["b4"], spec["baft"], geom)
     return (xs if res is not None else x), (xq, codes, geom)
+
+
+class KDLossFn(torch.autograd.Function):
+    """KDLossSoftandHard (src/quantization/utils.py:59-77) on (cls logits, dist logits, teacher logits, labels): value and both
+    gradients in one pass over the rows (ofq_kd_loss_fwd), the backward scales the saved gradients by the incoming one."""
+
+    @staticmethod
+    def forward(ctx, cls_out, dist_out, soft_target, hard_target):
+        loss, dcls, ddist = ops.kd_loss_fwd(cls_out, dist_out, soft_target, hard_target)
+        ctx.save_for_backward(dcls, ddist)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dcls, ddist = ctx.saved_tensors
+        oc, od = ops.kd_loss_bwd(g.contiguous(), dcls, ddist)
+        return oc, od, None, None
+
+
+def kd_loss_fusable(cls_out, dist_out, soft_target, hard_target):
+    ok = lambda t: torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1   # noqa: E731
+    return (ok(cls_out) and ok(dist_out) and ok(soft_target) and cls_out.shape == dist_out.shape == soft_target.shape
+            and torch.is_tensor(hard_target) and hard_target.is_cuda and hard_target.dtype == torch.int64 and hard_target.dim() == 1
+            and hard_target.is_contiguous() and hard_target.shape[0] == cls_out.shape[0] and not soft_target.requires_grad)
+
+
+class AssembleTokensFn(torch.autograd.Function):
+    """cat(cls_token, [dist_token,] patches) + pos_embed (deit.py:32-44) in one launch.  Backward: the patches' gradient is a
+    view, pos_embed's is ONE column sum over the batch, and its first rows are the class / distillation tokens' gradients."""
+
+    @staticmethod
+    def forward(ctx, patches, cls_token, dist_token, pos):
+        ctx.ntok = 1 if dist_token is None else 2
+        return ops.assemble_tokens(patches.contiguous(), cls_token, dist_token, pos)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, C = g.shape
+        g = g.contiguous()
+        dpos = ops.colsum(g.view(B, T * C)).view(1, T, C)
+        dcls = dpos[:, 0:1]
+        ddist = dpos[:, 1:2] if ctx.ntok == 2 else None
+        return g[:, ctx.ntok:], dcls, ddist, dpos

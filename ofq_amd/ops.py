@@ -779,6 +779,37 @@ def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False):
     return out
 
 
+def kd_loss_fwd(cls_logits, dist_logits, teacher_logits, target):
+    """(loss, dcls, ddist) of KDLossSoftandHard in two launches (ofq_kd_loss_fwd); logits [B][K] fp32 with unit inner stride."""
+    B, K = cls_logits.shape
+    dev = cls_logits.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dcls = torch.empty((B, K), dtype=torch.float32, device=dev)
+    ddist = torch.empty((B, K), dtype=torch.float32, device=dev)
+    rows = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    _chk(lib().ofq_kd_loss_fwd(cls_logits.data_ptr(), dist_logits.data_ptr(), teacher_logits.data_ptr(), target.data_ptr(),
+                               loss.data_ptr(), dcls.data_ptr(), ddist.data_ptr(), rows.data_ptr(), B, K, cls_logits.stride(0),
+                               dist_logits.stride(0), teacher_logits.stride(0), _stream()), "ofq_kd_loss_fwd")
+    return loss, dcls, ddist
+
+
+def kd_loss_bwd(g, dcls, ddist):
+    oc, od = torch.empty_like(dcls), torch.empty_like(ddist)
+    _chk(lib().ofq_kd_loss_bwd(g.data_ptr(), dcls.data_ptr(), ddist.data_ptr(), oc.data_ptr(), od.data_ptr(), dcls.numel(), _stream()),
+         "ofq_kd_loss_bwd")
+    return oc, od
+
+
+def assemble_tokens(patches, cls_token, dist_token, pos):
+    """cat(cls, [dist,] patches) + pos in one pass; patches (B, P, C), tokens (1, 1, C), pos (1, P + ntok, C)"""
+    B, P, C = patches.shape
+    T = pos.shape[1]
+    out = torch.empty((B, T, C), dtype=torch.float32, device=patches.device)
+    _chk(lib().ofq_assemble_tokens(patches.data_ptr(), cls_token.data_ptr(), _p(dist_token), pos.data_ptr(), out.data_ptr(), B, T, C,
+                                   _stream()), "ofq_assemble_tokens")
+    return out
+
+
 def colsum(x2d):
     rows, cols = x2d.shape
     out = torch.empty(cols, dtype=torch.float32, device=x2d.device)

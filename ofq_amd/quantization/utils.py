@@ -1,8 +1,14 @@
 """Distillation losses used by the shipped recipes — src/quantization/utils.py:44-77 (KLLossSoft,
-KDLossSoftandHard, `--kd_hard_and_soft 1`).  B x 1000 logits: negligible work, stock torch ops."""
+KDLossSoftandHard, `--kd_hard_and_soft 1`).  KDLossSoftandHard on device logits runs as one HIP kernel pair
+(functional.KDLossFn: value + both gradients, instead of ~20 ATen launches); everything else uses stock torch ops."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+try:                                   # the HIP path (device tensors); CPU tensors keep the stock ops below
+    from .. import functional as F_ofq
+except Exception:  # noqa: BLE001
+    F_ofq = None
 
 
 class KLLossSoft(torch.nn.modules.loss._Loss):
@@ -27,5 +33,8 @@ class KDLossSoftandHard(nn.Module):
     def forward(self, output, hard_target, soft_target):
         if isinstance(output, tuple):
             cls_output, dist_output = output[0], output[1]
+            soft = soft_target[0] if isinstance(soft_target, tuple) else soft_target
+            if F_ofq is not None and F_ofq.kd_loss_fusable(cls_output, dist_output, soft, hard_target):
+                return F_ofq.KDLossFn.apply(cls_output, dist_output, soft, hard_target)        # same value, two launches
             return self.KLSoft(dist_output, soft_target) + self.Hard(cls_output, hard_target)
         return self.KLSoft(output, soft_target) + self.Hard(output, hard_target)

@@ -1260,3 +1260,55 @@ def test_window_sized_attention_backward_kernels_vs_fp64(ops, shape):
         dk_ref = torch.einsum("bhnm,bnhj->bmhj", dS[..., :N].double(), qh).reshape(B, N, C)
         assert rel_err(dk.cpu(), dk_ref.float()) < 2e-6
 
+
+
+@pytest.mark.parametrize("BK", [(128, 1000), (7, 10), (33, 257)])
+def test_kd_loss_kernel_equals_the_torch_ops(ops, BK):
+    """ofq_kd_loss_fwd / _bwd (KDLossSoftandHard, src/quantization/utils.py:59-77; train.py:906-913) against the stock ops the
+    reference uses: loss value and both logit gradients, also under a non-unit upstream gradient."""
+    import torch.nn.functional as F
+    from ofq_amd.functional import KDLossFn, kd_loss_fusable
+    B, K = BK
+    g = torch.Generator(device="cuda").manual_seed(5)
+    c = (torch.randn(B, K, device="cuda", generator=g) * 3).requires_grad_(True)
+    d = (torch.randn(B, K, device="cuda", generator=g) * 3).requires_grad_(True)
+    t = torch.randn(B, K, device="cuda", generator=g) * 2
+    y = torch.randint(0, K, (B,), device="cuda", generator=g)
+    assert kd_loss_fusable(c, d, t, y)
+    ref = -torch.sum(F.softmax(t, dim=1) * F.log_softmax(d, dim=1), dim=1).mean() + F.cross_entropy(c, y)
+    (ref * 1.7).backward()
+    gc, gd = c.grad.clone(), d.grad.clone()
+    c.grad = d.grad = None
+    loss = KDLossFn.apply(c, d, t, y)
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel_err(c.grad.cpu(), gc.cpu()) < 2e-6 and rel_err(d.grad.cpu(), gd.cpu()) < 2e-6
+    # through the module the reference's recipes construct
+    from ofq_amd.quantization.utils import KDLossSoftandHard
+    assert abs(float(KDLossSoftandHard()((c.detach(), d.detach()), y, t)) - float(ref)) < 2e-6 * abs(float(ref))
+
+
+@pytest.mark.parametrize("dist", [True, False])
+def test_token_assembly_kernel_is_cat_plus_pos_embed(ops, dist):
+    """ofq_assemble_tokens (deit.py:32-44): values bit for bit, gradients against autograd of the cat + add."""
+    from ofq_amd.functional import AssembleTokensFn
+    B, P, C = 5, 196, 192
+    g = torch.Generator(device="cuda").manual_seed(6)
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=g).requires_grad_(True)      # noqa: E731
+    x, cls, pos = mk(B, P, C), mk(1, 1, C), mk(1, P + (2 if dist else 1), C)
+    dtk = mk(1, 1, C) if dist else None
+    parts = [cls.expand(B, -1, -1)] + ([dtk.expand(B, -1, -1)] if dist else []) + [x]
+    ref = torch.cat(parts, dim=1) + pos
+    up = torch.randn(ref.shape, device="cuda", generator=g)
+    (ref * up).sum().backward()
+    want = [t.grad.clone() for t in (x, cls, pos)] + ([dtk.grad.clone()] if dist else [])
+    for t in (x, cls, pos, dtk):
+        if t is not None:
+            t.grad = None
+    out = AssembleTokensFn.apply(x, cls, dtk, pos)
+    assert torch.equal(out, ref)
+    (out * up).sum().backward()
+    got = [t.grad for t in (x, cls, pos)] + ([dtk.grad] if dist else [])
+    assert torch.equal(got[0], want[0])
+    for a, b in zip(got[1:], want[1:]):
+        assert a.shape == b.shape and rel_err(a.cpu(), b.cpu()) < 2e-6

@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # bench.py's timer classes (first word of the ops._Timed name) -> the kernel(s) behind them
-CLASSES = [("qgemm_bf16s_nt_wide", ("qgemm_bf16s_nt_wide_kernel",)),
+CLASSES = [("qgemm_bf16s_nt_wide", ("qgemm_bf16s_nt_wide_kernel", "qgemm_bf16s_nt_wide_sk_kernel")),     # classic + streaming / two-segment
            ("qgemm_bf16s_tn_wide_group", ("qgemm_bf16s_tn_wide_group_kernel",)),
            ("qgemm_bf16s_tn_wide_stream", ("qgemm_bf16s_tn_wide_stream_kernel",)),
            ("qgemm_bf16s_tn_wide", ("qgemm_bf16s_tn_wide_kernel",)),
