@@ -336,13 +336,16 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         mode = "global"
         if self.dp is not None and self.dp.sync:
-            # with a process group alive, RCCL's watchdog thread polls the events of earlier collectives: let only this
-            # thread's calls count as capture errors -- and, when collectives are captured, let the watchdog retire the
-            # earlier ones first (it looks every 100 ms)
+            # with a process group alive, c10d's watchdog thread polls the end events of the collectives it has not retired yet
+            # (every 100 ms), and on this stack an event query from that thread while THIS thread captures ends the process
+            # ("operation not permitted on an event last recorded in a capturing stream" -- also in split mode, where no
+            # collective is captured: seen with --sync-statsq, whose extra all-reduce per warm-up step is still on the
+            # watchdog's list when the capture starts right after the synchronize above).  So: only this thread's calls count
+            # as capture errors, and the watchdog gets three of its periods to retire the finished collectives -- everything
+            # is complete on the device (synchronize), retiring is all that is left; c10d offers no handle to wait for it
             mode = "thread_local"
-            if self.mode == "full":
-                import time
-                time.sleep(0.35)
+            import time
+            time.sleep(0.35)
         if self.mode == "split":
             self.dp.pack_only = True
             try:
