@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--sync-statsq", action="store_true",
                     help="also all-reduce the StatsQ scale vectors each step and assert that it changes nothing (north_star's "
                          "'StatsQ statistics' collective: not in the reference, a no-op by construction)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="development only: the N ranks of --gpus N all use device 0 and talk over gloo (device tensors through the "
+                         "host) -- exercises the several-rank flow of this file and of the data-parallel step on a one-GPU box; the "
+                         "number it prints is N ranks time-sharing one GPU, not a scaling point")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the DataParallel wrapper (bucket hooks + RCCL all-reduce) even with one rank")
     return ap.parse_args()
@@ -181,7 +185,7 @@ def self_launch(args):
     import subprocess
     n = args.gpus
     have = torch.cuda.device_count()                 # counts devices without initialising the runtime
-    if have < n:
+    if have < n and not (args.share_gpu and have >= 1):
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
@@ -234,6 +238,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the OFQ MI355X path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -245,7 +251,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         with _c_stdout_to_stderr():
-            dist.init_process_group(backend="nccl", device_id=dev)
+            if args.share_gpu:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev)
             dist.barrier()                                  # creates the communicator (and prints RCCL's banner) now
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -412,7 +421,9 @@ def main():
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
                           "launch": ("eager (one ctypes launch per kernel)" if not use_graph else "hipGraph replay" if graph_mode == "full"
                                      else "hipGraph replay of the compute, bucket all-reduces eager between two graphs"),
-                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
+                          "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if not args.share_gpu else 0,
+                          **({"share_gpu": "%d ranks time-share ONE GPU over gloo (development run, not a scaling point)" % world}
+                             if args.share_gpu else {})},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)

@@ -650,3 +650,97 @@ def test_bench_line_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
+
+
+def _two_rank_worker(rank, world, port, errq):
+    """One of two processes that SHARE the box's one GPU and talk over gloo (which moves device tensors through the host):
+    the closest thing to a several-rank run a one-GPU box allows -- every rank-coordination path of the data-parallel step
+    executes with a real peer (constructor broadcast, bucket all-reduces with world 2, the arrival-order rebuild, the latch
+    agreement, captured compute with eager collectives)."""
+    import traceback
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from ofq_amd import engine, parallel
+        from ofq_amd.quantization.utils import KDLossSoftandHard
+        base = _tiny(seed=rank)                              # different initial weights on every rank: rank 0's must win
+        batches = [_batch(seed=20 + 2 * i + rank) for i in range(2)]      # rank-specific data
+        engine.setup_alpha(base, batches[0][0])              # rank-specific LSQ steps, created lazily: rank 0's must win too
+        loss_fn = KDLossSoftandHard()
+
+        # (1) one synchronised step: the gradients are the mean over the ranks of the LOCAL gradients
+        m_loc = copy.deepcopy(base).train()
+        dp0 = parallel.DataParallel(copy.deepcopy(base).train(), bucket_mb=1.0)
+        m_loc.load_state_dict(dp0.module.state_dict())       # rank 0's parameters, as the wrapper broadcast them
+        out, _ = m_loc(batches[0][0])
+        loss_fn(out, batches[0][1], batches[0][2]).backward()
+        opt0 = engine.make_optimizer(dp0.module, lr=0.0, weight_decay=0.0)
+        engine.train_step(dp0.module, opt0, *batches[0], loss_fn, dp=dp0)
+        for (n, p), q in zip(m_loc.named_parameters(), dp0.module.parameters()):
+            if p.grad is None:
+                continue
+            mean = p.grad.detach().clone()
+            dist.all_reduce(mean)
+            mean /= world
+            assert rel_err(q.grad.cpu(), mean.cpu()) < 2e-6, (n, rel_err(q.grad.cpu(), mean.cpu()))
+        dp0.release()
+
+        # (2) five steps: eager DataParallel against captured compute + eager collectives, and rank against rank
+        res = {}
+        for mode in ("eager", "split"):
+            model = copy.deepcopy(base).train()
+            dp = parallel.DataParallel(model, bucket_mb=1.0)
+            opt = engine.make_optimizer(model, lr=_lr_at(0), weight_decay=0.05)
+            gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, warmup=2, mode="split") if mode == "split" else None
+            losses = []
+            for i in range(5):
+                for g in opt.param_groups:
+                    g["lr"] = _lr_at(i)
+                b = batches[i % 2]
+                loss = gs(*b) if gs is not None else engine.train_step(model, opt, *b, loss_fn, dp=dp)
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            if gs is not None:
+                assert gs.mode == "split" and gs.graph_b is not None and gs.captures == 1
+            res[mode] = (losses, [p.detach().clone() for p in model.parameters()])
+            flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+            lo, hi = flat.clone(), flat.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), "replicas diverged in mode " + mode
+            dp.release()
+        assert res["eager"][0] == res["split"][0], res
+        for a, b_ in zip(res["eager"][1], res["split"][1]):
+            assert torch.equal(a, b_)
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:  # noqa: BLE001
+        errq.put("rank %d:\n%s" % (rank, traceback.format_exc()))
+        raise
+
+
+def test_two_ranks_on_one_gpu_over_gloo_run_the_data_parallel_step():
+    """train.py:474, :727, :927-933 with world_size 2 for real: two processes share the GPU and exchange device tensors through
+    gloo.  Gradients = mean of the ranks' local gradients; five steps of the eager DataParallel step and of the split-graph
+    step (the several-rank default) give the same losses and parameters bit for bit, and the replicas stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    errq = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, errq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    msgs = []
+    while not errq.empty():
+        msgs.append(errq.get())
+    assert not msgs, "\n".join(msgs)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
