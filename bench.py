@@ -343,6 +343,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if ops.nt_sk_error(dev):
+        raise SystemExit("bench.py: a stream-K hand-off of the dX GEMM timed out (cut tile stored without a partial): results invalid")
     if dp is not None and dp.sync_statsq:
         dp.check_statsq_pending()                     # --sync-statsq: the asserted no-op (outside the timed region: a host sync)
     loss_value = float(loss.detach())                 # (the static loss tensor of the graph: read before any further step)

@@ -461,11 +461,14 @@ def _sk_workspace(device):
 
 
 def nt_sk_error(device):
-    """The stream-K kernels' error word (a bounded spin ran out): 0 = never.  Host sync; tests and debugging only."""
-    buf = _sk_ws.get((device.index, _stream()))
-    if buf is None:
-        return 0
-    return int(buf[:32768].view(torch.int32)[4096].item())
+    """The stream-K kernels' error word (a bounded spin ran out: the owner of a cut tile gave up waiting for a partial and
+    stored a wrong tile), over every workspace of the device: 0 = never.  A host sync: called outside timed regions
+    (bench.py after the timed loop, train.py at its log points, the tests)."""
+    err = 0
+    for (idx, _st), buf in _sk_ws.items():
+        if idx == device.index:
+            err |= int(buf[:32768].view(torch.int32)[4096].item())
+    return err
 
 
 def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):

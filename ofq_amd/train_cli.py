@@ -194,7 +194,7 @@ def log(rank, msg):
 
 
 def main_worker(local_rank, args, cga, spawned):
-    from . import engine, parallel
+    from . import engine, ops, parallel
     from .deit import create_model
     from .quantization.utils import KDLossSoftandHard, KLLossSoft
     check_supported(args)
@@ -311,6 +311,8 @@ def main_worker(local_rank, args, cga, spawned):
                 torch.cuda.synchronize()                                                    # train.py:944
                 if dp is not None and dp.sync_statsq:
                     dp.check_statsq_pending()     # --sync-statsq: raises when the replicas' StatsQ scales have drifted apart
+                if ops.nt_sk_error(x.device):
+                    raise RuntimeError("ofq_amd: a stream-K hand-off of the dX GEMM timed out; the gradients of this run are invalid")
                 bt = time.time() - end
                 lv = loss.detach().clone()
                 if world > 1:
