@@ -3736,7 +3736,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
     adv_a();
   };
 
-#ifdef NTSK_CLOCK_PROBE      // tools/nt_sk_sweep.py: shader clock the chip holds while G workgroups run this kernel
+#if defined(NTSK_CLOCK_PROBE) || defined(NTSK_PHASE_PROBE)      // tools/nt_sk_sweep.py: shader clock the chip holds while G workgroups run this kernel
   const unsigned long long pc0 = __builtin_readcyclecounter(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
@@ -3767,6 +3767,12 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
 
     int l31e = l31, lhe = lh, tide = tid;
     asm volatile("" : "+v"(l31e), "+v"(lhe), "+v"(tide));      // keep the epilogue's lane offsets out of the k-loop's registers
+#ifdef NTSK_PHASE_PROBE      // tools/nt_sk_phases.py: where the hand-off of a cut tile spends its time (10 ns ticks since kernel start)
+#define NTSK_STAMP(slot) do { if (tid == 0) p.flags[4200 + w * 8 + (slot)] = (int)(__builtin_amdgcn_s_memrealtime() - pr0); } while (0)
+    NTSK_STAMP(kb != 0 ? 0 : 2);
+#else
+#define NTSK_STAMP(slot) do {} while (0)
+#endif
     if (kb != 0) {
       // ---- not the owner: publish the partial tile (register order, one float4 per lane and store: coalesced) ----
       // (the address is a VGPR pair: a scalar base would be restored from spill lanes by v_readlane right in front of the
@@ -3785,6 +3791,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(p.flags + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      NTSK_STAMP(1);
     } else {
       if (ke != nkt) {
         // ---- owner of a cut tile: add the partials of the following workgroups, in order ----
@@ -3802,6 +3809,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
               __builtin_amdgcn_s_sleep(8);
             }
             __hip_atomic_store(p.flags + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x == w + 1) NTSK_STAMP(3);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           }
           __syncthreads();
@@ -3820,6 +3828,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
             }
         }
       }
+      if (ke != nkt) NTSK_STAMP(4);
       // ---- store the finished tile ----
       const float alpha = NSEG > 1 ? 1.f : p.seg[0].alpha;
       const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
@@ -3885,6 +3894,10 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     u += (unsigned)(ke - kb);
   }
+#ifdef NTSK_PHASE_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NTSK_STAMP(5);
+#endif
 #ifdef NTSK_CLOCK_PROBE
   if (w == G / 2 && tid == 0) {
     p.flags[4098] = (int)(__builtin_readcyclecounter() - pc0);
