@@ -9,7 +9,11 @@
  * Conventions
  *  - all pointers are DEVICE pointers to contiguous fp32 unless stated; sizes are element counts
  *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
- *  - no allocation, no host synchronisation, no global state  => hipGraph-capturable
+ *  - no allocation and no host synchronisation  => hipGraph-capturable.  Host state, all of it: (1) the queue of deferred
+ *    second-stage reductions between ofq_sum_defer(1) and ofq_sum_flush() (a capture records the queue at its flush); (2) the
+ *    OFQ_* environment switches that some launchers read ONCE at their first call -- A/B and test hooks that choose between
+ *    kernels giving the same results (tools/README.md), never needed in production; (3) nothing else: no caches, no streams,
+ *    no device memory owned by the library (workspaces, flags and tables are the caller's)
  *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative OFQ_E* code
  *  - workspaces are caller-provided; the *_ws_bytes() functions are pure host arithmetic
  */

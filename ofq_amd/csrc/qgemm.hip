@@ -3470,12 +3470,14 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   return 0;
 }
 
-// ---- stream-K form of the wide input-gradient kernel ------------------------------------------------------------------
-// The one-tile-per-workgroup launch above leaves the chip badly filled on the linear layers of a ViT: M = 25 344 token rows
-// are 198 row tiles for 256 CUs (77 %), N = 1536 makes 792 tiles = 3.09 per CU, and every workgroup pays its own first
-// memory round trip and its 196 KB store burst at the same moment as all the others (measured: ~19 us of a 37 us launch at
-// K = 384 are launch edges).  Here `gridDim.x` workgroups (one per CU) share the launch's tiles x k-steps UNITS evenly: workgroup
-// w walks the units [U w / G, U (w+1) / G) in order, i.e. a run of consecutive (tile, k-range) pieces.  A tile that lies
+// ---- streaming / stream-K form of the wide input-gradient kernel -------------------------------------------------------
+// The one-tile-per-workgroup launch above pays, per tile, a first memory round trip and a 196 KB store burst at the same moment
+// as every other workgroup (measured: ~19 us of a 37 us launch at K = 384 are launch edges), and N = 1536 makes 792 tiles =
+// 3.09 per CU.  Here `gridDim.x` persistent workgroups (one per CU) share the launch's tiles x k-step PAIRS evenly: workgroup
+// w walks the units [U w / G, U (w+1) / G) in order as ONE continuous k-step stream -- the load cursors run three / two steps
+// ahead of the MFMAs straight through tile boundaries, a boundary costs its epilogue only.  The launcher (nt_sk_grid) picks G
+// so that no tile is cut whenever a divisor of the tile count fills three quarters of the chip (198 for the DeiT-S shapes:
+// every bit equals the one-tile-per-workgroup kernel's); otherwise G = the CU count and tiles are CUT.  A tile that lies
 // inside one run is stored directly.  A tile cut by a run boundary is finished by its OWNER, the workgroup that holds its
 // k = 0 piece (the tail of that workgroup's run): the other holders (the heads of the following workgroups' runs -- done
 // early) publish their fp32 partial tile to their slot of the workspace (write-through stores, drained, then a flag), the
