@@ -64,8 +64,11 @@ def parse():
                     help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--graph", action="store_true",
                     help="with several ranks: capture the RCCL collectives inside the step's graph as well (default there: "
-                         "captured compute with the bucket all-reduces issued eagerly between two graphs; the capture of "
-                         "collectives is validated with one rank only, tests/test_graph_gpu.py)")
+                         "captured compute in sub-graphs cut at the gradient buckets, each bucket's all-reduce issued eagerly "
+                         "behind its sub-graph; the capture of collectives is validated with one rank only, tests/test_graph_gpu.py)")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="with several ranks: round 4's form -- one graph for the whole backward, then every bucket all-reduce "
+                         "(exposed), then the optimiser graph -- instead of the sub-graphs cut at the bucket boundaries")
     ap.add_argument("--teacher-gemm", default="bf16x9", choices=["f32", "bf16x9", "bf16x6"],
                     help="with --with-teacher: fp32-MFMA GEMMs, or the weights pre-split into bf16 planes (9 / 6 plane products)")
     ap.add_argument("--stock-teacher", action="store_true",
@@ -314,7 +317,9 @@ def main():
     use_graph = not args.no_graph
     # with the data-parallel wrapper (several ranks, or --force-dp): "split" = captured compute + eager collectives
     # (engine.GraphedTrainStep) unless --graph asks for the collectives inside the graph
-    graph_mode = "full" if (dp is None or args.graph) else "split"
+    # ("segmented": graph A cut at the bucket boundaries, each bucket's all-reduce issued behind its sub-graph and overlapped
+    # with the next one; --split-graph keeps round 4's form: all collectives after the whole backward graph)
+    graph_mode = "full" if (dp is None or args.graph) else ("split" if args.split_graph else "segmented")
     n_warm = args.warmup
     if use_graph:
         # same step, device side replayed from a hipGraph: the first two calls run eagerly, the third captures
@@ -422,7 +427,9 @@ def main():
                                          if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
                           "launch": ("eager (one ctypes launch per kernel)" if not use_graph else "hipGraph replay" if graph_mode == "full"
-                                     else "hipGraph replay of the compute, bucket all-reduces eager between two graphs"),
+                                     else "hipGraph replay of the compute, bucket all-reduces eager between two graphs" if graph_mode == "split"
+                                     else "hipGraph replay in %d sub-graphs cut at the gradient buckets, each bucket's all-reduce issued "
+                                          "behind its sub-graph (overlapped with the next)" % len(gstep.segments)),
                           "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if not args.share_gpu else 0,
                           **({"share_gpu": "%d ranks time-share ONE GPU over gloo (development run, not a scaling point)" % world}
                              if args.share_gpu else {})},

@@ -177,13 +177,20 @@ int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float
  *              C[m,n] (+)= sum_seg alpha_seg * sum_k (A_seg[m,k] * k_scale_seg[k]) * B_seg[n,k]
  *            -- the input gradients that two layers send to one tensor (attention.py:180 and :200: v and W_qk both read
  *            x_hat) as ONE GEMM over the concatenated contraction; with two segments alpha is applied to the k-scale
- *            (callers pass powers of two: same bits as applying it last).  Every K % 32 == 0, N > 128, M * lda * 4 < 2^32.
+ *            (callers pass powers of two: same bits as applying it last).  Every K % 32 == 0 AND the sum of K over the segments % 64 == 0
+ *            (the workgroups share PAIRS of k-steps; EINVAL otherwise), lda >= K, ldb >= K, ldc >= N, N > 128, M * lda * 4 < 2^32.
  *            The launch uses the largest divisor of the tile count between 3/4 num_wgs and num_wgs as its workgroup count
  *            when there is one (whole tiles only: then every bit equals ofq_qgemm_bf16s_nt's), num_wgs workgroups with cut
  *            tiles otherwise; num_wgs < 0 forces exactly -num_wgs workgroups.
  *            `ws`: ofq_qgemm_bf16s_nt_sk_ws_bytes(|num_wgs|) bytes, ZEROED once by the caller before its first use and then
  *            owned by this entry point (calls sharing it must be ordered on one stream).  ofq_qgemm_bf16s_nt_sk_pays: 1 when
- *            the stream-K launch is expected to beat the one-tile-per-workgroup launch for the shape. */
+ *            the stream-K launch is expected to beat the one-tile-per-workgroup launch for the shape.
+ *            Hand-off errors: every wait of an owner for a partial is bounded (~0.6 s); when one runs out the owner raises the
+ *            STICKY error word of the workspace (int 4096 of `ws`), leaves the late publisher's flag alone and stores a wrong
+ *            tile -- this and every later launch on the workspace are suspect until ofq_qgemm_bf16s_nt_sk_reset has re-zeroed the
+ *            flag area.  ofq_qgemm_bf16s_nt_sk_check makes the word visible INSIDE a step without a host sync: loss[0] = NaN
+ *            when it is set (one thread; capturable).  (int 4097 of `ws`: fault injection for tests -- the workgroup with that
+ *            index + 1 never publishes; zero in real runs.) */
 typedef struct ofq_nt_seg {
   const float* A; const void* B_bf16; const float* k_scale;
   int64_t K, lda, ldb;
@@ -193,6 +200,8 @@ size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs);
 int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs);
 int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumulate, int64_t M, int64_t N, int64_t ldc,
                           int num_wgs, void* ws, size_t ws_bytes, ofq_stream_t stream);
+int ofq_qgemm_bf16s_nt_sk_check(const void* ws, float* loss, ofq_stream_t stream);
+int ofq_qgemm_bf16s_nt_sk_reset(void* ws, ofq_stream_t stream);
 /*  dX GEMM fused with the backward of the layer's own input quantiser (qlinear.py:66-69: x -> move_b4 -> LSQ -> move_aft
  *  -> F.linear): dX_hat = alpha * (dY * k_scale) @ B never leaves the kernel; its epilogue applies ofq_lsq_bwd's
  *  arithmetic (per-token step lsq_s[m % S], offset b4[n], optional GELU prologue) and writes dx[M][N] (ld ldx), and
@@ -388,12 +397,16 @@ int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
 
 /*  KD loss of the shipped recipes (KDLossSoftandHard, src/quantization/utils.py:59-77, train.py:906-913), value and gradients:
  *            loss = mean_b(-sum_k softmax(teacher_b)[k] log_softmax(dist_b)[k]) + mean_b(-log_softmax(cls_b)[target_b]);
- *            dcls / ddist [B][K] = d loss / d logits (contiguous), row_ws: 2 B floats.  ofq_kd_loss_bwd: out = grad_loss[0] * saved. */
+ *            dcls / ddist [B][K] = d loss / d logits (contiguous), row_ws: 2 B + 1 floats.  Labels as nn.CrossEntropyLoss takes them
+ *            (utils.py:70): target == -100 (ignore_index) rows contribute nothing and the hard term is the mean over the other rows
+ *            (row_ws[2 B] = B / their count, to be passed as cls_scale below; no such row: exactly 1); any other label outside
+ *            [0, K), where the stock op traps, makes the loss NaN.  ofq_kd_loss_bwd: out_dist = grad_loss[0] * ddist,
+ *            out_cls = grad_loss[0] * dcls * cls_scale[0] (cls_scale NULL: 1). */
 int ofq_kd_loss_fwd(const float* cls_logits, const float* dist_logits, const float* teacher_logits, const int64_t* target,
                     float* loss, float* dcls, float* ddist, float* row_ws, int64_t B, int64_t K, int64_t ld_cls, int64_t ld_dist,
                     int64_t ld_teacher, ofq_stream_t stream);
-int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, float* out_cls, float* out_dist, int64_t n,
-                    ofq_stream_t stream);
+int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, const float* cls_scale, float* out_cls,
+                    float* out_dist, int64_t n, ofq_stream_t stream);
 /*  token assembly of the (distilled) ViT (deit.py:32-44): out[b] = cat(cls, [dist,] patches[b]) + pos; patches [B][T - ntok][C]
  *            (ntok = 2 with a distillation token, 1 with dist_token NULL), cls / dist [C], pos [T][C], out [B][T][C]; C % 4 == 0. */
 int ofq_assemble_tokens(const float* patches, const float* cls_token, const float* dist_token, const float* pos, float* out,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ofq_qgemm_bf16s_nt_sk_ws_bytes": (sz, [i32]),
     "ofq_qgemm_bf16s_nt_sk_pays": (i32, [i64, i64, i64, i32]),
     "ofq_qgemm_bf16s_nt_sk": (i32, [C.POINTER(NtSeg), i32, vp, i32, i64, i64, i64, i32, vp, sz, vp]),
+    "ofq_qgemm_bf16s_nt_sk_check": (i32, [vp, vp, vp]),
+    "ofq_qgemm_bf16s_nt_sk_reset": (i32, [vp, vp]),
     "ofq_qgemm_bf16s_nt_lsq_ws_bytes": (sz, [i64, i64]),
     "ofq_qgemm_bf16s_nt_lsq": (i32, [vp, vp, vp, f32, vp, vp, i64, f32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i64, i64, i64,
                                      i64, i64, vp, sz, vp]),
@@ -111,7 +113,7 @@ SIGNATURES = {
     "ofq_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "ofq_permute_tokens": (i32, [vp, vp, vp, i64, i64, i64, vp]),
     "ofq_kd_loss_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
-    "ofq_kd_loss_bwd": (i32, [vp, vp, vp, vp, vp, i64, vp]),
+    "ofq_kd_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),
     "ofq_assemble_tokens": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "ofq_split_f32_bf16x3": (i32, [vp, vp, i64, i64, vp]),
     "ofq_gemm_bf16x3x3_nt": (i32, [vp, vp, vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, vp]),

@@ -248,6 +248,10 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t st
 //   dc[k] = (softmax(c)[k] - [k == y]) / B          dd[k] = (softmax(d)[k] * sum_j p_t[j] - p_t[k]) / B.
 // The row losses go to `rows` [2][B]; kd_loss_reduce_kernel adds them in index order (one thread: B is the batch) -- fixed order,
 // no atomics.  Replaces ~20 ATen launches per step (two log_softmax, softmax, nll, three divisions, sums, their backwards).
+// Labels follow nn.CrossEntropyLoss (the reference's hard-label term, utils.py:70): a row with target == -100 (ignore_index)
+// contributes neither loss nor gradient and the hard term is the mean over the OTHER rows (rows[2B] = B / count rescales dc
+// in the backward; count == 0 gives NaN, as the stock op does); any other label outside [0, K) -- where the stock op traps
+// with a device assert -- makes the loss NaN.
 __global__ __launch_bounds__(256) void kd_loss_rows_kernel(const float* __restrict__ c, const float* __restrict__ d,
                                                            const float* __restrict__ t, const int64_t* __restrict__ y,
                                                            float* __restrict__ dc, float* __restrict__ dd, float* __restrict__ rows,
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) void kd_loss_rows_kernel(const float* __restri
   zc = ofq_wave_sum(zc); zd = ofq_wave_sum(zd); zt = ofq_wave_sum(zt);
   const float lzc = logf(zc), lzd = logf(zd);
   const int yb = (int)y[b];
+  const bool ignored = y[b] == -100;              // nn.CrossEntropyLoss's ignore_index
   float soft = 0.f, psum = 0.f;
   for (int k = lane; k < K; k += 64) {
     const float p = expf(tr[k] - mt) / zt;
@@ -286,29 +291,33 @@ __global__ __launch_bounds__(256) void kd_loss_rows_kernel(const float* __restri
   for (int k = lane; k < K; k += 64) {
     const float p = expf(tr[k] - mt) / zt;
     dd[(int64_t)b * K + k] = (expf((dr[k] - md) - lzd) * psum - p) * invB;
-    dc[(int64_t)b * K + k] = (expf((cr[k] - mc) - lzc) - (k == yb ? 1.f : 0.f)) * invB;
+    dc[(int64_t)b * K + k] = ignored ? 0.f : (expf((cr[k] - mc) - lzc) - (k == yb ? 1.f : 0.f)) * invB;
   }
   if (lane == 0) {
     rows[b] = -soft;
-    rows[B + b] = (yb >= 0 && yb < K) ? -((cr[yb] - mc) - lzc) : 0.f;
+    rows[B + b] = ignored ? 0.f : ((yb >= 0 && yb < K) ? -((cr[yb] - mc) - lzc) : NAN);
   }
 }
-__global__ void kd_loss_reduce_kernel(const float* __restrict__ rows, float* __restrict__ loss, int B) {
+__global__ void kd_loss_reduce_kernel(float* __restrict__ rows, const int64_t* __restrict__ y, float* __restrict__ loss, int B) {
   float s = 0.f, h = 0.f;
+  int count = 0;
   for (int b = 0; b < B; ++b) {
     s += rows[b];
     h += rows[B + b];
+    count += y[b] != -100 ? 1 : 0;
   }
-  loss[0] = s / (float)B + h / (float)B;
+  loss[0] = s / (float)B + h / (float)count;
+  rows[2 * B] = (float)B / (float)count;          // 1.0 exactly when no row is ignored
 }
-// g (device scalar: the gradient arriving at the loss) times the two saved gradients
+// g (device scalar: the gradient arriving at the loss) times the two saved gradients; cls_scale[0] = B / (rows not ignored)
 __global__ __launch_bounds__(256) void kd_loss_scale_kernel(const float* __restrict__ g, const float* __restrict__ dc,
-                                                            const float* __restrict__ dd, float* __restrict__ oc,
-                                                            float* __restrict__ od, int64_t n) {
+                                                            const float* __restrict__ dd, const float* __restrict__ cls_scale,
+                                                            float* __restrict__ oc, float* __restrict__ od, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     const float gv = g[0];
-    oc[i] = dc[i] * gv;
+    const float v = dc[i] * gv;
+    oc[i] = cls_scale ? v * cls_scale[0] : v;
     od[i] = dd[i] * gv;
   }
 }
@@ -322,15 +331,15 @@ extern "C" int ofq_kd_loss_fwd(const float* cls_logits, const float* dist_logits
   hipLaunchKernelGGL(kd_loss_rows_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, st, cls_logits, dist_logits, teacher_logits,
                      target, dcls, ddist, row_ws, (int)B, (int)K, ld_cls, ld_dist, ld_teacher);
   OFQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kd_loss_reduce_kernel, dim3(1), dim3(1), 0, st, row_ws, loss, (int)B);
+  hipLaunchKernelGGL(kd_loss_reduce_kernel, dim3(1), dim3(1), 0, st, row_ws, target, loss, (int)B);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, float* out_cls, float* out_dist,
-                               int64_t n, ofq_stream_t stream) {
+extern "C" int ofq_kd_loss_bwd(const float* grad_loss, const float* dcls, const float* ddist, const float* cls_scale, float* out_cls,
+                               float* out_dist, int64_t n, ofq_stream_t stream) {
   if (!grad_loss || !dcls || !ddist || !out_cls || !out_dist || n <= 0) return OFQ_EINVAL;
   hipLaunchKernelGGL(kd_loss_scale_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_loss, dcls, ddist,
-                     out_cls, out_dist, n);
+                     cls_scale, out_cls, out_dist, n);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -700,6 +700,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------ bf16-split backward
+#ifdef OFQ_2PLANE_ABLATE              // timing experiment only (wrong numbers): the third bf16 plane is skipped in the wide k-steps
+#define NSM_ 2
+#else
+#define NSM_ 3
+#endif
 #define QBS_BK 32                      // k per stage
 #define QBS_LD (QBS_BK * 2 + 16)       // padded LDS row in bytes (bf16)
 
@@ -1767,7 +1772,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
               cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
             }
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -1807,10 +1812,10 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
       constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
       if constexpr (ks == 0) {                        // second-step fragments into the registers that have just been used up
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -2111,7 +2116,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
               cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
             }
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -2148,10 +2153,10 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
 #ifdef TNS_SKIP_PAD_BLOCKS
       if (i == 0 || !skip_i1)
 #endif
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+        if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -3219,7 +3224,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -3253,10 +3258,10 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
       constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = *reinterpret_cast<const bf16x8*>(b + G * 32 * QBS_LD + 32);
-        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
 #ifndef NTW_X_NO_STAGING
@@ -3689,7 +3694,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -3724,10 +3729,10 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
     static_for<NM>([&](auto G_) {
       constexpr int Gi = decltype(G_)::value;
       constexpr int ks = Gi / (6 * NJ), q = (Gi / (2 * NJ)) % NS, i = (Gi / NJ) % 2, j = Gi % NJ;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
       if constexpr (ks == 0) {
         if constexpr (Gi < NJ) bv[1][Gi] = *reinterpret_cast<const bf16x8*>(b + Gi * 32 * QBS_LD + 32);
-        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = Gi * NP / NM, P1 = (Gi + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -3792,7 +3797,8 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.flags + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (flags[4097]: fault injection for the tests -- the workgroup named there, +1, never publishes; zero in every real run)
+      if (tid == 0 && p.flags[4097] != w + 1) __hip_atomic_store(p.flags + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       NTSK_STAMP(1);
     } else {
       if (ke != nkt) {
@@ -3801,20 +3807,27 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
         for (int x = w + 1; x < G; ++x) {
           const unsigned ux = 2u * (unsigned)((p.units * (unsigned long long)x) / (unsigned long long)G);
           if (ux >= tile_end) break;
+          bool tmo = false;
           if (tid == 0) {
             int it = 0;
+            bool got = true;
             while (__hip_atomic_load(p.flags + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
               if (++it > QNT_SK_SPIN_LIMIT) {
+                // STICKY error word: this launch and every later one on this workspace is suspect until the caller has re-zeroed
+                // the flag area (ofq_qgemm_bf16s_nt_sk_reset).  The publisher's flag is NOT reset here: it may still arrive,
+                // and a flag cleared now and set later would be taken for the NEXT launch's partial.
                 __hip_atomic_store(p.flags + 4096, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = false;
                 break;
               }
               __builtin_amdgcn_s_sleep(8);
             }
-            __hip_atomic_store(p.flags + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got) __hip_atomic_store(p.flags + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (x == w + 1) NTSK_STAMP(3);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            tmo = !got;
           }
-          __syncthreads();
+          if (__syncthreads_or(tmo ? 1 : 0)) continue;      // timed out: the tile goes without this partial (error word raised)
           const f32x4v* src = reinterpret_cast<const f32x4v*>(p.ws) + (size_t)x * SLOT_F4 + tide;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -3948,12 +3961,13 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
   if (forced) num_wgs = -num_wgs;
   if (!segs || (nseg != 1 && nseg != 2) || !C || !ws || M <= 0 || N <= 128 || num_wgs <= 0 || num_wgs > 4096) return OFQ_EINVAL;
   if (ws_bytes < ofq_qgemm_bf16s_nt_sk_ws_bytes(num_wgs)) return OFQ_ENOWS;
-  if (M >= (1ll << 30) || N >= (1ll << 30) || !al16(ws)) return OFQ_EINVAL;
+  if (M >= (1ll << 30) || N >= (1ll << 30) || !al16(ws) || ldc < N) return OFQ_EINVAL;
   QNtSkArgs a = {};
   int nkt = 0;
   for (int i = 0; i < nseg; ++i) {
     const ofq_nt_seg& sg = segs[i];
-    if (!sg.A || !sg.B_bf16 || sg.K <= 0 || (sg.K % QBS_BK) || (sg.lda & 3) || (sg.ldb & 7) || !al16(sg.A) || !al16(sg.B_bf16) ||
+    if (!sg.A || !sg.B_bf16 || sg.K <= 0 || (sg.K % QBS_BK) || (sg.lda & 3) || (sg.ldb & 7) || sg.lda < sg.K || sg.ldb < sg.K ||
+        !al16(sg.A) || !al16(sg.B_bf16) ||
         (sg.k_scale && !al16(sg.k_scale)) || M * sg.lda * 4 >= (1ll << 32) || N * sg.ldb * 2 >= (1ll << 32))
       return OFQ_EINVAL;
     a.seg[i].A = sg.A; a.seg[i].B = (const unsigned short*)sg.B_bf16; a.seg[i].s = sg.k_scale;
@@ -3981,6 +3995,23 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
   }
   OFQ_LAUNCH_CHECK();
   return 0;
+}
+
+// The error word of a stream-K workspace, surfaced inside the step: loss[0] becomes NaN when a hand-off of an earlier launch on
+// this workspace timed out (one thread; captured with the step, so a replayed step poisons its loss as well).
+__global__ void nt_sk_check_kernel(const int* __restrict__ flags, float* __restrict__ loss) {
+  if (__hip_atomic_load(flags + 4096, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) loss[0] = __builtin_nanf("");
+}
+extern "C" int ofq_qgemm_bf16s_nt_sk_check(const void* ws, float* loss, ofq_stream_t stream) {
+  if (!ws || !loss) return OFQ_EINVAL;
+  hipLaunchKernelGGL(nt_sk_check_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const int*)ws, loss);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// Back to the state of a fresh workspace: every flag, the error word and the test words zero (asynchronous, on `stream`).
+extern "C" int ofq_qgemm_bf16s_nt_sk_reset(void* ws, ofq_stream_t stream) {
+  if (!ws) return OFQ_EINVAL;
+  return hipMemsetAsync(ws, 0, QNT_SK_FLAG_BYTES, (hipStream_t)stream) == hipSuccess ? 0 : OFQ_EINVAL;
 }
 
 // Wide form of the plane-product GEMM (the fp32 KD teacher's linear layers, ofq_gemm_bf16x3x3_nt): 128 x 384 tile, eight
@@ -4142,7 +4173,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3x3_wide_kernel(QGemmArgs p) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][e], z_, x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -5065,10 +5096,10 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
       constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) {

@@ -246,6 +246,8 @@ def _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp):
         F_ofq.DW_DEFER = False
     F_ofq.flush_dw()
     F_ofq.assert_step_queues_empty()            # nothing parked, queued or deferred may outlive the backward pass
+    if loss.is_cuda:
+        ops.nt_sk_poison(loss.detach())         # a timed-out stream-K hand-off (corrupt dX) turns this step's loss into NaN
     return loss
 
 
@@ -263,6 +265,8 @@ def _step_update(optimizer, dp, cga):
 def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=None, cga=None):
     """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
     loss_fn = loss_fn or KDLossSoftandHard()
+    if images.is_cuda:
+        ops.nt_sk_poll(images.device)           # raises when an earlier step's stream-K hand-off timed out (no host sync)
     if dp is not None:
         dp.sync_buffers()                       # DDP's per-forward buffer broadcast (train.py:727, broadcast_buffers=True)
     return _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga)
@@ -290,11 +294,16 @@ class GraphedTrainStep:
     The first `warmup` calls run eagerly (real training steps: lazily created state -- optimizer moments, workspaces,
     CGA masks -- must exist before the capture); the next call captures and replays."""
 
+    # what a capture next to a live process group does (see _capture); tools/capture_stress.py flips these to reproduce the
+    # watchdog crash of round 4
+    capture_error_mode_dp = "thread_local"
+    drain_before_capture = True
+
     def __init__(self, model, optimizer, loss_fn=None, dp=None, cga=None, warmup=2, alias_inputs=False, mode="full"):
         if not hasattr(optimizer, "advance_for_replay"):
             raise RuntimeError("GraphedTrainStep needs ofq_amd.optim.FusedAdamW (per-step scalars in device memory)")
-        if mode not in ("full", "split"):
-            raise ValueError("mode must be 'full' or 'split'")
+        if mode not in ("full", "split", "segmented"):
+            raise ValueError("mode must be 'full', 'split' or 'segmented'")
         self.model, self.optimizer, self.dp, self.cga = model, optimizer, dp, cga
         # mode "split" (the default of bench.py / train.py with several ranks): captured compute, eager collectives --
         #   graph A = zero_grad + StatsQ refresh + forward + loss + backward + the packing of the gradient buckets,
@@ -303,7 +312,15 @@ class GraphedTrainStep:
         # No collective is ever captured (RCCL inside a hipGraph has only been exercised with one rank here), the host issues
         # two graph launches and one collective per bucket per step instead of ~850 kernel launches, and the all-reduce is
         # exposed (90.8 MB of gradients over xGMI: well under a millisecond of a 22 ms step) instead of overlapped.
+        # mode "segmented" (the default of bench.py / train.py with several ranks since round 5): graph A is cut at the bucket
+        # boundaries -- the capture is ended and a new one begun inside the gradient hook that packs a bucket -- and bucket i's
+        # all-reduce is issued eagerly right after sub-graph i has been launched: RCCL's stream waits for exactly that
+        # sub-graph and reduces next to sub-graph i+1 (train.py:727's "all-reduce overlapped with backward" at ~2 host calls
+        # per bucket); only the last bucket's collective is exposed.  The backward pass of the capture runs on the calling
+        # thread (torch.autograd.set_multithreading_enabled(False)): a capture is ended by the thread that began it.
         self.mode = mode if (dp is not None and dp.sync) else "full"
+        self.segments = []                       # [(graph, [bucket indices packed inside it])]
+        self.verify_replays = 3                  # replays after which the ranks compare their reduced gradients (world > 1)
         self.graph_b = None
         self.loss_fn = loss_fn or KDLossSoftandHard()
         self.warmup = int(warmup)
@@ -336,17 +353,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         mode = "global"
         if self.dp is not None and self.dp.sync:
-            # with a process group alive, c10d's watchdog thread polls the end events of the collectives it has not retired yet
-            # (every 100 ms), and on this stack an event query from that thread while THIS thread captures ends the process
-            # ("operation not permitted on an event last recorded in a capturing stream" -- also in split mode, where no
-            # collective is captured: seen with --sync-statsq, whose extra all-reduce per warm-up step is still on the
-            # watchdog's list when the capture starts right after the synchronize above).  So: only this thread's calls count
-            # as capture errors, and the watchdog gets three of its periods to retire the finished collectives -- everything
-            # is complete on the device (synchronize), retiring is all that is left; c10d offers no handle to wait for it
-            mode = "thread_local"
-            import time
-            time.sleep(0.35)
-        if self.mode == "split":
+            # With a process group alive, c10d's watchdog thread polls the end events of the collectives it has not retired yet
+            # (hipEventQuery every 100 ms).  Under capture mode "global" every thread's event queries count as capture errors
+            # while ANY thread captures, and on this stack that ends the process ("operation not permitted on an event last
+            # recorded in a capturing stream", raised in the watchdog: tools/capture_stress.py reproduces it).  So: only this
+            # thread's calls count (thread_local), and the capture starts only after every collective issued so far reports
+            # completion through its own Work handle (bounded, raises on timeout -- no blind sleep).
+            mode = self.capture_error_mode_dp
+            if self.drain_before_capture:
+                self.dp.drain_collectives()
+        if self.mode == "segmented":
+            self._capture_segmented(images, target, soft_target, mode)
+            g = self.segments[0][0]
+        elif self.mode == "split":
             self.dp.pack_only = True
             try:
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
@@ -367,6 +386,70 @@ class GraphedTrainStep:
         # the gradient tensors the replays write (static addresses in the graph's pool)
         self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
 
+    def _verify_reduction(self):
+        """First replays of a several-rank run: all ranks must hold identical reduced gradients before the optimiser graph runs
+        (DataParallel.check_reduced_gradients; a host sync, hence only `verify_replays` times)."""
+        if self.verify_replays > 0 and self.dp is not None and self.dp.world > 1:
+            self.verify_replays -= 1
+            self.dp.check_reduced_gradients()
+
+    def _capture_segmented(self, images, target, soft_target, capture_mode):
+        """Graph A as a chain of sub-graphs cut at the bucket boundaries (see __init__), graph B as in split mode."""
+        import gc
+        dp = self.dp
+        segs, state = [], {"g": None, "mark": 0, "carry": []}
+        pool = [torch.cuda.graph_pool_handle()]        # one private pool for the whole chain (replayed in capture order)
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool[0], capture_error_mode=capture_mode)
+            state["g"], state["mark"] = g, ops.LAUNCHES[0]
+
+        def end(buckets):
+            state["g"].capture_end()
+            segs.append((state["g"], buckets))
+            state["g"] = None
+
+        def on_packed(i):
+            # the hook that has just packed bucket i (DataParallel._launch): close the running sub-graph here unless it is the
+            # last bucket (whatever follows it -- the rest of backward, the loss check -- stays in its graph) or nothing has been
+            # launched since the last cut (two buckets completed by one node: they share a sub-graph)
+            state["carry"].append(i)
+            packed = sum(len(b) for _, b in segs) + len(state["carry"])
+            if packed < len(dp.buckets) and ops.LAUNCHES[0] > state["mark"]:
+                with torch.cuda.stream(self.stream):
+                    end(state["carry"])
+                    state["carry"] = []
+                    begin()
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        dp.pack_only, dp.on_packed = True, on_packed
+        prev_mt = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)      # the hooks (and so capture_end / capture_begin) run on this thread
+        try:
+            with torch.cuda.stream(self.stream):
+                begin()
+                try:
+                    self.loss = _step_compute(self.model, self.optimizer, images, target, soft_target, self.loss_fn, dp)
+                    dp.finish_gradient_sync()                  # packs what the hooks have not packed; starts nothing
+                    end(state["carry"])
+                except BaseException:
+                    if state["g"] is not None:                 # leave no stream in capture mode behind
+                        try:
+                            state["g"].capture_end()
+                        except Exception:  # noqa: BLE001
+                            pass
+                    raise
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, stream=self.stream, pool=pool[0], capture_error_mode=capture_mode):
+                _step_update(self.optimizer, None, self.cga)
+        finally:
+            torch.autograd.set_multithreading_enabled(prev_mt)
+            dp.pack_only, dp.on_packed = False, None
+        assert sorted(i for _, b in segs for i in b) == list(range(len(dp.buckets))), "a gradient bucket was never packed"
+        self.segments, self.graph_b = segs, gb
+
     def __call__(self, images, target, soft_target):
         self.calls += 1
         if self.graph is None and self.calls <= self.warmup:
@@ -376,6 +459,7 @@ class GraphedTrainStep:
                 loss = train_step(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
             cur.wait_stream(self.stream)
             return loss
+        ops.nt_sk_poll(images.device)
         if self.dp is not None:
             self.dp.sync_buffers()
         # the signedness latch of a still-unsigned image quantiser: decide on the host, as the eager forward would
@@ -407,10 +491,20 @@ class GraphedTrainStep:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
         self.optimizer.advance_for_replay()
-        self.graph.replay()
-        if self.graph_b is not None:
-            self.dp.all_reduce_packed()
+        if self.mode == "segmented":
+            for g, buckets in self.segments:
+                g.replay()
+                for i in buckets:                          # runs on RCCL's stream behind this sub-graph, next to the following one
+                    self.dp.all_reduce_bucket(i)
+            self.dp.wait_collectives()
+            self._verify_reduction()
             self.graph_b.replay()
+        else:
+            self.graph.replay()
+            if self.graph_b is not None:
+                self.dp.all_reduce_packed()
+                self._verify_reduction()
+                self.graph_b.replay()
         if self._static_grads and self._static_grads[0][0].grad is not self._static_grads[0][1]:
             for p, g in self._static_grads:            # an eager step in between re-pointed p.grad: show the replay's
                 p.grad = g

@@ -75,6 +75,20 @@ def assert_no_pending_dx():
                            "did not run its backward)" % n)
 
 
+_END_CHECK_QUEUED = [False]
+
+
+def _check_parked_at_end_of_backward():
+    if _END_CHECK_QUEUED[0]:
+        return
+    _END_CHECK_QUEUED[0] = True
+
+    def _cb():
+        _END_CHECK_QUEUED[0] = False
+        assert_no_pending_dx()
+    torch.autograd.Variable._execution_engine.queue_callback(_cb)
+
+
 def assert_step_queues_empty():
     """End of a training step's backward pass (engine._step_body, after flush_dw): no parked input-gradient GEMM, no queued
     weight-gradient GEMM, no deferred second-stage reduction -- each of them stands for gradient memory that autograd already
@@ -130,8 +144,18 @@ _DEFERRED_ONCE = set()
 _ADOPT_CHECK = []          # (leaf, address the queued kernel wrote): verified at the end of the step
 
 
+def _forget_parked_dx():
+    """Drop input-gradient GEMMs parked by a backward pass that never finished (their dY / weight operands stay pinned otherwise,
+    and the next step would fail in assert_no_pending_dx for something that step did not do)."""
+    for acc in _DX_PENDING:
+        acc.pop("lin_pending", None)
+    del _DX_PENDING[:]
+    _END_CHECK_QUEUED[0] = False
+
+
 def begin_backward():
     """engine._step_body, right before loss.backward()."""
+    _forget_parked_dx()
     _QUEUED_LEAVES.clear()
     _DEFERRED_ONCE.clear()
     del _ADOPT_CHECK[:]
@@ -214,6 +238,7 @@ def flush_dw():
 
 def drop_dw():
     """Forget the queue (a backward pass that raised)."""
+    _forget_parked_dx()
     del _DW_QUEUE[:]
     _DW_TILES[0] = 0
     _QUEUED_LEAVES.clear()
@@ -310,6 +335,10 @@ class CodesLinearFn(torch.autograd.Function):
                     and ops.nt_concat_ok(dy2d, aux["wcodesT"], acc.get("lin_pending"))):
                 acc.setdefault("lin_pending", []).append(seg)
                 _DX_PENDING.append(acc)
+                if not DW_DEFER:
+                    # outside engine's step (whose end runs assert_step_queues_empty) a partner that never arrives would go
+                    # unnoticed: have the END of this backward pass check it (autograd's per-pass callback queue)
+                    _check_parked_at_end_of_backward()
             elif npend:
                 segs = acc.pop("lin_pending") + [seg]
                 _DX_PENDING[:] = [a_ for a_ in _DX_PENDING if a_ is not acc]
@@ -1080,14 +1109,14 @@ class KDLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cls_out, dist_out, soft_target, hard_target):
-        loss, dcls, ddist = ops.kd_loss_fwd(cls_out, dist_out, soft_target, hard_target)
-        ctx.save_for_backward(dcls, ddist)
+        loss, dcls, ddist, cls_scale = ops.kd_loss_fwd(cls_out, dist_out, soft_target, hard_target)
+        ctx.save_for_backward(dcls, ddist, cls_scale)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        dcls, ddist = ctx.saved_tensors
-        oc, od = ops.kd_loss_bwd(g.contiguous(), dcls, ddist)
+        dcls, ddist, cls_scale = ctx.saved_tensors
+        oc, od = ops.kd_loss_bwd(g.contiguous(), dcls, ddist, cls_scale)
         return oc, od, None, None
 
 

@@ -83,7 +83,11 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+LAUNCHES = [0]          # ctypes launches so far (engine.GraphedTrainStep: "has this capture segment recorded anything yet?")
+
+
 def _chk(rc, what):
+    LAUNCHES[0] += 1
     if rc != 0:
         raise RuntimeError("ofq_amd: %s failed with code %d" % (what, rc))
 
@@ -471,6 +475,56 @@ def nt_sk_error(device):
     return err
 
 
+def nt_sk_poison(loss):
+    """loss <- NaN when a stream-K hand-off on this device / stream has timed out (one tiny launch, no host sync, capturable):
+    engine's step calls it right after the backward pass, so a corrupt gradient is announced by the loss of the same step."""
+    buf = _sk_ws.get((loss.device.index, _stream()))
+    if buf is not None:
+        _chk(lib().ofq_qgemm_bf16s_nt_sk_check(buf.data_ptr(), loss.data_ptr(), _stream()), "ofq_qgemm_bf16s_nt_sk_check")
+
+
+_sk_poll = {}
+
+
+def nt_sk_poll(device):
+    """Host side of the same check without a synchronisation: every call queues an asynchronous copy of the error words to
+    pinned memory behind the work enqueued so far and looks at the copy queued by the PREVIOUS call if it has arrived.
+    Raises once an error word is seen (after re-zeroing the flag areas, so that training can be resumed from a checkpoint
+    without restarting the process); engine.train_step / GraphedTrainStep call it once per step."""
+    bufs = [buf for (idx, _st), buf in _sk_ws.items() if idx == device.index]
+    st = _sk_poll.get(device.index)
+    if st is not None and st[1].query():
+        bad = bool(st[0][:st[2]].any())
+        _sk_poll.pop(device.index)
+        st = None
+        if bad:
+            nt_sk_reset(device)
+            raise RuntimeError("ofq_amd: a stream-K hand-off timed out in an earlier step (a workgroup of ofq_qgemm_bf16s_nt_sk "
+                               "waited ~0.6 s for a partial tile): the gradients since then are invalid; the flag areas have been "
+                               "re-zeroed -- restore the last checkpoint")
+    if st is None and bufs:
+        host = torch.empty(len(bufs), dtype=torch.int32).pin_memory()
+        for i, buf in enumerate(bufs):
+            host[i:i + 1].copy_(buf[:32768].view(torch.int32)[4096:4097], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _sk_poll[device.index] = (host, ev, len(bufs))
+
+
+def nt_sk_reset(device):
+    """Re-zero flags, error word and test words of every stream-K workspace of the device (after nt_sk_error() != 0)."""
+    _sk_poll.pop(device.index, None)
+    for (idx, _st), buf in _sk_ws.items():
+        if idx == device.index:
+            _chk(lib().ofq_qgemm_bf16s_nt_sk_reset(buf.data_ptr(), _stream()), "ofq_qgemm_bf16s_nt_sk_reset")
+
+
+def nt_sk_inject_fault(device, wg):
+    """Test hook: workgroup `wg` of the next stream-K launches on the current stream never publishes its partial (wg < 0: off)."""
+    buf = _sk_workspace(device)
+    buf[:32768].view(torch.int32)[4097] = wg + 1 if wg >= 0 else 0
+
+
 def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
     """out[m,n] (+)= sum over segs of alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]; segs = [(A, B_bf16, k_scale, alpha), ...] (1 or 2)"""
     M, N = out.shape
@@ -524,7 +578,10 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     N = B_bf16.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    if nsplit == 3 and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
+    # (the stream-K launch shares PAIRS of 32-wide k-steps and addresses rows with 32-bit offsets: other shapes take the
+    # one-tile-per-workgroup kernel also when sk=True)
+    sk_able = N > 128 and K % 64 == 0 and M * A.stride(0) * 4 < 2 ** 32 and N * B_bf16.stride(0) * 2 < 2 ** 32
+    if nsplit == 3 and sk_able and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
         return qgemm_bf16s_nt_sk([(A, B_bf16, k_scale, alpha)], out, accumulate)
     with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
@@ -789,17 +846,17 @@ def kd_loss_fwd(cls_logits, dist_logits, teacher_logits, target):
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dcls = torch.empty((B, K), dtype=torch.float32, device=dev)
     ddist = torch.empty((B, K), dtype=torch.float32, device=dev)
-    rows = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    rows = torch.empty(2 * B + 1, dtype=torch.float32, device=dev)
     _chk(lib().ofq_kd_loss_fwd(cls_logits.data_ptr(), dist_logits.data_ptr(), teacher_logits.data_ptr(), target.data_ptr(),
                                loss.data_ptr(), dcls.data_ptr(), ddist.data_ptr(), rows.data_ptr(), B, K, cls_logits.stride(0),
                                dist_logits.stride(0), teacher_logits.stride(0), _stream()), "ofq_kd_loss_fwd")
-    return loss, dcls, ddist
+    return loss, dcls, ddist, rows[2 * B:]          # (the last one: B / number of rows whose label is not ignore_index)
 
 
-def kd_loss_bwd(g, dcls, ddist):
+def kd_loss_bwd(g, dcls, ddist, cls_scale=None):
     oc, od = torch.empty_like(dcls), torch.empty_like(ddist)
-    _chk(lib().ofq_kd_loss_bwd(g.data_ptr(), dcls.data_ptr(), ddist.data_ptr(), oc.data_ptr(), od.data_ptr(), dcls.numel(), _stream()),
-         "ofq_kd_loss_bwd")
+    _chk(lib().ofq_kd_loss_bwd(g.data_ptr(), dcls.data_ptr(), ddist.data_ptr(), 0 if cls_scale is None else cls_scale.data_ptr(),
+                               oc.data_ptr(), od.data_ptr(), dcls.numel(), _stream()), "ofq_kd_loss_bwd")
     return oc, od
 
 

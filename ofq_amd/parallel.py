@@ -94,6 +94,13 @@ class DataParallel(torch.nn.Module):
         # all_reduce_packed() then reduces every bucket eagerly.  This is how engine.GraphedTrainStep(mode="split") keeps
         # RCCL out of its captured graphs: [graph: forward + backward + packing] -> eager all-reduces -> [graph: optimiser].
         self.pack_only = False
+        # on_packed(bucket index): called at the end of a pack_only bucket launch -- engine.GraphedTrainStep(mode="segmented")
+        # ends the running stream capture there, so that the bucket's all-reduce can be issued between two sub-graphs
+        self.on_packed = None
+        # Work handles of the eager collectives issued since the last drain_collectives(): a stream capture is only started
+        # once every one of them reports completion (engine.GraphedTrainStep._capture)
+        self._eager_works = []
+        self._pending_works = []
         if broadcast and self.sync:
             self.broadcast_parameters()
         self._build_buckets(bucket_mb)
@@ -108,13 +115,20 @@ class DataParallel(torch.nn.Module):
         for dtype in {t.dtype for t in tensors}:
             group = [t for t in tensors if t.dtype == dtype]
             flat = torch.cat([t.reshape(-1) for t in group])
-            dist.broadcast(flat, src=0, group=self.group)
+            self._broadcast(flat)
             off = 0
             for t in group:
                 n = t.numel()
                 t.copy_(flat[off:off + n].view_as(t))
                 off += n
         self._forget_latches()
+
+    def _broadcast(self, flat):
+        w = dist.broadcast(flat, src=0, group=self.group, async_op=True)
+        w.wait()
+        if not hasattr(self, "_eager_works"):
+            self._eager_works = []
+        self._eager_works.append(w)
 
     def _latch_quantizers(self):
         return [m for m in self.module.modules() if hasattr(m, "sync_latch") and hasattr(m, "latched")]
@@ -135,7 +149,7 @@ class DataParallel(torch.nn.Module):
         for dtype in {t.dtype for t in bufs}:
             group = [t for t in bufs if t.dtype == dtype]
             flat = torch.cat([t.reshape(-1) for t in group])
-            dist.broadcast(flat, src=0, group=self.group)
+            self._broadcast(flat)
             off = 0
             for t in group:
                 n = t.numel()
@@ -189,6 +203,8 @@ class DataParallel(torch.nn.Module):
         self.zero_grad()
 
     def _reset(self):
+        if len(self._eager_works) > 256:              # (eager training never drains: keep the tail, a drain synchronises anyway)
+            del self._eager_works[:-64]
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
@@ -220,12 +236,74 @@ class DataParallel(torch.nn.Module):
             p.grad = v
         if self.pack_only:
             b.work = "packed"
+            if self.on_packed is not None:
+                self.on_packed(self.buckets.index(b))
             return
+        b.work = self._all_reduce(b)
+
+    def _all_reduce(self, b):
+        """Start the asynchronous mean all-reduce of one packed bucket (RCCL: AVG inside the collective; gloo: divide, then SUM)."""
         if self._avg:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            w = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:
             b.flat.div_(self.world)
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if not _capturing(b.flat):
+            self._eager_works.append(w)
+        return w
+
+    def all_reduce_bucket(self, i):
+        """The all-reduce of bucket i of a pack_only step, on its own: engine.GraphedTrainStep(mode="segmented") issues it right
+        after the sub-graph that packed the bucket, so that it runs on RCCL's stream next to the following sub-graph."""
+        if self.sync:
+            self._pending_works.append(self._all_reduce(self.buckets[i]))
+
+    def wait_collectives(self):
+        """The current stream waits for the collectives started by all_reduce_bucket (+ the StatsQ-scale check if it is on)."""
+        if not self.sync:
+            return
+        if self.sync_statsq:
+            self._statsq_all_reduce()
+        for w in self._pending_works:
+            w.wait()
+        del self._pending_works[:]
+
+    @torch.no_grad()
+    def check_reduced_gradients(self):
+        """After the bucket all-reduces of a step: every rank must hold the SAME bytes (an all-reduce hands every rank the same
+        result).  One small MAX / MIN all-reduce pair over per-bucket checksums and a host sync: engine.GraphedTrainStep calls it
+        for the first replays of a several-rank run, so that a mis-ordered collective (a reduce that ran before its bucket was
+        packed, or raced with the optimiser) stops the run instead of training on different gradients per rank."""
+        if not self.sync:
+            return 0.0
+        cs = torch.stack([torch.stack((b.flat.double().sum(), b.flat.double().abs().sum())) for b in self.buckets]).reshape(-1)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dev = float((hi - lo).abs().max())
+        if dev != 0.0 or not bool(torch.isfinite(cs).all()):
+            raise RuntimeError("ofq_amd DataParallel: the ranks hold different (or non-finite) gradients after the all-reduce "
+                               "(checksum spread %g): a collective ran out of order with the kernels around it" % dev)
+        return dev
+
+    def drain_collectives(self, timeout_s=30.0):
+        """Before a stream capture: every eager collective issued so far must have COMPLETED as seen through its own Work
+        handle (c10d's watchdog thread polls the same end events; a capture that starts while one of them is still in flight
+        has ended the process on this stack).  Bounded: raises after timeout_s instead of sleeping blindly."""
+        import time
+        works, self._eager_works = self._eager_works, []
+        t0 = time.monotonic()
+        for w in works:
+            w.wait()
+        if works and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for w in works:
+            while not w.is_completed():
+                if time.monotonic() - t0 > timeout_s:
+                    raise RuntimeError("ofq_amd DataParallel: a collective issued before the capture did not complete within %.0f s"
+                                       % timeout_s)
+                time.sleep(0.001)
+        return len(works)
 
     def _on_grad(self, p):
         if self._arrival is not None:
@@ -285,13 +363,7 @@ class DataParallel(torch.nn.Module):
         so far; the current stream then waits for the four collectives), then the StatsQ-scale check if it is on."""
         if not self.sync:
             return
-        works = []
-        for b in self.buckets:
-            if self._avg:
-                works.append(dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-            else:
-                b.flat.div_(self.world)
-                works.append(dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        works = [self._all_reduce(b) for b in self.buckets]
         if self.sync_statsq:
             self._statsq_all_reduce()
         for w in works:
@@ -305,10 +377,14 @@ class DataParallel(torch.nn.Module):
         local = torch.cat(vecs)
         mean = local.clone()
         if self._avg:
-            dist.all_reduce(mean, op=dist.ReduceOp.AVG, group=self.group)
+            w = dist.all_reduce(mean, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            w.wait()
         else:
-            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group)
+            w = dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()
             mean.div_(self.world)
+        if not _capturing(local):
+            self._eager_works.append(w)
         dev = (mean - local).abs().max()                 # stays on the device ...
         if self._statsq_pending is None:                 # (a persistent scalar: a captured step max-accumulates into the
             self._statsq_pending = torch.zeros((), dtype=dev.dtype, device=dev.device)     # same memory in every replay)

@@ -281,9 +281,10 @@ def main_worker(local_rank, args, cga, spawned):
     graphed = None
     multi_rank = dp is not None and getattr(dp, "world", 1) > 1
     if not args.no_graph and hasattr(optimizer, "advance_for_replay"):
-        # several ranks: captured compute, eager bucket all-reduces between two graphs (--graph: collectives captured too)
+        # several ranks: captured compute in sub-graphs cut at the gradient buckets, each bucket's all-reduce issued eagerly behind
+        # its sub-graph and overlapped with the next (--graph: collectives captured too)
         graphed = engine.GraphedTrainStep(model, optimizer, loss_fn, dp=dp, cga=hooks,
-                                          mode="split" if (multi_rank and not args.graph) else "full")
+                                          mode="segmented" if (multi_rank and not args.graph) else "full")
     no_soft = torch.zeros(args.batch_size, args.num_classes, device=dev)
     for epoch in range(first, last):                                                        # cga.py:760 / train.py:816
         model.train()

@@ -320,8 +320,11 @@ def test_data_parallel_over_rccl_one_rank_equals_plain_step_and_graph():
         dist.destroy_process_group()
 
 
-def test_split_graph_step_with_eager_collectives_equals_the_eager_step():
-    """engine.GraphedTrainStep(mode="split"), the several-rank default of bench.py / train.py: graph A = zero_grad + StatsQ
+@pytest.mark.parametrize("mode", ["segmented", "split"])
+def test_split_graph_step_with_eager_collectives_equals_the_eager_step(mode):
+    """engine.GraphedTrainStep(mode="segmented"), the several-rank default of bench.py / train.py since round 5: graph A cut into
+    sub-graphs at the gradient-bucket boundaries, bucket i's all-reduce issued eagerly behind sub-graph i (so that it runs next
+    to sub-graph i+1: train.py:727's overlap), then graph B; and mode="split", round 4's form: graph A = zero_grad + StatsQ
     refresh + forward + loss + backward + bucket packing, then the bucket all-reduces issued eagerly on RCCL's stream, then
     graph B = CGA masks + AdamW + restore (train.py:474, :727, :927-933; cga.py:953-1013).  One rank over RCCL (a 1-GPU box)
     against the eager DataParallel step and the plain step: losses, parameters and AdamW state bit for bit over seven steps
@@ -339,19 +342,37 @@ def test_split_graph_step_with_eager_collectives_equals_the_eager_step():
             return parallel.DataParallel(model, bucket_mb=1.0, force_sync=True, sync_statsq=True)
         lp, sp, _, _ = _run(base, len(seq), False, seq, cga=True)
         le, se, _, _ = _run(base, len(seq), False, seq, cga=True, dp_factory=mk)
-        calls = []
-        real = dist.all_reduce
+        calls, events = [], []
+        real, real_replay = dist.all_reduce, torch.cuda.CUDAGraph.replay
 
         def spy(t, *a, **k):
             calls.append(torch.cuda.is_current_stream_capturing())
+            events.append("ar")
             return real(t, *a, **k)
+
+        def spy_replay(self_):
+            events.append("replay")
+            return real_replay(self_)
         dist.all_reduce = spy
+        torch.cuda.CUDAGraph.replay = spy_replay
         try:
-            lg, sg, gs, mg = _run(base, len(seq), True, seq, cga=True, dp_factory=mk, mode="split")
+            lg, sg, gs, mg = _run(base, len(seq), True, seq, cga=True, dp_factory=mk, mode=mode)
         finally:
             dist.all_reduce = real
-        assert gs.mode == "split" and gs.graph_b is not None and gs.captures == 2
+            torch.cuda.CUDAGraph.replay = real_replay
+        assert gs.mode == mode and gs.graph_b is not None and gs.captures == 2
         assert calls and not any(calls), "a collective was issued inside a stream capture"
+        if mode == "segmented":
+            # several sub-graphs, every bucket in exactly one of them, and in the last replayed step the first bucket's
+            # all-reduce is on RCCL's stream BEFORE the last backward sub-graph is launched (overlap by construction)
+            nseg = len(gs.segments)
+            assert nseg >= 2 and sorted(i for _, b in gs.segments for i in b) == list(range(len(gs.dp.buckets)))
+            last = events[-(nseg + 1 + len(gs.dp.buckets) + 1):]           # nseg replays + graph B + bucket ARs + StatsQ AR
+            assert last.count("replay") == nseg + 1, last
+            first_ar = last.index("ar")
+            last_a_replay = [i for i, e in enumerate(last) if e == "replay"][-2]
+            assert first_ar < last_a_replay, last
+            assert last[-1] == "replay" and last[-2] == "ar"
         assert lp == le == lg, (lp, le, lg)
         _same(se, sg)
         _same(sp, sg)
@@ -690,11 +711,11 @@ def _two_rank_worker(rank, world, port, errq):
 
         # (2) five steps: eager DataParallel against captured compute + eager collectives, and rank against rank
         res = {}
-        for mode in ("eager", "split"):
+        for mode in ("eager", "split", "segmented"):
             model = copy.deepcopy(base).train()
             dp = parallel.DataParallel(model, bucket_mb=1.0)
             opt = engine.make_optimizer(model, lr=_lr_at(0), weight_decay=0.05)
-            gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, warmup=2, mode="split") if mode == "split" else None
+            gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, warmup=2, mode=mode) if mode != "eager" else None
             losses = []
             for i in range(5):
                 for g in opt.param_groups:
@@ -704,7 +725,10 @@ def _two_rank_worker(rank, world, port, errq):
                 losses.append(float(loss.detach()))
             torch.cuda.synchronize()
             if gs is not None:
-                assert gs.mode == "split" and gs.graph_b is not None and gs.captures == 1
+                assert gs.mode == mode and gs.graph_b is not None and gs.captures == 1
+                assert gs.verify_replays == 0              # the ranks compared their reduced gradients after the first replays
+                if mode == "segmented":
+                    assert len(gs.segments) >= 2
             res[mode] = (losses, [p.detach().clone() for p in model.parameters()])
             flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
             lo, hi = flat.clone(), flat.clone()
@@ -712,9 +736,10 @@ def _two_rank_worker(rank, world, port, errq):
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             assert torch.equal(lo, hi), "replicas diverged in mode " + mode
             dp.release()
-        assert res["eager"][0] == res["split"][0], res
-        for a, b_ in zip(res["eager"][1], res["split"][1]):
-            assert torch.equal(a, b_)
+        for mode in ("split", "segmented"):
+            assert res["eager"][0] == res[mode][0], (mode, res["eager"][0], res[mode][0])
+            for a, b_ in zip(res["eager"][1], res[mode][1]):
+                assert torch.equal(a, b_), mode
         dist.barrier()
         dist.destroy_process_group()
     except BaseException:  # noqa: BLE001

@@ -474,6 +474,80 @@ def test_two_segment_dx_gemm_is_the_sum_of_the_two_gemms(ops, mnkk):
     assert ops.nt_sk_error(dy0.device) == 0
 
 
+def test_stream_k_handoff_timeout_is_raised_sticky_and_recoverable(ops):
+    """The hand-off of a cut tile (csrc/qgemm.hip, qgemm_bf16s_nt_wide_sk_kernel): a publisher that never sets its flag (fault
+    injection word of the workspace) makes the owner's bounded wait run out.  Then: the error word is raised and STAYS raised over
+    later launches; ops.nt_sk_poison turns a step's loss into NaN without a host sync; ops.nt_sk_poll raises on the host at the next
+    step boundary and re-zeroes the flag area; and the launches after that give the right bits again."""
+    M, N, K = 640, 384, 256
+    dy, ks, wcodes = _nt_operands(M, N, K, 5)
+    wT = ops.codes_transpose_bf16(wcodes)
+    dev = dy.device
+    good = torch.full((M, N), float("nan"), device="cuda")
+    ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], good, wgs=3)            # 5 tiles x 4 k-step pairs on 3 workgroups: tiles 1 and 3 are cut
+    torch.cuda.synchronize()
+    assert ops.nt_sk_error(dev) == 0
+    loss = torch.ones((), device="cuda")
+    ops.nt_sk_poison(loss)
+    assert float(loss) == 1.0
+    ops.nt_sk_poll(dev); torch.cuda.synchronize(); ops.nt_sk_poll(dev)       # nothing to report
+    ops.nt_sk_inject_fault(dev, 1)                                           # workgroup 1 publishes the head of its run ... never
+    bad = torch.full((M, N), float("nan"), device="cuda")
+    ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], bad, wgs=3)
+    torch.cuda.synchronize()
+    assert ops.nt_sk_error(dev) != 0
+    assert not torch.equal(bad, good)                                       # the owner stored its tile without the partial
+    ops.nt_sk_inject_fault(dev, -1)
+    again = torch.full((M, N), float("nan"), device="cuda")
+    ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], again, wgs=3)               # the word is sticky: a clean launch does not clear it
+    torch.cuda.synchronize()
+    assert ops.nt_sk_error(dev) != 0
+    ops.nt_sk_poison(loss)
+    assert torch.isnan(loss)
+    ops.nt_sk_poll(dev)                                                     # queues the copy ...
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="stream-K hand-off timed out"):
+        ops.nt_sk_poll(dev)                                                 # ... and the next step boundary sees it
+    torch.cuda.synchronize()
+    assert ops.nt_sk_error(dev) == 0                                        # flag area re-zeroed by the poll that raised
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], out, wgs=3)
+        assert torch.equal(out, good)
+    assert ops.nt_sk_error(dev) == 0
+
+
+def test_engine_step_surfaces_a_stream_k_timeout(ops):
+    """engine.train_step: the step whose backward follows a timed-out hand-off returns a NaN loss, and the next call raises."""
+    from ofq_amd import engine
+    model = engine.build_student("deit_tiny_distilled_patch16_224", wbits=4, abits=4, depth=1, num_classes=10).cuda()
+    img = torch.randn(2, 3, 224, 224, device="cuda")
+    tgt = torch.randint(0, 10, (2,), device="cuda")
+    soft = torch.randn(2, 10, device="cuda")
+    engine.setup_alpha(model, img)
+    model.train()
+    opt = engine.make_optimizer(model)
+    l0 = engine.train_step(model, opt, img, tgt, soft)
+    assert torch.isfinite(l0)
+    dev = img.device
+    # an unrelated stream-K launch on the same stream times out (fault injection) between two steps
+    dy, ks, wcodes = _nt_operands(640, 384, 256, 5)
+    out = torch.empty((640, 384), device="cuda")
+    ops.nt_sk_inject_fault(dev, 1)
+    ops.qgemm_bf16s_nt_sk([(dy, ops.codes_transpose_bf16(wcodes), ks, 0.25)], out, wgs=3)
+    ops.nt_sk_inject_fault(dev, -1)
+    l1 = engine.train_step(model, opt, img, tgt, soft)
+    torch.cuda.synchronize()
+    assert torch.isnan(l1)
+    with pytest.raises(RuntimeError, match="stream-K hand-off timed out"):
+        engine.train_step(model, opt, img, tgt, soft)
+        torch.cuda.synchronize()
+        engine.train_step(model, opt, img, tgt, soft)
+    torch.cuda.synchronize()
+    assert ops.nt_sk_error(dev) == 0
+    assert torch.isfinite(engine.train_step(model, opt, img, tgt, soft))
+
+
 @pytest.mark.parametrize("colmode", [0, 1])
 def test_i8_recompute_backward_is_deterministic(ops, colmode):
     """ofq_qgemm_i8_lsq_bwd at the DeiT-S token count, five launches on the same operands: outputs AND the per-workgroup
@@ -1286,6 +1360,23 @@ def test_kd_loss_kernel_equals_the_torch_ops(ops, BK):
     # through the module the reference's recipes construct
     from ofq_amd.quantization.utils import KDLossSoftandHard
     assert abs(float(KDLossSoftandHard()((c.detach(), d.detach()), y, t)) - float(ref)) < 2e-6 * abs(float(ref))
+    # nn.CrossEntropyLoss's ignore_index (-100): such rows give neither loss nor gradient, the hard term averages over the others
+    yi = y.clone()
+    yi[::3] = -100
+    c.grad = d.grad = None
+    ref = -torch.sum(F.softmax(t, dim=1) * F.log_softmax(d, dim=1), dim=1).mean() + F.cross_entropy(c, yi)
+    (ref * 0.6).backward()
+    gc, gd = c.grad.clone(), d.grad.clone()
+    c.grad = d.grad = None
+    loss = KDLossFn.apply(c, d, t, yi)
+    (loss * 0.6).backward()
+    assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel_err(c.grad.cpu(), gc.cpu()) < 2e-6 and rel_err(d.grad.cpu(), gd.cpu()) < 2e-6
+    assert float(c.grad[::3].abs().max()) == 0.0
+    # a label outside [0, K) that is not ignore_index (the stock op traps): the loss is NaN, not a silently different number
+    yb = y.clone()
+    yb[0] = K
+    assert torch.isnan(KDLossFn.apply(c.detach(), d.detach(), t, yb))
 
 
 @pytest.mark.parametrize("dist", [True, False])

@@ -131,6 +131,26 @@ def _worker(rank, world, port, q):
     dp.all_reduce_packed()
     g_packed = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
     assert torch.equal(g_packed, g_sync)
+    # the same, bucket by bucket (engine.GraphedTrainStep(mode="segmented"): on_packed fires in the hook that packs a bucket --
+    # there the step cuts its captured graph -- and all_reduce_bucket(i) / wait_collectives() reduce each bucket on its own)
+    seen = []
+    dp.pack_only, dp.on_packed = True, seen.append
+    dp.zero_grad()
+    (((dp(xs) - ys) ** 2).mean() + 0.0 * net.extra.sum()).backward()
+    dp.finish_gradient_sync()
+    dp.pack_only, dp.on_packed = False, None
+    assert sorted(seen) == list(range(len(dp.buckets))), seen
+    for i in seen:
+        dp.all_reduce_bucket(i)
+    dp.wait_collectives()
+    g_seg = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
+    assert torch.equal(g_seg, g_sync)
+    assert dp.check_reduced_gradients() == 0.0           # every rank holds the same reduced bytes
+    assert dp.drain_collectives() > 0 and dp.drain_collectives() == 0       # every eager collective so far has completed
+    if rank == 1:
+        dp.buckets[0].flat[0] += 1.0                       # ... and a rank whose gradients differ is caught
+    with pytest.raises(RuntimeError, match="different .* gradients"):
+        dp.check_reduced_gradients()
     # StatsQ statistic is a pure function of the (identical) weights: max - min over ranks must be exactly 0
     class Holder(nn.Module):
         pass

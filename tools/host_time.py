@@ -35,7 +35,7 @@ for mode in MODES:
     if mode == "eager":
         step = lambda: engine.train_step(model, opt, images, target, soft, crit, dp=dp)      # noqa: E731
     else:
-        gs = engine.GraphedTrainStep(model, opt, crit, dp=dp, warmup=2, alias_inputs=True, mode="split" if mode == "split" else "full")
+        gs = engine.GraphedTrainStep(model, opt, crit, dp=dp, warmup=2, alias_inputs=True, mode=mode if mode in ("split", "segmented") else "full")
         step = lambda: gs(images, target, soft)                                             # noqa: E731
     for _ in range(6):
         step()
