@@ -46,7 +46,9 @@ int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* 
                    int8_t* levels, int scale_given, int odd_codes, ofq_stream_t stream);
 /*  The code path of the quantised linear layers in one launch: scale, the odd int8 codes 2L+1 [rows][cols], optionally
  *  the fake-quant values (out may be NULL), the codes transposed as bf16 [cols][rows] (operand of the dX GEMM) and
- *  rout[row] = sum_k rvec[k] * code[row][k] (the offset term of ofq_qgemm_i8_nt: rvec = the layer's move_aft). */
+ *  rout[row] = sum_k rvec[k] * code[row][k] (the offset term of ofq_qgemm_i8_nt: rvec = the layer's move_aft).
+ *  bits | 0x100 (here and in ofq_statsq_tensor's bits): the transposed codes are written as FP16 instead of bf16 -- the operand
+ *  of the two-plane fp16 form of the dX GEMM (ofq_qgemm_bf16s_nt with amax). */
 int ofq_statsq_codes_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* codes,
                          void* codesT_bf16, const float* rvec, float* rout, ofq_stream_t stream);
 /*  The same code path for MANY weight tensors in one or two launches (weights only change at the optimizer step, so a
@@ -165,9 +167,15 @@ int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, co
 
 /*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
  *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.
- *            K % 8 == 0, lda % 4 == 0, ldb % 8 == 0. */
+ *            K % 8 == 0, lda % 4 == 0, ldb % 8 == 0.
+ *            amax != NULL (with nsplit = 2): the TWO-PLANE FP16 form (round 5).  *amax = the bits of an upper bound of max |A|
+ *            (a device word: what ofq_absmax_f32 or the producing backward kernel's amax_out wrote), B = the codes as FP16.
+ *            The launch scales A*k_scale by the power of two that puts its largest magnitude into [2^14, 2^15), splits it into
+ *            hi = rne_f16(x), lo = rne_f16(x - hi) -- |x - hi - lo| <= 2^-24 |x| for elements within 2^-17 of the maximum,
+ *            <= 2^-39 of the maximum below -- and un-scales in the epilogue: fp32-grade on the scale of the tensor with two
+ *            matrix-core products per element instead of three (reference op: autograd of F.linear, qlinear.py:69). */
 int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha, int accumulate,
-                       int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                       int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* amax,
                        ofq_stream_t stream);
 /*  stream-K form of the same product, for shapes whose 128 x 384 tiles do not fill the chip (M = 25 344 tokens: 198 row
  *            tiles on 256 CUs): `num_wgs` workgroups (pass the CU count) share the tiles x k-steps of the launch evenly, each walking its share as one continuous k-step stream;
@@ -195,6 +203,8 @@ typedef struct ofq_nt_seg {
   const float* A; const void* B_bf16; const float* k_scale;
   int64_t K, lda, ldb;
   float alpha;
+  const void* amax;     /* NULL: three bf16 planes, B_bf16 = bf16 codes.  Else (every segment of the launch): the device word
+                           holding the bits of an upper bound of max |A| -- the two-plane fp16 form, B_bf16 = FP16 codes */
 } ofq_nt_seg;
 size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs);
 int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs);
@@ -220,7 +230,7 @@ int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const float* k_s
 size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split);
 int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S, float gscale,
                        float* db, int compute_db, const float* baft, int64_t Ktok, int64_t M, int64_t N, int64_t lda,
-                       int64_t ldb, int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                       int64_t ldb, int split, void* ws, size_t ws_bytes, const void* amax, ofq_stream_t stream);
 /*  several weight gradients in one GEMM launch + one reduce launch (each job = one ofq_qgemm_bf16s_tn call, same
  *            results bit for bit).  The weight gradients of F.linear (qlinear.py:69) have no consumer before the
  *            optimiser step / gradient all-reduce (train.py:927-933), so a caller may collect the ones of a whole
@@ -232,11 +242,20 @@ typedef struct ofq_tn_job {
   const float* dY; const int8_t* codes; float* dW; const float* lsq_s; float* db; const float* baft;
   int64_t S, Ktok, M, N, lda, ldb;
   float gscale; int32_t compute_db;
+  const void* amax;     /* NULL: three bf16 planes of dY.  Else (every job of the launch): the device word with the bits of an upper
+                           bound of max |dY| -- two fp16 planes of dY * step * 2^E (see ofq_qgemm_bf16s_nt) */
 } ofq_tn_job;
 size_t ofq_qgemm_bf16s_tn_group_ws_bytes(const ofq_tn_job* jobs, int njobs, int split);
 int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int split, void* ws, size_t ws_bytes, ofq_stream_t stream);
 /*  int8 codes [rows][cols] -> bf16 [cols][rows];   out[r] = sum_k vec[k]*codes[r][k] */
 int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
+/*  the same with the codes as FP16 (B operand of the two-plane form: ofq_qgemm_bf16s_nt / _nt_sk with amax) */
+int ofq_codes_transpose_f16(const int8_t* codes, void* out_f16, int64_t rows, int64_t cols, ofq_stream_t stream);
+/*  *amax = max(*amax, bits of max |x[r][c]|) over x fp32 [rows][cols] (ld), by atomic maxima on the bit patterns (order-independent:
+ *            deterministic; a NaN in x gives the NaN pattern).  The caller zeroes *amax.  Serves the two-plane fp16 backward GEMMs
+ *            (autograd of F.linear, qlinear.py:69) for gradient tensors whose producer did not write the word itself.
+ *            cols % 4 == 0, ld % 4 == 0, x 16-byte aligned. */
+int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* amax, ofq_stream_t stream);
 int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);
 
 /* ---- attention products on the integer codes (QAttention_qkreparam.forward attention.py:200-219 and autograd).
@@ -287,10 +306,14 @@ int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, const float*
                              void* ws, size_t ws_bytes, ofq_stream_t stream);
 int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
                        int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream);
+/*  (dqkx, dxq) amax: NULL = three bf16 planes of dS; else the device word with the bits of an upper bound of max |dS| over the
+ *  N real columns of its rows (the pad columns up to ldS are never read and may hold anything): the two-plane fp16 form of the
+ *  wide kernels, see ofq_qgemm_bf16s_nt */
 int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,
-                         const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+                         const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, const void* amax,
+                         ofq_stream_t stream);
 int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float* dxq, const float* sq, float gscale_q, int accumulate,
-                        int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream);
+                        int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, const void* amax, ofq_stream_t stream);
 /*  helpers: out[r][v] = sum_k vecs[v][k]*codes[r][k];  out[r][h] = sum_{c<d} x[r][h*d+c]*vec[h*d+c];
  *  batched int8 transpose with zero padding in [B][R][C] -> out [B][C][Rp] */
 int ofq_rowdot_i8_multi(const int8_t* codes, const float* vecs, float* out, int64_t rows, int64_t cols, int nvec,

@@ -24,13 +24,13 @@ class GemmDesc(C.Structure):
 
 
 class NtSeg(C.Structure):
-    _fields_ = [("A", vp), ("B_bf16", vp), ("k_scale", vp), ("K", i64), ("lda", i64), ("ldb", i64), ("alpha", f32)]
+    _fields_ = [("A", vp), ("B_bf16", vp), ("k_scale", vp), ("K", i64), ("lda", i64), ("ldb", i64), ("alpha", f32), ("amax", vp)]
 
 
 class TnJob(C.Structure):
     _fields_ = [("dY", vp), ("codes", vp), ("dW", vp), ("lsq_s", vp), ("db", vp), ("baft", vp),
                 ("S", i64), ("Ktok", i64), ("M", i64), ("N", i64), ("lda", i64), ("ldb", i64),
-                ("gscale", f32), ("compute_db", C.c_int32)]
+                ("gscale", f32), ("compute_db", C.c_int32), ("amax", vp)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol of include/ofq_hip.h (tests/test_abi.py checks)
@@ -56,7 +56,7 @@ SIGNATURES = {
     "ofq_qgemm_i8_lsq_bwd_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_i8_lsq_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, vp, i64, vp, i64,
                                    vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
-    "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
+    "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp]),
     "ofq_qgemm_bf16s_nt_sk_ws_bytes": (sz, [i32]),
     "ofq_qgemm_bf16s_nt_sk_pays": (i32, [i64, i64, i64, i32]),
     "ofq_qgemm_bf16s_nt_sk": (i32, [C.POINTER(NtSeg), i32, vp, i32, i64, i64, i64, i32, vp, sz, vp]),
@@ -66,10 +66,12 @@ SIGNATURES = {
     "ofq_qgemm_bf16s_nt_lsq": (i32, [vp, vp, vp, f32, vp, vp, i64, f32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i64, i64, i64,
                                      i64, i64, vp, sz, vp]),
     "ofq_qgemm_bf16s_tn_ws_bytes": (sz, [i64, i64, i32]),
-    "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_tn_group_ws_bytes": (sz, [C.POINTER(TnJob), i32, i32]),
     "ofq_qgemm_bf16s_tn_group": (i32, [C.POINTER(TnJob), i32, i32, vp, sz, vp]),
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "ofq_codes_transpose_f16": (i32, [vp, vp, i64, i64, vp]),
+    "ofq_absmax_f32": (i32, [vp, i64, i64, i64, vp, vp]),
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_scores_plain_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
@@ -82,8 +84,8 @@ SIGNATURES = {
     "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dp_softmax_bwd_ws_bytes": (sz, [i64, i64, i64]),
     "ofq_qattn_dp_softmax_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, f32, f32, i32, vp, vp, vp, i64, i64, i64, i64, i64, vp, sz, vp]),
-    "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
-    "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp]),
+    "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp, vp]),
+    "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp, vp]),
     "ofq_rowdot_i8_multi": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "ofq_rowdot_f32_seg": (i32, [vp, vp, vp, i64, i32, i32, i64, vp]),
     "ofq_codes_transpose_i8": (i32, [vp, vp, i64, i64, i64, i64, vp]),

@@ -240,6 +240,42 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t st
   return 0;
 }
 
+// ---- max |x| of a gradient tensor, as the bits of a float in a device word (atomicMax over the bit patterns of |x|: they order
+// like the values, and a maximum does not depend on the order of its updates -- deterministic).  The two-plane fp16 form of the
+// backward GEMMs (csrc/qgemm.hip, split2_f16) takes its power-of-two scale from such a word; the backward kernels that PRODUCE a
+// gradient tensor write it as a by-product (their amax_out argument), this kernel serves producers that do not.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols4, int64_t ld,
+                                                     unsigned* __restrict__ amax) {
+  float m = 0.f;
+  unsigned nanbits = 0u;
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4);
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * c);
+    m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    if (!(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w)) nanbits = 0x7fc00000u;      // fmaxf drops NaNs
+  }
+  unsigned b = __float_as_uint(m) | nanbits;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned other = __shfl_xor(b, o, 64);
+    b = other > b ? other : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0u) atomicMax(amax, b);
+}
+extern "C" int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* amax, ofq_stream_t stream) {
+  if (!x || !amax || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || ld < cols || ((uintptr_t)x & 15) || cols >= (1ll << 31))
+    return OFQ_EINVAL;
+  const int64_t total = rows * (cols / 4);
+  int64_t blocks = ceil_div(total, 256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows, (int)(cols / 4), ld, (unsigned*)amax);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- KD loss of the shipped recipes, forward and gradients in one pass ------------------------------------------------------------
 // KDLossSoftandHard (src/quantization/utils.py:59-77, `--kd_hard_and_soft 1`):
 //   loss = mean_b( -sum_k softmax(t_b)[k] * log_softmax(d_b)[k] ) + mean_b( -log_softmax(c_b)[y_b] )

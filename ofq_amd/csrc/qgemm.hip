@@ -34,6 +34,7 @@ struct QGemmArgs {
   const float* cs;       // i8 linear: column scale [N]
   const float* r;        // i8 linear: offset term [N] (optional)
   const float* s;        // i8: LSQ step vector of the rows [S];  bf16s: k-scale ks (optional)
+  const unsigned* amax;  // bf16s, two-plane fp16 form: bits of an upper bound of max |A| (device word)
   // attention epilogues (i8) / extras (bf16s)
   const float* s2;       // second LSQ step vector (columns: qkx steps [N*nb1] / v steps [C])
   const float* u;        // scores: [nb0][M][nb1]      bf16s-nt: per-row addend [nb0][M][nb1]
@@ -700,11 +701,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------ bf16-split backward
-#ifdef OFQ_2PLANE_ABLATE              // timing experiment only (wrong numbers): the third bf16 plane is skipped in the wide k-steps
-#define NSM_ 2
-#else
-#define NSM_ 3
-#endif
 #define QBS_BK 32                      // k per stage
 #define QBS_LD (QBS_BK * 2 + 16)       // padded LDS row in bytes (bf16)
 
@@ -799,6 +795,79 @@ __device__ __forceinline__ unsigned valu_pack_hi16(float lo_elem, float hi_elem)
   return d;
 }
 
+// ---- two fp16 planes instead of three bf16 planes (round 5) -----------------------------------------------------------
+// x (fp32, pre-scaled by a power of two so that the largest |x| of the launch sits below 2^15) = hi + lo + err with
+// hi = rne_f16(x), lo = rne_f16(x - hi): x - hi is exact in fp32 (<= 13 significant bits), so |err| <= 2^-24 |x| as long
+// as lo stays a normal fp16 (|x| >= 2^-3 of the scaled range), and <= 2^-25 absolute below that (fp16 denormals are kept by
+// v_cvt_pk_f16_f32, v_fma_mix_f32 and v_mfma_f32_32x32x16_f16 alike: tools/probe/f16_mfma_probe.hip).  With the launch
+// maximum scaled to [2^14, 2^15) that is: fp32 precision for every element within 2^-17 of the maximum, an absolute
+// error of 2^-39 of the maximum below -- fp32-grade against the tensor scale, at two MFMAs per k-step instead of three.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16q mfma_16b(bf16x8 a, bf16x8 b, f32x16q c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void valu_mul2(float a0, float b0, float a1, float b1, float& x0, float& x1) {
+  asm("v_mul_f32 %0, %2, %3\n\tv_mul_f32 %1, %4, %5" : "=&v"(x0), "=v"(x1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+__device__ __forceinline__ unsigned valu_cvt_pk_f16(float x0, float x1) {                       // (lo half: x0)
+  unsigned d;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(x0), "v"(x1));
+  return d;
+}
+// r0 = x0 - f32(h.lo), r1 = x1 - f32(h.hi): one mixed-precision fma each, exact
+__device__ __forceinline__ void valu_resid2_f16(unsigned h, float x0, float x1, float& r0, float& r1) {
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r0), "=v"(r1) : "v"(h), "v"(x0), "v"(x1));
+}
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hi, unsigned& lo) {
+  float r0, r1;
+  hi = valu_cvt_pk_f16(x0, x1);
+  valu_resid2_f16(hi, x0, x1, r0, r1);
+  lo = valu_cvt_pk_f16(r0, r1);
+}
+// four int8 codes of one dword -> two packed fp16 pairs (exact): bytes ^ 0x80 are the codes + 128 as unsigned, 0x64xx is
+// the fp16 1024 + xx, minus 1152 gives the code.  c64 = 0x64646464 (a VGPR: v_perm_b32 may read one scalar operand only)
+__device__ __forceinline__ void valu_cvt4_i8_f16(unsigned w, unsigned c64, unsigned& d01, unsigned& d23) {
+  unsigned t;
+  asm("v_xor_b32 %2, 0x80808080, %3\n\t"
+      "v_perm_b32 %0, %4, %2, %5\n\t"
+      "v_perm_b32 %1, %4, %2, %6\n\t"
+      "v_pk_add_f16 %0, %0, %7\n\t"
+      "v_pk_add_f16 %1, %1, %7"
+      : "=&v"(d01), "=&v"(d23), "=&v"(t) : "v"(w), "v"(c64), "s"(0x04010400u), "s"(0x04030402u), "v"(0xE480E480u));
+}
+// The power of two that brings t (an upper bound of max |x| of the launch) into [2^14, 2^15), and its inverse; 1 for t = 0,
+// inf or nan (a non-finite gradient stays non-finite through the product, as it would in fp32)
+__device__ __forceinline__ void f16_plane_scale(float t, float& sE, float& inv_sE) {
+  const int ex = (int)((__float_as_uint(t) >> 23) & 0xffu) - 127;
+  int E = 14 - ex;
+  E = E < -100 ? -100 : (E > 100 ? 100 : E);
+  if (!(t > 0.f) || ((__float_as_uint(t) >> 23) & 0xffu) == 0xffu) E = 0;
+  sE = __uint_as_float((unsigned)(E + 127) << 23);
+  inv_sE = __uint_as_float((unsigned)(127 - E) << 23);
+}
+// max |v[0 .. n)| over an NT-thread workgroup, through NT / 64 floats of LDS at `red` (two barriers; every thread gets the result)
+template <int NT = 512>
+__device__ __forceinline__ float block_absmax(const float* __restrict__ v, int n, float* red, int tid) {
+  float m = 0.f;
+  for (int k = tid; k < n; k += NT) m = fmaxf(m, fabsf(v[k]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block512_absmax(const float* __restrict__ v, int n, float* red, int tid) {
+  return block_absmax<512>(v, n, red, tid);
+}
+
 __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
   // two small signed integers -> packed bf16 pair (exact for |v| <= 256)
   return (__float_as_uint((float)b0) >> 16) | (__float_as_uint((float)b1) & 0xffff0000u);
@@ -809,9 +878,10 @@ __device__ __forceinline__ unsigned i8x2_to_bf16x2(int b0, int b1) {
 // up to fp32 accumulation), PMAX = 3 the six leading ones (the dropped terms are <= 2^-24 of the product).  This is the
 // GEMM of the frozen fp32 KD teacher, whose weights are split once: 6 / 9 bf16 MFMAs per k-step amortise the split of the
 // activations that bounds the three-product kernels, at 16x the fp32-MFMA rate per instruction.
-template <int NSPLIT, bool B_I8, int NB = 1, int PMAX = 5>
+template <int NSPLIT, bool B_I8, int NB = 1, int PMAX = 5, bool F16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2, NB == 1 ? 3 : 2))) void qgemm_bf16s_nt_kernel(QGemmArgs p) {
   static_assert(NB == 1 || !B_I8, "plane-split B is an fp32 operand");
+  static_assert(!F16 || (NSPLIT == 2 && !B_I8 && NB == 1), "two fp16 planes: the linear layers' dX (B = fp16 codes)");
   constexpr int BM = 128, BN = 128;
   constexpr int PLANE = BM * QBS_LD;                 // bytes per bf16 plane of A
   constexpr int PLANE_B = BN * QBS_LD;
@@ -852,6 +922,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
   const int kqb = (tid & 3) * 8;
   // gload only issues the loads; scaling, masking, the int8 -> bf16 conversion and the split happen at the LDS store of
   // the next iteration, behind the MFMAs of this one (a value touched inside gload is waited for in front of them)
+  float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see qgemm_bf16s_nt_wide_sk_kernel)
+  if constexpr (F16) {
+    const float m = ksp ? block_absmax<256>(ksp, K, reinterpret_cast<float*>(smem), tid) : 1.f;
+    const float a = __uint_as_float(*p.amax);
+    f16_plane_scale(a == a ? a * m : a, sE, inv_sE);
+  }
   f32x4v ra[4], rks;
   i32x4 rb[NB][2];
   bool rkina = false, rkinb = false;
@@ -884,6 +960,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
     for (int e = 0; e < 4; ++e) {
       float t = ksp ? rks[e] : 1.f;
       if (B_I8 && p.gscale2 > 0.f) t = ofq_lsq_eff_scale(t, p.gscale2);      // raw LSQ step -> effective value
+      if constexpr (F16) t *= sE;
       ks[e] = rkina ? t : 0.f;
     }
 #pragma unroll
@@ -894,8 +971,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
       const f32x2v k01 = {ks[0] * z, ks[1] * z}, k23 = {ks[2] * z, ks[3] * z};
       const f32x2v a01 = {ra[i][0], ra[i][1]}, a23 = {ra[i][2], ra[i][3]};
       unsigned lo[NSPLIT], hi[NSPLIT];
-      split_pair_bf16<NSPLIT>(a01 * k01, lo);
-      split_pair_bf16<NSPLIT>(a23 * k23, hi);
+      if constexpr (F16) {
+        const f32x2v x01 = a01 * k01, x23 = a23 * k23;
+        split2_f16(x01[0], x01[1], lo[0], lo[1]);
+        split2_f16(x23[0], x23[1], hi[0], hi[1]);
+      } else {
+        split_pair_bf16<NSPLIT>(a01 * k01, lo);
+        split_pair_bf16<NSPLIT>(a23 * k23, hi);
+      }
 #pragma unroll
       for (int sidx = 0; sidx < NSPLIT; ++sidx) {
         uint2 w;
@@ -968,7 +1051,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[r][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma_16b<F16>(av[i], bv[r][j], acc[i][j]);
         }
       }
     }
@@ -1015,7 +1098,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (m < p.M && nok[j]) {
-            float v = acc[i][j][eb * 4 + ee] * p.alpha + uu;
+            float v = acc[i][j][eb * 4 + ee] * (F16 ? p.alpha * inv_sE : p.alpha) + uu;
             if (NB > 1) v += cbias[j];
             if (p.accumulate) v += old[ee][j];
             Cb[(int64_t)m * p.ldc + ncc[j]] = v;
@@ -1043,6 +1126,7 @@ struct QTnArgs {
   float* ws;             // [split][M][N]
   float* csum;           // [split][M] column sums of dY over this split's tokens (optional)
   const float* s;        // LSQ step vector [S]
+  const unsigned* amax;  // two-plane fp16 form (wide kernels): bits of an upper bound of max |A| (device word); NULL: three bf16 planes
   // direct (batched, un-split) mode: C written by the GEMM kernel itself
   float* C;              // NULL = split-K mode
   const float* baft;     // direct mode: + colsum_k(A)[m] * baft[n + b1 * sBf1]
@@ -1518,9 +1602,10 @@ __device__ unsigned long long g_tnw_dbg[8][8];     // [wave][phase] cycles of bl
 // The body of the wide dW kernel: workgroup `lid` of the problem `p` (tile = lid % ntiles, split index = lid / ntiles),
 // batch entry `gby`.  Two entry points share it: one problem per launch (qgemm_bf16s_tn_wide_kernel) and several
 // problems per launch (qgemm_bf16s_tn_wide_group_kernel, the deferred weight gradients of a transformer block).
-template <int NJ>
+// F16: two fp16 planes of dY * (token step * 2^E) against the codes widened to fp16 (see split2_f16): 8 NJ MFMAs per k-step.
+template <int NJ, bool F16 = false>
 __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, const int gby) {
-  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int BM = 128, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int LDA = QTN_LD;                 // 320 B: 4 consecutive k rows land on disjoint 64-B bank slots
   constexpr int LDB = BN * 2 + 64;            // same residue (64) modulo the 256-B bank line
   constexpr int PLANE = QTN_BK * LDA;
@@ -1535,6 +1620,15 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
   const int wm = wid >> 2, wn = wid & 3;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  // F16: the launch's power of two from the maximum word of dY and the largest token step (effective steps are the raw
+  // steps floored at 1e-5 and rounded once more: the margin covers it)
+  float sE = 1.f, inv_sE = 1.f;
+  const unsigned c64 = 0x64646464u;
+  if constexpr (F16) {
+    const float m = fmaxf(block512_absmax(p.s, p.S, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
+    const float am = __uint_as_float(*p.amax);
+    f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
+  }
   const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
   const int tps = (nkt + p.split - 1) / p.split;
   const int t_begin = sidx * tps, t_end = min(nkt, t_begin + tps);
@@ -1614,7 +1708,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
 #endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float sc = ofq_lsq_eff_scale(rs[sl][i], p.gscale);
+      const float sc = F16 ? ofq_lsq_eff_scale(rs[sl][i], p.gscale) * sE : ofq_lsq_eff_scale(rs[sl][i], p.gscale);
       const unsigned msk = rok[sl][i] ? 0xffffffffu : 0u;
       float4 v;
       v.x = __uint_as_float(__float_as_uint(ra[sl][i].x) & msk);
@@ -1624,8 +1718,14 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
       csacc.x += v.x; csacc.y += v.y; csacc.z += v.z; csacc.w += v.w;
       const f32x2v v01 = {v.x, v.y}, v23 = {v.z, v.w};
       unsigned lo[NS], hi[NS];
-      split_pair_bf16<NS>(v01 * sc, lo);
-      split_pair_bf16<NS>(v23 * sc, hi);
+      if constexpr (F16) {
+        const f32x2v x01 = v01 * sc, x23 = v23 * sc;
+        split2_f16(x01[0], x01[1], lo[0], lo[1]);
+        split2_f16(x23[0], x23[1], hi[0], hi[1]);
+      } else {
+        split_pair_bf16<NS>(v01 * sc, lo);
+        split_pair_bf16<NS>(v23 * sc, hi);
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
@@ -1644,10 +1744,16 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
       const unsigned bm = rbok[sl][i] ? 0xffffffffu : 0u;
       const int w0 = (int)(rb[sl][i][0] & bm), w1 = (int)(rb[sl][i][1] & bm);
       uint4 w;
+      if constexpr (F16) {
+        valu_cvt4_i8_f16((unsigned)w0, c64, w.x, w.y);
+        valu_cvt4_i8_f16((unsigned)w1, c64, w.z, w.w);
+        if (!rbok[sl][i]) w = make_uint4(0u, 0u, 0u, 0u);        // (the masked code bytes are 0, i.e. code 0: already zero)
+      } else {
       w.x = i8x2_to_bf16x2((int)(signed char)(w0 & 0xff), (int)(signed char)((w0 >> 8) & 0xff));
       w.y = i8x2_to_bf16x2((int)(signed char)((w0 >> 16) & 0xff), (int)(signed char)((w0 >> 24) & 0xff));
       w.z = i8x2_to_bf16x2((int)(signed char)(w1 & 0xff), (int)(signed char)((w1 >> 8) & 0xff));
       w.w = i8x2_to_bf16x2((int)(signed char)((w1 >> 16) & 0xff), (int)(signed char)((w1 >> 24) & 0xff));
+      }
       *reinterpret_cast<uint4*>(&sb[NS * PLANE + b_row[i] * LDB + b_col[i] * 2]) = w;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1686,7 +1792,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16b<F16>(av[q][i], bv[0][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
       if (q == 0) {
 #pragma unroll
@@ -1702,7 +1808,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16b<F16>(av[q][i], bv[1][j], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);       // the staging that follows waits on global loads: keep it behind the MFMAs
   };
 
@@ -1729,7 +1835,9 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
   // each pair, then three LDS stores; per code chunk: two convert+pack pieces (no masks: tokens past Ktok are zeroed
   // through sc, columns past N are never written) and a store; then the seven loads in consumption order.  The
   // fragments of the second 16-deep MFMA step are read behind the MFMAs that used up their registers.
-  constexpr int NM = 12 * NJ, NPA = 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;
+  // F16 piece list per dY row chunk (11 pieces): [step], per pair [x0, x1 = v * sc; column sums] [h = cvt_pk] [r0, r1] [l = cvt_pk],
+  // two plane stores
+  constexpr int NM = 4 * NS * NJ, NPA = F16 ? 11 : 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned offA[2] = {0u, 0u}, offB[NJ];
 #pragma unroll
@@ -1761,8 +1869,26 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
         if constexpr (r == 0) {
           asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));       // first touch: the wait for the slot's loads lands here
           const float e = valu_eff_scale(rs[sl][i], p.gscale);
-          sc = rok[sl][i] ? e : 0.f;
+          sc = rok[sl][i] ? (F16 ? e * sE : e) : 0.f;
           okf = rok[sl][i] ? 1.f : 0.f;
+        } else if constexpr (F16) {
+          if constexpr (r < 9) {
+            constexpr int pr = (r - 1) / 4, st = (r - 1) % 4, e = pr * 2;
+            if constexpr (st == 0) {
+              valu_mul2(ra[sl][i][e], sc, ra[sl][i][e + 1], sc, x_, r1_);
+              cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
+              cs[e + 1] = valu_fma(ra[sl][i][e + 1], okf, cs[e + 1]);
+            }
+            if constexpr (st == 1) (pr == 0 ? lo : hi)[0] = valu_cvt_pk_f16(x_, r1_);
+            if constexpr (st == 2) valu_resid2_f16((pr == 0 ? lo : hi)[0], x_, r1_, p0v[0], p0v[1]);
+            if constexpr (st == 3) (pr == 0 ? lo : hi)[1] = valu_cvt_pk_f16(p0v[0], p0v[1]);
+          } else {
+            constexpr int q = r - 9;
+            uint2 w;
+            w.x = lo[q];
+            w.y = hi[q];
+            *reinterpret_cast<uint2*>(&nxt[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+          }
         } else if constexpr (r < 15) {
           constexpr int pr = (r - 1) / 7, rr = (r - 1) % 7;
           if constexpr (rr < 6) {
@@ -1772,7 +1898,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
               cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
             }
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -1787,9 +1913,11 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
         constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
         if constexpr (r == 0) {
           asm volatile("" : "+v"(rb[sl][j]));
-          valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+          if constexpr (F16) valu_cvt4_i8_f16(rb[sl][j][0], c64, bw[0], bw[1]);
+          else valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
         } else if constexpr (r == 1) {
-          valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+          if constexpr (F16) valu_cvt4_i8_f16(rb[sl][j][1], c64, bw[2], bw[3]);
+          else valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
         } else {
           *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
         }
@@ -1811,11 +1939,11 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
     };
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
-      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      constexpr int ks = G / (2 * NS * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
       if constexpr (ks == 0) {                        // second-step fragments into the registers that have just been used up
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -1869,7 +1997,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m < p.M) W[(int64_t)m * p.N + n] = acc[i][j][e];
+          if (m < p.M) W[(int64_t)m * p.N + n] = F16 ? acc[i][j][e] * inv_sE : acc[i][j][e];
         }
     }
   }
@@ -1907,7 +2035,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
           const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           const int m = m0 + ml;
           if (m < p.Mstore) {
-            float v = acc[i][j][e];
+            float v = F16 ? acc[i][j][e] * inv_sE : acc[i][j][e];
             if (p.baft) v += red1[ml] * bf;
             Cb[(int64_t)m * p.ldc + n] = v;
           }
@@ -1916,11 +2044,11 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
   }
 }
 
-template <int NJ>
+template <int NJ, bool F16 = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
   int lid, gby;
   xcd_remap_grid(lid, gby);
-  tn_wide_body<NJ>(p, lid, gby);
+  tn_wide_body<NJ, F16>(p, lid, gby);
 }
 
 // ---- persistent direct-mode variant (attention dqkx: K = the 198 tokens of an image, 7 k-steps per tile) ---------------
@@ -1931,9 +2059,9 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_kernel(QTnArgs p) {
 // of the finished 128 x 384 tile) and nothing else -- no pipeline drain, no fresh memory round trip.  The one-tile-per-
 // workgroup launch of the same problem (1536 workgroups of 7 k-steps on 256 CUs: six rounds of prologue + 7 steps +
 // epilogue) took 178 us per DeiT-S block for 35 us of MFMA work.
-template <int NJ, bool STK = false>
+template <int NJ, bool STK = false, bool F16 = false>
 __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int chunk, const int b0, const int tpw) {
-  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int BM = 128, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int LDA = QTN_LD;
   constexpr int LDB = BN * 2 + 64;
   constexpr int PLANE = QTN_BK * LDA;
@@ -1953,6 +2081,13 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
   const int a_k = tid >> 5, a_t = (tid & 31) * 4;
   const int ldA = (int)p.lda, ldB = (int)p.ldb;
+  float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see tn_wide_body)
+  const unsigned c64 = 0x64646464u;
+  if constexpr (F16) {
+    const float m = fmaxf(block512_absmax(p.s, p.S, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
+    const float am = __uint_as_float(*p.amax);
+    f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
+  }
   int b_row[NJ], b_col[NJ];
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
@@ -2035,14 +2170,20 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
     for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rb[sl][j]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float sc = rok[sl][i] ? ofq_lsq_eff_scale(rs[sl][i], p.gscale) : 0.f;
+      const float sc = rok[sl][i] ? (F16 ? ofq_lsq_eff_scale(rs[sl][i], p.gscale) * sE : ofq_lsq_eff_scale(rs[sl][i], p.gscale)) : 0.f;
       const float okf = rok[sl][i] ? 1.f : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
       const f32x2v v01 = {ra[sl][i][0], ra[sl][i][1]}, v23 = {ra[sl][i][2], ra[sl][i][3]};
       unsigned lo[NS], hi[NS];
-      split_pair_bf16<NS>(v01 * sc, lo);
-      split_pair_bf16<NS>(v23 * sc, hi);
+      if constexpr (F16) {
+        const f32x2v x01 = v01 * sc, x23 = v23 * sc;
+        split2_f16(x01[0], x01[1], lo[0], lo[1]);
+        split2_f16(x23[0], x23[1], hi[0], hi[1]);
+      } else {
+        split_pair_bf16<NS>(v01 * sc, lo);
+        split_pair_bf16<NS>(v23 * sc, hi);
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
@@ -2055,8 +2196,13 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       unsigned bw[4];
-      valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
-      valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+      if constexpr (F16) {
+        valu_cvt4_i8_f16(rb[sl][j][0], c64, bw[0], bw[1]);
+        valu_cvt4_i8_f16(rb[sl][j][1], c64, bw[2], bw[3]);
+      } else {
+        valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+        valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+      }
       *reinterpret_cast<uint4*>(&sb[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -2076,7 +2222,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
 
   using Slot0 = std::integral_constant<int, 0>;
   using Slot1 = std::integral_constant<int, 1>;
-  constexpr int NM = 12 * NJ, NPA = 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;
+  constexpr int NM = 4 * NS * NJ, NPA = F16 ? 11 : 18, NPB = 3, NP = 2 * NPA + NPB * NJ + 2 + NJ;      // (piece lists: tn_wide_body)
   // one k-step of the stream: MFMA on `cur`, staging of the next step (register slot SLOT -> `nxt`), loads at the cursor
   // into the freed slot; the piece list is the one of tn_wide_body
   bool skip_i1 = false;           // this wave's second 32-row block lies outside the matrix in the tile being computed
@@ -2105,8 +2251,26 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
         if constexpr (r == 0) {
           asm volatile("" : "+v"(ra[sl][i]), "+v"(rs[sl][i]));
           const float e = valu_eff_scale(rs[sl][i], p.gscale);
-          sc = rok[sl][i] ? e : 0.f;
+          sc = rok[sl][i] ? (F16 ? e * sE : e) : 0.f;
           okf = rok[sl][i] ? 1.f : 0.f;
+        } else if constexpr (F16) {
+          if constexpr (r < 9) {
+            constexpr int pr = (r - 1) / 4, st = (r - 1) % 4, e = pr * 2;
+            if constexpr (st == 0) {
+              valu_mul2(ra[sl][i][e], sc, ra[sl][i][e + 1], sc, x_, r1_);
+              cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
+              cs[e + 1] = valu_fma(ra[sl][i][e + 1], okf, cs[e + 1]);
+            }
+            if constexpr (st == 1) (pr == 0 ? lo : hi)[0] = valu_cvt_pk_f16(x_, r1_);
+            if constexpr (st == 2) valu_resid2_f16((pr == 0 ? lo : hi)[0], x_, r1_, p0v[0], p0v[1]);
+            if constexpr (st == 3) (pr == 0 ? lo : hi)[1] = valu_cvt_pk_f16(p0v[0], p0v[1]);
+          } else {
+            constexpr int q = r - 9;
+            uint2 w;
+            w.x = lo[q];
+            w.y = hi[q];
+            *reinterpret_cast<uint2*>(&nxt[q * PLANE + (a_k + 16 * i) * LDA + a_t * 2]) = w;
+          }
         } else if constexpr (r < 15) {
           constexpr int pr = (r - 1) / 7, rr = (r - 1) % 7;
           if constexpr (rr < 6) {
@@ -2116,7 +2280,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
               cs[e] = valu_fma(ra[sl][i][e], okf, cs[e]);
             }
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -2131,9 +2295,11 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
         constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
         if constexpr (r == 0) {
           asm volatile("" : "+v"(rb[sl][j]));
-          valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
+          if constexpr (F16) valu_cvt4_i8_f16(rb[sl][j][0], c64, bw[0], bw[1]);
+          else valu_cvt4_i8_bf16(rb[sl][j][0], bw[0], bw[1]);
         } else if constexpr (r == 1) {
-          valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
+          if constexpr (F16) valu_cvt4_i8_f16(rb[sl][j][1], c64, bw[2], bw[3]);
+          else valu_cvt4_i8_bf16(rb[sl][j][1], bw[2], bw[3]);
         } else {
           *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
         }
@@ -2149,14 +2315,14 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
     };
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
-      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      constexpr int ks = G / (2 * NS * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
 #ifdef TNS_SKIP_PAD_BLOCKS
       if (i == 0 || !skip_i1)
 #endif
-        if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
+        if constexpr (j == NJ - 1) av[q][i] = tr_frag_ld<LDA>(sa + q * PLANE + 16 * LDA + i * 64);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -2173,6 +2339,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   // the finished tile q: C (+ colsum_k(A)[m] * baft[n]) to global memory, accumulators back to zero.  Nothing here may
   // wait on the vector-memory counter: the prefetch loads of the next steps are in flight (the offset vector comes from
   // LDS, where bf_reg -- loaded at the tile's first step -- was parked before the tile's last barrier).
+  auto aval = [&](float v) -> float { return F16 ? v * inv_sE : v; };      // an accumulator in the units of the product
   auto epilogue = [&](int q) {
     const int b1 = q / tpi, t = q - b1 * tpi;
     const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
@@ -2222,7 +2389,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int mr = (e & 3) + 8 * (e >> 2) + 4 * lhe;
-            Cb[mr * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            Cb[mr * ldc + nl] = p.baft ? aval(acc[i][j][e]) + rsum[e] * bf : aval(acc[i][j][e]);
             acc[i][j][e] = 0.f;
           }
         }
@@ -2237,7 +2404,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
           const float bf = p.baft ? sbf[nl] : 0.f;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            if (nok && off[e] >= 0) Cs[off[e] + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            if (nok && off[e] >= 0) Cs[off[e] + nl] = p.baft ? aval(acc[i][j][e]) + rsum[e] * bf : aval(acc[i][j][e]);
             acc[i][j][e] = 0.f;
           }
         }
@@ -2249,7 +2416,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhe;
-            Cs[ml * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            Cs[ml * ldc + nl] = p.baft ? aval(acc[i][j][e]) + rsum[e] * bf : aval(acc[i][j][e]);
             acc[i][j][e] = 0.f;
           }
         }
@@ -2263,7 +2430,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
           for (int e = 0; e < 16; ++e) {
             const int mr = (e & 3) + 8 * (e >> 2) + 4 * lhe;
             const int ml = wm * 64 + i * 32 + mr;
-            if (nok && mr < rv) Cs[ml * ldc + nl] = p.baft ? acc[i][j][e] + rsum[e] * bf : acc[i][j][e];
+            if (nok && mr < rv) Cs[ml * ldc + nl] = p.baft ? aval(acc[i][j][e]) + rsum[e] * bf : aval(acc[i][j][e]);
             acc[i][j][e] = 0.f;
           }
         }
@@ -2335,7 +2502,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   }
 }
 
-template <int NJ, bool STK = false>
+template <int NJ, bool STK = false, bool F16 = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_stream_kernel(QTnArgs p, int tpw, int stagger) {
   int chunk, b0;
   xcd_remap_grid(chunk, b0);
@@ -2348,7 +2515,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_stream_kernel(QTnArgs
     const int phase = (blockIdx.y * gridDim.x + blockIdx.x) % stagger;
     for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(70);           // ~2.2 us each (64 x 70 clocks)
   }
-  tn_wide_stream_body<NJ, STK>(p, chunk, b0, tpw);
+  tn_wide_stream_body<NJ, STK, F16>(p, chunk, b0, tpw);
 }
 
 // Several split-K problems in one launch.  The weight-gradient GEMMs of the linear layers have no consumer before the
@@ -2363,14 +2530,14 @@ struct QTnGroup {
   int wg_start[QTN_GROUP_MAX + 1];      // first workgroup of job j in the launch order (after the XCD remap)
   int njobs;
 };
-template <int NJ>
+template <int NJ, bool F16 = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_tn_wide_group_kernel(QTnGroup g) {
   int L, gby;
   xcd_remap_grid(L, gby);
   int j = 0;
 #pragma unroll
   for (int q = 1; q < QTN_GROUP_MAX; ++q) j += (q < g.njobs && L >= g.wg_start[q]) ? 1 : 0;
-  tn_wide_body<NJ>(g.job[j], L - g.wg_start[j], 0);
+  tn_wide_body<NJ, F16>(g.job[j], L - g.wg_start[j], 0);
 }
 
 // Split-K reduce, latency-parallel version (N % 4 == 0, N >= 256): the row-per-block kernel below walks the `split`
@@ -2502,7 +2669,7 @@ extern "C" size_t ofq_qgemm_bf16s_tn_ws_bytes(int64_t M, int64_t N, int split) {
 
 extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const float* lsq_s, int64_t S,
                                   float gscale, float* db, int compute_db, const float* baft, int64_t Ktok, int64_t M,
-                                  int64_t N, int64_t lda, int64_t ldb, int split, void* ws, size_t ws_bytes,
+                                  int64_t N, int64_t lda, int64_t ldb, int split, void* ws, size_t ws_bytes, const void* amax,
                                   ofq_stream_t stream) {
   if (!dY || !codes || !dW || !lsq_s || !ws || Ktok <= 0 || M <= 0 || N <= 0 || S <= 0 || split < 1) return OFQ_EINVAL;
   if ((M & 3) || (N & 15) || (lda & 3) || (ldb & 15) || !al16(dY) || !al16(codes) || Ktok >= (1ll << 30)) return OFQ_EINVAL;
@@ -2511,6 +2678,7 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   a.A = dY; a.B = codes; a.ws = (float*)ws; a.s = lsq_s; a.lda = lda; a.ldb = ldb;
   a.M = (int)M; a.N = (int)N; a.Ktok = (int)Ktok; a.S = (int)S; a.split = split;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.nb1 = 1;
+  a.amax = (const unsigned*)amax;        // (used by the wide kernels; the narrow one keeps its three bf16 planes)
   if (compute_db && !db) return OFQ_EINVAL;
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -2519,10 +2687,14 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
     // wide tile: one dY split feeds three (two when N is not a multiple of 384) 128-column blocks
     if (N % 384 == 0) {
       a.tiles_n = (int)(N / 384);
-      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+      const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * split));
+      if (amax) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_kernel<3, true>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_kernel<3, false>), grid, dim3(512), 0, st, a);
     } else {
       a.tiles_n = (int)ceil_div(N, 256);
-      hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<2>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(512), 0, st, a);
+      const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * split));
+      if (amax) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_kernel<2, true>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_kernel<2, false>), grid, dim3(512), 0, st, a);
     }
   } else {
     hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
@@ -2573,6 +2745,8 @@ extern "C" int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int s
     a.M = (int)q.M; a.N = (int)q.N; a.Ktok = (int)q.Ktok; a.S = (int)q.S; a.split = split;
     a.tiles_m = (int)ceil_div(q.M, 128); a.tiles_n = three ? (int)(q.N / 384) : (int)ceil_div(q.N, 256);
     a.gscale = q.gscale; a.nb1 = 1;
+    a.amax = (const unsigned*)q.amax;
+    if ((q.amax != nullptr) != (jobs[0].amax != nullptr)) return OFQ_EINVAL;      // one operand form per launch
     a.csum = q.compute_db ? wsf + (size_t)split * q.M * q.N : nullptr;
     g.wg_start[j] = wg;
     wg += a.tiles_m * a.tiles_n * split;
@@ -2585,10 +2759,14 @@ extern "C" int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int s
   g.wg_start[njobs] = wg;
   g.njobs = r.njobs = njobs;
   hipStream_t st = (hipStream_t)stream;
-  if (three)
-    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_group_kernel<3>, dim3((unsigned)wg), dim3(512), 0, st, g);
-  else
-    hipLaunchKernelGGL(qgemm_bf16s_tn_wide_group_kernel<2>, dim3((unsigned)wg), dim3(512), 0, st, g);
+  const bool f16 = jobs[0].amax != nullptr;
+  if (three) {
+    if (f16) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_group_kernel<3, true>), dim3((unsigned)wg), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_group_kernel<3, false>), dim3((unsigned)wg), dim3(512), 0, st, g);
+  } else {
+    if (f16) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_group_kernel<2, true>), dim3((unsigned)wg), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_group_kernel<2, false>), dim3((unsigned)wg), dim3(512), 0, st, g);
+  }
   OFQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(qgemm_tn_reduce4_group_kernel, dim3((unsigned)blk), dim3(256), 0, st, r);
   OFQ_LAUNCH_CHECK();
@@ -2603,6 +2781,7 @@ extern "C" int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int s
 struct QNnArgs {
   const float* A; const int8_t* B; float* C;
   const float* s;        // LSQ steps of qkx: index k*ks_stride + kb
+  const unsigned* amax;  // wide kernel, two-plane fp16 form: bits of an upper bound of max |A| over the columns that are read
   int64_t lda, ldb, ldc, sA0, sB0, sC0, sAk, sBk;
   int M, N, K, nkb, ks_stride, tiles_m, tiles_n, accumulate;
   float gscale;
@@ -2792,7 +2971,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ------------------------------------------------------------------------------------------------ helpers
 // codes^T as bf16: in int8 [R][Cc] -> out bf16 [Cc][R]   (weights only: a few MB per step)
 __global__ __launch_bounds__(256) void codes_transpose_bf16_kernel(const int8_t* __restrict__ in, unsigned short* __restrict__ out,
-                                                                   int R, int Cc) {
+                                                                   int R, int Cc, int f16) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -2803,7 +2982,10 @@ __global__ __launch_bounds__(256) void codes_transpose_bf16_kernel(const int8_t*
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < Cc && r < R) out[(int64_t)c * R + r] = (unsigned short)(__float_as_uint(tile[tx][i]) >> 16);
+    if (c < Cc && r < R) {
+      const _Float16 h = (_Float16)tile[tx][i];
+      out[(int64_t)c * R + r] = f16 ? __builtin_bit_cast(unsigned short, h) : (unsigned short)(__float_as_uint(tile[tx][i]) >> 16);
+    }
   }
 }
 
@@ -2894,7 +3076,15 @@ __global__ __launch_bounds__(256) void rowdot_i8_v16_kernel(const int8_t* __rest
 extern "C" int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream) {
   if (!codes || !out_bf16 || rows <= 0 || cols <= 0) return OFQ_EINVAL;
   hipLaunchKernelGGL(codes_transpose_bf16_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
-                     0, (hipStream_t)stream, codes, (unsigned short*)out_bf16, (int)rows, (int)cols);
+                     0, (hipStream_t)stream, codes, (unsigned short*)out_bf16, (int)rows, (int)cols, 0);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+// the same, codes as FP16 (B operand of the two-plane form of the backward GEMMs)
+extern "C" int ofq_codes_transpose_f16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream) {
+  if (!codes || !out_bf16 || rows <= 0 || cols <= 0) return OFQ_EINVAL;
+  hipLaunchKernelGGL(codes_transpose_bf16_kernel, dim3((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), dim3(256),
+                     0, (hipStream_t)stream, codes, (unsigned short*)out_bf16, (int)rows, (int)cols, 1);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -3032,9 +3222,10 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
 // element) applied to the dX tile while it is still in registers: dx, the per-row step-gradient partials [M][tiles_n]
 // and the per-column offset-gradient partials [tiles_m][2][N] are written instead of dX, so dX never travels to HBM and
 // back (8 of the 16 B/element of the unfused pair).
-template <int NJ, bool LSQ>
+template <int NJ, bool LSQ, bool F16 = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
-  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  static_assert(!(LSQ && F16), "the fused LSQ epilogue exists for the three-plane form only");
+  constexpr int BM = 128, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int PLANE = BM * QBS_LD;
   constexpr int STAGE = NS * PLANE + BN * QBS_LD;
   constexpr int NB = NJ;                               // 16-byte chunks of the weight tile per thread (BN*4/512)
@@ -3072,6 +3263,12 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     pb[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + (tid & 3) * 8;
   }
   const int kqa = (tid & 7) * 4, kqb = (tid & 3) * 8;
+  float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see qgemm_bf16s_nt_wide_sk_kernel)
+  if constexpr (F16) {
+    const float m = p.s ? block512_absmax(p.s, K, reinterpret_cast<float*>(smem), tid) : 1.f;
+    const float a = __uint_as_float(*p.amax);
+    f16_plane_scale(a == a ? a * m : a, sE, inv_sE);
+  }
   f32x4v ra[2][2], rks[2];
   i32x4 rb[NB];                                         // weights are L2-resident: one step of prefetch is enough
   bool rka[2], rkb;
@@ -3100,6 +3297,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
     f32x4v ks = rks[sl];
     if (!p.s) ks = f32x4v{1.f, 1.f, 1.f, 1.f};
+    if constexpr (F16) ks = ks * sE;
     if (!rka[sl]) ks = f32x4v{0.f, 0.f, 0.f, 0.f};           // beyond K: zero pieces (register select, the loads are done)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -3108,8 +3306,14 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
       const f32x2v k01 = {ks[0] * z, ks[1] * z}, k23 = {ks[2] * z, ks[3] * z};
       const f32x2v a01 = {ra[sl][i][0], ra[sl][i][1]}, a23 = {ra[sl][i][2], ra[sl][i][3]};
       unsigned lo[NS], hi[NS];
-      split_pair_bf16<NS>(a01 * k01, lo);
-      split_pair_bf16<NS>(a23 * k23, hi);
+      if constexpr (F16) {
+        const f32x2v x01 = a01 * k01, x23 = a23 * k23;
+        split2_f16(x01[0], x01[1], lo[0], lo[1]);
+        split2_f16(x23[0], x23[1], hi[0], hi[1]);
+      } else {
+        split_pair_bf16<NS>(a01 * k01, lo);
+        split_pair_bf16<NS>(a23 * k23, hi);
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 w;
@@ -3161,7 +3365,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks][q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_16b<F16>(av[ks][q][i], bv[ks][j], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);       // the staging below consumes global loads: keep its waits behind the MFMAs
   };
 
@@ -3190,7 +3394,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   // piece packing the three planes of the pair -- and three LDS stores; then the weight chunks (store each, no masks:
   // rows past N only feed columns that are never written, k past K is zeroed through ks), then the six loads in
   // consumption order.
-  constexpr int NM = 12 * NJ, NPA = 17, NP = 2 * NPA + NB + NB + 3;
+  constexpr int NM = 4 * NS * NJ, NPA = F16 ? 10 : 17, NP = 2 * NPA + NB + NB + 3;
   auto step = [&](int kt, const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
     const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
@@ -3216,15 +3420,30 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
         if constexpr (r == 0 && i == 0) {          // first touch of the slot: the wait for its loads lands here
           asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ksv[e] = rka[sl] ? (p.s ? rks[sl][e] : 1.f) : 0.f;
+          for (int e = 0; e < 4; ++e) ksv[e] = rka[sl] ? (p.s ? rks[sl][e] : 1.f) * (F16 ? sE : 1.f) : 0.f;
         }
-        if constexpr (r < 14) {
+        if constexpr (F16) {
+          if constexpr (r < 8) {
+            constexpr int pr = r / 4, st = r % 4, e = pr * 2;
+            if constexpr (st == 0) valu_mul2(ra[sl][i][e], ksv[e], ra[sl][i][e + 1], ksv[e + 1], x_, r1_);
+            if constexpr (st == 1) (pr == 0 ? lo : hi)[0] = valu_cvt_pk_f16(x_, r1_);
+            if constexpr (st == 2) valu_resid2_f16((pr == 0 ? lo : hi)[0], x_, r1_, p0v[0], p0v[1]);
+            if constexpr (st == 3) (pr == 0 ? lo : hi)[1] = valu_cvt_pk_f16(p0v[0], p0v[1]);
+          } else {
+            constexpr int q = r - 8;
+            const int row = (tid + 512 * i) >> 3;
+            uint2 w;
+            w.x = lo[q];
+            w.y = hi[q];
+            *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = w;
+          }
+        } else if constexpr (r < 14) {
           constexpr int pr = r / 7, rr = r % 7;
           if constexpr (rr < 6) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -3254,14 +3473,13 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
         }
       }
     };
-    static_assert(NS == 3, "three planes");
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
-      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      constexpr int ks = G / (2 * NS * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = *reinterpret_cast<const bf16x8*>(b + G * 32 * QBS_LD + 32);
-        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
 #ifndef NTW_X_NO_STAGING
@@ -3291,6 +3509,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   }
 
   if constexpr (!LSQ) {
+    const float alpha_e = p.alpha * inv_sE;
     // interior tiles (every tile of the DeiT shapes): uniform tile base + one 32-bit lane offset per access, no
     // per-element bounds checks (each one is an exec-mask branch around a single store)
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
@@ -3314,7 +3533,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
           for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-              const float v = acc[i][j][eb * 4 + ee] * p.alpha;
+              const float v = acc[i][j][eb * 4 + ee] * alpha_e;
               Cs[mlb + ee * ldc + j * 32] = p.accumulate ? v + old[ee][j] : v;
             }
         }
@@ -3328,7 +3547,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[i][j][e] * p.alpha;
+            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[i][j][e] * alpha_e;
           }
       }
     } else {
@@ -3358,7 +3577,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
             const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * p.alpha + old[ee][j];
+              if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * alpha_e + old[ee][j];
           }
         }
     }
@@ -3446,13 +3665,13 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 
 extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha,
                                   int accumulate, int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                                  int64_t ldc, ofq_stream_t stream) {
+                                  int64_t ldc, const void* amax, ofq_stream_t stream) {
   if (!A || !B_bf16 || !C || M <= 0 || N <= 0 || K <= 0) return OFQ_EINVAL;
   if ((K & 7) || (lda & 3) || (ldb & 7) || !al16(A) || !al16(B_bf16) || (k_scale && !al16(k_scale)) || M >= (1ll << 30) ||
-      N >= (1ll << 30) || (nsplit != 2 && nsplit != 3))
+      N >= (1ll << 30) || (nsplit != 2 && nsplit != 3) || (amax && nsplit != 2))
     return OFQ_EINVAL;
   QGemmArgs a = {};
-  a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale;
+  a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale; a.amax = (const unsigned*)amax;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   static const bool narrow_only = getenv("OFQ_NT_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
@@ -3460,16 +3679,22 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
   // few rows (late Swin stages): 128-column tiles of the 4-wave kernel give 2-3x more workgroups, which matters more than
   // the shared split (measured: 185 vs 207 us at M=6272, N=768, K=3072; an 8-wave 128x128 variant lost to it as well)
   const bool too_few = (int64_t)a.tiles_m * ceil_div(N, 128 * nj) < 160 && (int64_t)a.tiles_m * a.tiles_n >= 192;
-  if (nsplit == 3 && N > 128 && !narrow_only && !too_few) {      // wide tiles: the dY panel is split once per 384 (256) columns
+  if ((nsplit == 3 || amax) && N > 128 && !narrow_only && !too_few) {      // wide tiles: the dY panel is split once per 384 (256) columns
     a.tiles_n = (int)ceil_div(N, 128 * nj);
     dim3 gridw((unsigned)(a.tiles_m * a.tiles_n));
-    if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    if (amax) {
+      if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, false, true>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, false, true>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    } else {
+      if (nj == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, false>), gridw, dim3(512), 0, (hipStream_t)stream, a);
+    }
     OFQ_LAUNCH_CHECK();
     return 0;
   }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-  if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (amax) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false, 1, 5, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
@@ -3495,6 +3720,7 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
 // spin is bounded: a timeout raises the error word behind the flags and the kernel finishes with wrong numbers, not a hang.
 struct QNtSkSeg {
   const float* A; const unsigned short* B; const float* s;
+  const unsigned* amax;      // F16 form: bits of (an upper bound of) max |A| of this segment (device scalar)
   unsigned lda4, ldb2;       // row pitch of A / B in bytes
   int nkt;                   // k-steps of QBS_BK in this segment
   float alpha;
@@ -3508,9 +3734,11 @@ struct QNtSkArgs {
 };
 #define QNT_SK_SPIN_LIMIT (1 << 21)
 
-template <int NJ, int NSEG>
+// F16: two fp16 planes of the scaled panel (see split2_f16) against fp16 weight codes instead of three bf16 planes against
+// bf16 codes: 8 NJ MFMAs, 6 VALU per element pair and two plane stores per k-step instead of 12 NJ, 13 and three.
+template <int NJ, int NSEG, bool F16>
 __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p) {
-  constexpr int BM = 128, BN = 128 * NJ, NS = 3;
+  constexpr int BM = 128, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int PLANE = BM * QBS_LD;
   constexpr int STAGE = NS * PLANE + BN * QBS_LD;
   constexpr int NB = NJ;
@@ -3526,6 +3754,20 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
   const unsigned u_end = 2u * (unsigned)((p.units * (unsigned long long)(w + 1)) / (unsigned long long)G);
   const unsigned kqa4 = (unsigned)(tid & 7) * 16u, kqb2 = (unsigned)(tid & 3) * 16u;   // byte offset of this lane's chunk in a k-step
   const int kqa = (tid & 7) * 4, kqb = (tid & 3) * 8;
+  // F16: one power of two for the launch, from the segments' amax words and the largest k-scale (all workgroups compute
+  // the same value from the same inputs: the partial tiles of a cut tile are in the same units)
+  float sE = 1.f, inv_sE = 1.f;
+  if constexpr (F16) {
+    float t = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+      const float m = p.seg[sg].s ? block512_absmax(p.seg[sg].s, p.seg[sg].nkt * QBS_BK, reinterpret_cast<float*>(smem), tid) : 1.f;
+      const float a = __uint_as_float(*p.seg[sg].amax);
+      t = fmaxf(t, a * m * (NSEG > 1 ? fabsf(p.seg[sg].alpha) : 1.f));
+      if (!(a == a)) t = a;                                  // a NaN bound stays one
+    }
+    f16_plane_scale(t, sE, inv_sE);
+  }
 
   f32x16q acc[2][NJ];
   f32x4v ra[2][2], rks[2];
@@ -3620,6 +3862,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
     for (int e = 0; e < 4; ++e) {
       float v = rhs[sl] ? rks[sl][e] : 1.f;
       if constexpr (NSEG > 1) v *= rkm[sl];
+      if constexpr (F16) v *= sE;
       ksv[e] = v;
     }
   };
@@ -3634,8 +3877,14 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
       const f32x2v k01 = {ksv[0], ksv[1]}, k23 = {ksv[2], ksv[3]};
       const f32x2v a01 = {ra[sl][i][0], ra[sl][i][1]}, a23 = {ra[sl][i][2], ra[sl][i][3]};
       unsigned lo[NS], hi[NS];
-      split_pair_bf16<NS>(a01 * k01, lo);
-      split_pair_bf16<NS>(a23 * k23, hi);
+      if constexpr (F16) {
+        const f32x2v x01 = a01 * k01, x23 = a23 * k23;
+        split2_f16(x01[0], x01[1], lo[0], lo[1]);
+        split2_f16(x23[0], x23[1], hi[0], hi[1]);
+      } else {
+        split_pair_bf16<NS>(a01 * k01, lo);
+        split_pair_bf16<NS>(a23 * k23, hi);
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         uint2 wv;
@@ -3658,7 +3907,9 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
   // one k-step of the stream: the MFMAs of the step staged in `cur`; behind them, in small pieces, the staging of the next
   // step (register slot SLOT -> `nxt`), the weight loads at the B cursor (two steps ahead) and the dY-panel loads at the A
   // cursor (three ahead).  Same piece list as qgemm_bf16s_nt_wide_kernel.
-  constexpr int NM = 12 * NJ, NPA = 17, NP = 2 * NPA + NB + NB + 3;
+  // F16 piece list per row chunk (10 pieces): per pair [x0 = a0*ks0, x1 = a1*ks1] [h = cvt_pk(x0, x1)] [r0 = x0 - h.lo, r1 = x1 - h.hi]
+  // [l = cvt_pk(r0, r1)], then the two plane stores
+  constexpr int NM = 4 * NS * NJ, NPA = F16 ? 10 : 17, NP = 2 * NPA + NB + NB + 3;
   auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     constexpr int sl = decltype(SLOT)::value;
     const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
@@ -3688,13 +3939,28 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
           asm volatile("" : "+v"(rks[sl]), "+v"(ra[sl][0]), "+v"(ra[sl][1]));
           slot_scale(SLOT, ksv);
         }
-        if constexpr (r < 14) {
+        if constexpr (F16) {
+          if constexpr (r < 8) {
+            constexpr int pr = r / 4, st = r % 4, e = pr * 2;
+            if constexpr (st == 0) valu_mul2(ra[sl][i][e], ksv[e], ra[sl][i][e + 1], ksv[e + 1], x_, r1_);
+            if constexpr (st == 1) (pr == 0 ? lo : hi)[0] = valu_cvt_pk_f16(x_, r1_);
+            if constexpr (st == 2) valu_resid2_f16((pr == 0 ? lo : hi)[0], x_, r1_, p0v[0], p0v[1]);
+            if constexpr (st == 3) (pr == 0 ? lo : hi)[1] = valu_cvt_pk_f16(p0v[0], p0v[1]);
+          } else {
+            constexpr int q = r - 8;
+            const int row = (tid + 512 * i) >> 3;
+            uint2 wv;
+            wv.x = lo[q];
+            wv.y = hi[q];
+            *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = wv;
+          }
+        } else if constexpr (r < 14) {
           constexpr int pr = r / 7, rr = r % 7;
           if constexpr (rr < 6) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][i][e], ksv[e], x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -3725,14 +3991,13 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
         }
       }
     };
-    static_assert(NS == 3, "three planes");
     static_for<NM>([&](auto G_) {
       constexpr int Gi = decltype(G_)::value;
-      constexpr int ks = Gi / (6 * NJ), q = (Gi / (2 * NJ)) % NS, i = (Gi / NJ) % 2, j = Gi % NJ;
-      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      constexpr int ks = Gi / (2 * NS * NJ), q = (Gi / (2 * NJ)) % NS, i = (Gi / NJ) % 2, j = Gi % NJ;
+      acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
       if constexpr (ks == 0) {
         if constexpr (Gi < NJ) bv[1][Gi] = *reinterpret_cast<const bf16x8*>(b + Gi * 32 * QBS_LD + 32);
-        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = Gi * NP / NM, P1 = (Gi + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
@@ -3845,7 +4110,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
       }
       if (ke != nkt) NTSK_STAMP(4);
       // ---- store the finished tile ----
-      const float alpha = NSEG > 1 ? 1.f : p.seg[0].alpha;
+      const float alpha = (NSEG > 1 ? 1.f : p.seg[0].alpha) * inv_sE;
       const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
       if (interior) {
         float* Cs = p.C + (int64_t)m0 * p.ldc + n0;
@@ -3970,7 +4235,8 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
         !al16(sg.A) || !al16(sg.B_bf16) ||
         (sg.k_scale && !al16(sg.k_scale)) || M * sg.lda * 4 >= (1ll << 32) || N * sg.ldb * 2 >= (1ll << 32))
       return OFQ_EINVAL;
-    a.seg[i].A = sg.A; a.seg[i].B = (const unsigned short*)sg.B_bf16; a.seg[i].s = sg.k_scale;
+    a.seg[i].A = sg.A; a.seg[i].B = (const unsigned short*)sg.B_bf16; a.seg[i].s = sg.k_scale; a.seg[i].amax = (const unsigned*)sg.amax;
+    if ((sg.amax != nullptr) != (segs[0].amax != nullptr)) return OFQ_EINVAL;      // one operand format per launch
     a.seg[i].lda4 = (unsigned)(sg.lda * 4); a.seg[i].ldb2 = (unsigned)(sg.ldb * 2);
     a.seg[i].nkt = (int)(sg.K / QBS_BK); a.seg[i].alpha = sg.alpha;
     nkt += a.seg[i].nkt;
@@ -3986,12 +4252,23 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
   if ((unsigned long long)g > a.units) g = (int)a.units;
   const dim3 grid((unsigned)g), block(512);
   hipStream_t st = (hipStream_t)stream;
+  const bool f16 = segs[0].amax != nullptr;        // two fp16 planes against fp16 codes (B_bf16 then holds fp16 values)
   if (nj == 3) {
-    if (nseg == 1) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 2>), grid, block, 0, st, a);
+    if (nseg == 1) {
+      if (f16) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 1, false>), grid, block, 0, st, a);
+    } else {
+      if (f16) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 2, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<3, 2, false>), grid, block, 0, st, a);
+    }
   } else {
-    if (nseg == 1) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 2>), grid, block, 0, st, a);
+    if (nseg == 1) {
+      if (f16) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 1, false>), grid, block, 0, st, a);
+    } else {
+      if (f16) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 2, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_sk_kernel<2, 2, false>), grid, block, 0, st, a);
+    }
   }
   OFQ_LAUNCH_CHECK();
   return 0;
@@ -4173,7 +4450,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3x3_wide_kernel(QGemmArgs p) {
             constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
             if constexpr (st == 0) valu_mul_hi16(ra[sl][e], z_, x_, p0v[el]);
             if constexpr (st == 1) valu_sub_hi16(x_, p0v[el], r1_, p1v[el]);
-            if constexpr (st == 2 && NSM_ == 3) { r2v[el] = valu_sub(r1_, p1v[el]); }
+            if constexpr (st == 2) { r2v[el] = valu_sub(r1_, p1v[el]); }
           } else {
             valu_pack3_hi16(p0v, p1v, r2v, pr == 0 ? lo : hi);
           }
@@ -4856,9 +5133,11 @@ extern "C" int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* 
 }
 // dqkx[b,m,h,c] = sum_n dS[b,h,n,m] * (ax[n]*qx[b,n,c] + bax[c])
 extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float* dqkx, const float* sx, float gscale_x,
-                                    const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
+                                    const float* bax, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, const void* amax,
+                                    ofq_stream_t stream) {
   if (!dS || !xcodes || !dqkx || !sx || B <= 0 || H <= 0 || N <= 0 || (C & 15) || (ldS & 3) || ldS < N) return OFQ_EINVAL;
   QTnArgs a = {};
+  a.amax = (const unsigned*)amax;      // two-plane fp16 form of the wide kernels (C % 384 == 0); elsewhere three bf16 planes
   a.A = dS; a.B = xcodes; a.C = dqkx; a.s = sx; a.baft = bax; a.lda = ldS; a.ldb = C; a.ldc = H * C;
   a.sA0 = H * N * ldS; a.sA1 = N * ldS; a.sB0 = N * C; a.sB1 = 0; a.sC0 = N * H * C; a.sC1 = C;
   a.M = (int)ldS; a.N = (int)C; a.Ktok = (int)N; a.S = (int)N; a.split = 1; a.nb1 = (int)H;
@@ -4897,15 +5176,22 @@ extern "C" int ofq_qattn_dqkx_bf16s(const float* dS, const int8_t* xcodes, float
       while (T % tpw) --tpw;                                                  // equal chunks
       int stagger = 0;                                                      // measured: 121 us without, 149 us with a 6-phase shift
       if (const char* e = getenv("OFQ_TN_STREAM_STAGGER")) stagger = atoi(e);  // A/B switch
-      if (stacked)
-        hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, true>), dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
-                           (hipStream_t)stream, a, (int)tpw, stagger);
-      else
-        hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, false>), dim3((unsigned)(T / tpw), (unsigned)B), dim3(512), 0,
-                           (hipStream_t)stream, a, (int)tpw, stagger);
+      const dim3 grid((unsigned)(T / tpw), (unsigned)B);
+      hipStream_t st = (hipStream_t)stream;
+      if (stacked) {
+        if (amax) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, true, true>), grid, dim3(512), 0, st, a, (int)tpw, stagger);
+        else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, true, false>), grid, dim3(512), 0, st, a, (int)tpw, stagger);
+      } else {
+        if (amax) hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, false, true>), grid, dim3(512), 0, st, a, (int)tpw, stagger);
+        else hipLaunchKernelGGL((qgemm_bf16s_tn_wide_stream_kernel<3, false, false>), grid, dim3(512), 0, st, a, (int)tpw, stagger);
+      }
       OFQ_LAUNCH_CHECK();
       return 0;
     }
+    if (amax)
+      hipLaunchKernelGGL((qgemm_bf16s_tn_wide_kernel<3, true>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(512), 0,
+                         (hipStream_t)stream, a);
+    else
     hipLaunchKernelGGL(qgemm_bf16s_tn_wide_kernel<3>, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)(B * H)), dim3(512), 0,
                        (hipStream_t)stream, a);
     OFQ_LAUNCH_CHECK();
@@ -4958,8 +5244,9 @@ extern "C" int ofq_qattn_dk_plain_bf16s(const float* dS, const int8_t* qcodes, f
 // k index runs over (head, key token); double-buffered LDS, two register slots, staging interleaved into the MFMA
 // stream (see static_for).  k past the token count is zeroed through the per-k step (v_mul_legacy_f32: 0 * x = 0 even
 // for the uninitialised pad columns of dS) and through zero codes.
+template <bool F16>
 __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
-  constexpr int BM = 128, NJ = 3, BN = 128 * NJ, NS = 3;
+  constexpr int BM = 128, NJ = 3, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int PLANE = BM * QBS_LD;                // [row][k] bf16, 80 B rows
   constexpr int LDB = BN * 2 + 64;                  // [k][c] bf16
   constexpr int STAGE = NS * PLANE + QBS_BK * LDB;
@@ -4978,6 +5265,13 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
   const int T = nkt * p.nkb;
 
   const int kqa = (tid & 7) * 4;
+  float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see tn_wide_body); steps of every (key, head)
+  const unsigned c64 = 0x64646464u;
+  if constexpr (F16) {
+    const float m = fmaxf(block512_absmax(p.s, K * p.ks_stride, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
+    const float am = __uint_as_float(*p.amax);
+    f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
+  }
   unsigned rowoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) rowoff[i] = (unsigned)(min(m0 + ((tid + 512 * i) >> 3), p.M - 1) * (int)p.lda);
@@ -5023,7 +5317,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
   // pieces of the staging of one slot (shared by the prologue, which runs them back to back, and the k-step)
   float ksv[4], x_ = 0.f, r1_ = 0.f, p0v[2], p1v[2], r2v[2];
   unsigned lo[NS], hi[NS], bw[4];
-  constexpr int NPA = 17, NPB = 3, NPS = 2 * NPA + NPB * NJ;      // staging pieces; the k-step appends one load piece
+  constexpr int NPA = F16 ? 10 : 17, NPB = 3, NPS = 2 * NPA + NPB * NJ;      // staging pieces; the k-step appends one load piece
   auto stage_piece = [&](unsigned char* nxt, auto SLOT, auto P_) {
     constexpr int sl = decltype(SLOT)::value;
     constexpr int P = decltype(P_)::value;
@@ -5034,10 +5328,27 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float t = valu_eff_scale(rsv[sl][e], p.gscale);
-          ksv[e] = e < rkn[sl] ? t : 0.f;
+          ksv[e] = e < rkn[sl] ? (F16 ? t * sE : t) : 0.f;
         }
       }
-      if constexpr (r < 14) {
+      if constexpr (F16) {
+        if constexpr (r < 8) {
+          constexpr int pr = r / 4, st = r % 4, e = pr * 2;
+          if constexpr (st == 0)      // (legacy multiply: 0 * x = 0 also for the never-written pad columns of dS)
+            asm("v_mul_legacy_f32 %0, %2, %3\n\tv_mul_legacy_f32 %1, %4, %5" : "=&v"(x_), "=v"(r1_)
+                : "v"(ra[sl][i][e]), "v"(ksv[e]), "v"(ra[sl][i][e + 1]), "v"(ksv[e + 1]));
+          if constexpr (st == 1) (pr == 0 ? lo : hi)[0] = valu_cvt_pk_f16(x_, r1_);
+          if constexpr (st == 2) valu_resid2_f16((pr == 0 ? lo : hi)[0], x_, r1_, p0v[0], p0v[1]);
+          if constexpr (st == 3) (pr == 0 ? lo : hi)[1] = valu_cvt_pk_f16(p0v[0], p0v[1]);
+        } else {
+          constexpr int q = r - 8;
+          const int row = (tid + 512 * i) >> 3;
+          uint2 w;
+          w.x = lo[q];
+          w.y = hi[q];
+          *reinterpret_cast<uint2*>(&nxt[q * PLANE + row * QBS_LD + kqa * 2]) = w;
+        }
+      } else if constexpr (r < 14) {
         constexpr int pr = r / 7, rr = r % 7;
         if constexpr (rr < 6) {
           constexpr int el = rr / 3, st = rr % 3, e = pr * 2 + el;
@@ -5060,9 +5371,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
       constexpr int j = (P - 2 * NPA) / NPB, r = (P - 2 * NPA) % NPB;
       if constexpr (r == 0) {
         asm volatile("" : "+v"(rb[sl][j]));
-        valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][0] : 0u, bw[0], bw[1]);
+        if constexpr (F16) valu_cvt4_i8_f16(rbk[sl][j] ? rb[sl][j][0] : 0u, c64, bw[0], bw[1]);
+        else valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][0] : 0u, bw[0], bw[1]);
       } else if constexpr (r == 1) {
-        valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][1] : 0u, bw[2], bw[3]);
+        if constexpr (F16) valu_cvt4_i8_f16(rbk[sl][j] ? rb[sl][j][1] : 0u, c64, bw[2], bw[3]);
+        else valu_cvt4_i8_bf16(rbk[sl][j] ? rb[sl][j][1] : 0u, bw[2], bw[3]);
       } else {
         *reinterpret_cast<uint4*>(&nxt[NS * PLANE + b_row[j] * LDB + b_col[j] * 2]) = make_uint4(bw[0], bw[1], bw[2], bw[3]);
       }
@@ -5081,7 +5394,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
   const int fr_b = (8 * lh + (p16 >> 2)) * LDB + (16 * ((lane >> 4) & 1) + 4 * (p16 & 3)) * 2;
   using Slot0 = std::integral_constant<int, 0>;
   using Slot1 = std::integral_constant<int, 1>;
-  constexpr int NM = 12 * NJ, NP = NPS + 1;
+  constexpr int NM = 4 * NS * NJ, NP = NPS + 1;
   auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
     const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
     const unsigned char* sbb = &cur[NS * PLANE + fr_b + wn * 32 * NJ * 2];
@@ -5095,11 +5408,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     static_for<NM>([&](auto G_) {
       constexpr int G = decltype(G_)::value;
-      constexpr int ks = G / (6 * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
-      if constexpr (q < NSM_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][i], bv[ks][j], acc[i][j], 0, 0, 0);
+      constexpr int ks = G / (2 * NS * NJ), q = (G / (2 * NJ)) % NS, i = (G / NJ) % 2, j = G % NJ;
+      acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
       if constexpr (ks == 0) {
         if constexpr (G < NJ) bv[1][G] = tr_frag_ld<LDB>(sbb + 16 * LDB + G * 64);
-        if constexpr (j == NJ - 1 && q < NSM_) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
+        if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
       constexpr int P0 = G * NP / NM, P1 = (G + 1) * NP / NM;
       static_for<P1 - P0>([&](auto D_) {
@@ -5147,23 +5460,29 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
         const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          if (m < p.M) Cb[(int64_t)m * p.ldc + ncol[j]] = p.accumulate ? acc[i][j][eb * 4 + ee] + old[ee][j] : acc[i][j][eb * 4 + ee];
+          if (m < p.M) {
+            const float v = F16 ? acc[i][j][eb * 4 + ee] * inv_sE : acc[i][j][eb * 4 + ee];
+            Cb[(int64_t)m * p.ldc + ncol[j]] = p.accumulate ? v + old[ee][j] : v;
+          }
       }
     }
 }
 
 extern "C" int ofq_qattn_dxq_bf16s(const float* dS, const int8_t* qcodes, float* dxq, const float* sq, float gscale_q,
-                                   int accumulate, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, ofq_stream_t stream) {
+                                   int accumulate, int64_t B, int64_t H, int64_t N, int64_t C, int64_t ldS, const void* amax,
+                                   ofq_stream_t stream) {
   if (!dS || !qcodes || !dxq || !sq || B <= 0 || H <= 0 || N <= 0 || (C & 15) || (ldS & 7) || ldS < N) return OFQ_EINVAL;
   QNnArgs a = {};
+  a.amax = (const unsigned*)amax;      // two-plane fp16 form of the wide kernel (C == 384); elsewhere three bf16 planes
   a.A = dS; a.B = qcodes; a.C = dxq; a.s = sq; a.lda = ldS; a.ldb = H * C; a.ldc = C;
   a.sA0 = H * N * ldS; a.sB0 = N * H * C; a.sC0 = N * C; a.sAk = N * ldS; a.sBk = C;
   a.M = (int)N; a.N = (int)C; a.K = (int)N; a.nkb = (int)H; a.ks_stride = (int)H; a.accumulate = accumulate; a.gscale = gscale_q;
   a.tiles_m = (int)ceil_div(N, 128); a.tiles_n = (int)ceil_div(C, 128);
   static const bool nn_narrow = getenv("OFQ_NN_NARROW") != nullptr;           // A/B switch (tools/)
-  if (C == 384 && !nn_narrow && N * ldS < (1ll << 31))
-    hipLaunchKernelGGL(qgemm_bf16s_nn_wide_kernel, dim3((unsigned)a.tiles_m, (unsigned)B), dim3(512), 0, (hipStream_t)stream, a);
-  else
+  if (C == 384 && !nn_narrow && N * ldS < (1ll << 31)) {
+    if (amax) hipLaunchKernelGGL(qgemm_bf16s_nn_wide_kernel<true>, dim3((unsigned)a.tiles_m, (unsigned)B), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(qgemm_bf16s_nn_wide_kernel<false>, dim3((unsigned)a.tiles_m, (unsigned)B), dim3(512), 0, (hipStream_t)stream, a);
+  } else
     hipLaunchKernelGGL(qgemm_bf16s_nn_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();

@@ -5,10 +5,17 @@
 // HBM-bound: 4 B read + 4 B written per weight (+1 B for the optional level).
 #include "common.h"
 
+// a small integer code as a 16-bit float: bf16 (the three-plane backward GEMMs) or fp16 (the two-plane ones), both exact
+__device__ __forceinline__ unsigned short statsq_code16(float code, int f16) {
+  if (f16) { const _Float16 h = (_Float16)code; return __builtin_bit_cast(unsigned short, h); }
+  return (unsigned short)(__float_as_uint(code) >> 16);
+}
+
 __device__ __forceinline__ void statsq_row(const float* __restrict__ W, int64_t rows, int64_t cols, float n,
                                            float* __restrict__ out, float* __restrict__ scale, int8_t* __restrict__ levels,
                                            int scale_given, int odd_codes, unsigned short* __restrict__ codesT,
-                                           const float* __restrict__ rvec, float* __restrict__ rout, int64_t row, int lane) {
+                                           const float* __restrict__ rvec, float* __restrict__ rout, int64_t row, int lane,
+                                           int t_f16 = 0) {
   if (row >= rows) return;
   const float* w = W + row * cols;
   const bool vec = ((cols & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
@@ -37,7 +44,7 @@ __device__ __forceinline__ void statsq_row(const float* __restrict__ W, int64_t 
   int8_t* lv = levels ? levels + row * cols : nullptr;
   float racc = 0.f;                                 // sum_k rvec[k] * code[row][k]  (offset term of the int8 GEMM)
   auto side = [&](int64_t k, float code) {          // by-products of the code path: transposed bf16 codes, row dot
-    if (codesT) codesT[k * rows + row] = (unsigned short)(__float_as_uint(code) >> 16);   // small integers: exact in bf16
+    if (codesT) codesT[k * rows + row] = statsq_code16(code, t_f16);   // small integers: exact in bf16 / fp16
     if (rvec) racc += rvec[k] * code;
   };
   auto q1 = [&](float wv, float& L) -> float {
@@ -68,10 +75,10 @@ __device__ __forceinline__ void statsq_row(const float* __restrict__ W, int64_t 
           char4 c4 = make_char4((signed char)L0, (signed char)L1, (signed char)L2, (signed char)L3);
           reinterpret_cast<char4*>(lv)[i] = c4;
           if (codesT) {
-            codesT[(4 * i) * rows + row] = (unsigned short)(__float_as_uint(L0) >> 16);
-            codesT[(4 * i + 1) * rows + row] = (unsigned short)(__float_as_uint(L1) >> 16);
-            codesT[(4 * i + 2) * rows + row] = (unsigned short)(__float_as_uint(L2) >> 16);
-            codesT[(4 * i + 3) * rows + row] = (unsigned short)(__float_as_uint(L3) >> 16);
+            codesT[(4 * i) * rows + row] = statsq_code16(L0, t_f16);
+            codesT[(4 * i + 1) * rows + row] = statsq_code16(L1, t_f16);
+            codesT[(4 * i + 2) * rows + row] = statsq_code16(L2, t_f16);
+            codesT[(4 * i + 3) * rows + row] = statsq_code16(L3, t_f16);
           }
           if (rvec) {
             const float4 rv = make_float4(rvec[4 * i], rvec[4 * i + 1], rvec[4 * i + 2], rvec[4 * i + 3]);
@@ -108,9 +115,9 @@ __global__ __launch_bounds__(256) void statsq_fwd_kernel(const float* __restrict
                                                          float* __restrict__ scale, int8_t* __restrict__ levels,
                                                          int scale_given, int odd_codes,
                                                          unsigned short* __restrict__ codesT, const float* __restrict__ rvec,
-                                                         float* __restrict__ rout) {
+                                                         float* __restrict__ rout, int t_f16) {
   statsq_row(W, rows, cols, n, out, scale, levels, scale_given, odd_codes, codesT, rvec, rout,
-             (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+             (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, t_f16);
 }
 
 // Multi-tensor code path: the weights of a model only change at the optimizer step, so the scale / int8 codes / transposed
@@ -139,12 +146,14 @@ __global__ __launch_bounds__(256) void statsq_multi_kernel(StatsqPack pk) {
   const StatsqEntry& e = pk.e[t];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)((int)blockIdx.x - pk.first_block[t]) * STATSQ_RPB;
-  const float n = (float)(1 << (e.bits - 1));
+  const int t_f16 = (int)((e.bits >> 8) & 1);          // bits | 0x100: the transposed codes as fp16 instead of bf16
+  const int bits = (int)(e.bits & 0xff);
+  const float n = (float)(1 << (bits - 1));
   const bool tiled = ((e.cols & 3) == 0) && ((e.rows & 7) == 0) && ((((uintptr_t)e.W) & 15) == 0) && e.codesT &&
                      ((((uintptr_t)e.codesT) & 15) == 0) && ((((uintptr_t)e.codes) & 3) == 0) && ((((uintptr_t)e.rvec) & 15) == 0);
   if (!tiled) {                                         // odd geometry: the per-row form, two rows per wave
     for (int i = 0; i < 2; ++i)
-      statsq_row(e.W, e.rows, e.cols, n, nullptr, e.scale, e.codes, 0, 1, e.codesT, e.rvec, e.rout, row0 + 2 * wid + i, lane);
+      statsq_row(e.W, e.rows, e.cols, n, nullptr, e.scale, e.codes, 0, 1, e.codesT, e.rvec, e.rout, row0 + 2 * wid + i, lane, t_f16);
     return;
   }
   __shared__ float s_sh[STATSQ_RPB];
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void statsq_multi_kernel(StatsqPack pk) {
         const float cl = fminf(fmaxf(v, -1.0f), cmax);                             // :145
         const float L = rintf(__fsub_rn(__fmul_rn(cl, n), 0.5f));                  // :147
         code[k] = 2.f * L + 1.f;                                                    // odd codes 2L+1
-        ct[k][r] = (unsigned short)(__float_as_uint(code[k]) >> 16);               // small integers: exact in bf16
+        ct[k][r] = statsq_code16(code[k], t_f16);                                  // small integers: exact in bf16 / fp16
       }
       reinterpret_cast<char4*>(e.codes + (row0 + r) * e.cols)[c] =
           make_char4((signed char)code[0], (signed char)code[1], (signed char)code[2], (signed char)code[3]);
@@ -219,7 +228,8 @@ extern "C" int ofq_statsq_codes_multi(const void* host_entries, int64_t n, ofq_s
     int blocks = 0;
     for (int i = 0; i < pk.n; ++i) {
       const StatsqEntry& e = he[base + i];
-      if (!e.W || !e.scale || !e.codes || e.rows <= 0 || e.cols <= 0 || e.bits < 1 || e.bits > 7 || (e.rvec && !e.rout))
+      if (!e.W || !e.scale || !e.codes || e.rows <= 0 || e.cols <= 0 || (e.bits & 0xff) < 1 || (e.bits & 0xff) > 7 || (e.bits & ~0x1ffll) ||
+          (e.rvec && !e.rout))
         return OFQ_EINVAL;
       pk.e[i] = e;
       pk.first_block[i] = blocks;
@@ -233,13 +243,14 @@ extern "C" int ofq_statsq_codes_multi(const void* host_entries, int64_t n, ofq_s
 }
 
 static int statsq_launch(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale, int8_t* levels,
-                         int scale_given, int odd_codes, void* codesT, const float* rvec, float* rout, ofq_stream_t stream) {
+                         int scale_given, int odd_codes, void* codesT, const float* rvec, float* rout, ofq_stream_t stream,
+                         int t_f16 = 0) {
   if (!W || !scale || rows <= 0 || cols <= 0 || bits < 1 || bits > 8) return OFQ_EINVAL;
   if (odd_codes && bits > 7) return OFQ_EINVAL;       // 2L+1 must fit int8
   float n = (float)(1 << (bits - 1));
   dim3 grid((unsigned)((rows + 3) / 4));
   hipLaunchKernelGGL(statsq_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, rows, cols, n, out, scale,
-                     levels, scale_given, odd_codes, (unsigned short*)codesT, rvec, rout);
+                     levels, scale_given, odd_codes, (unsigned short*)codesT, rvec, rout, t_f16);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
@@ -253,5 +264,5 @@ extern "C" int ofq_statsq_fwd(const float* W, int64_t rows, int64_t cols, int bi
 extern "C" int ofq_statsq_codes_fwd(const float* W, int64_t rows, int64_t cols, int bits, float* out, float* scale,
                                     int8_t* codes, void* codesT_bf16, const float* rvec, float* rout, ofq_stream_t stream) {
   if (!codes || (rvec && !rout)) return OFQ_EINVAL;
-  return statsq_launch(W, rows, cols, bits, out, scale, codes, 0, 1, codesT_bf16, rvec, rout, stream);
+  return statsq_launch(W, rows, cols, bits & 0xff, out, scale, codes, 0, 1, codesT_bf16, rvec, rout, stream, (bits >> 8) & 1);
 }

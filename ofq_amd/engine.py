@@ -237,6 +237,8 @@ def _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp):
     loss = loss_fn(out, target, soft_target)
     F_ofq.DW_DEFER = True                       # weight-gradient GEMMs are queued and launched a block at a time
     F_ofq.begin_backward()
+    if loss.is_cuda:
+        ops.amax_begin(loss.device)             # the gradient tensors' maximum words (two-plane backward GEMMs): one fill per step
     try:
         loss.backward()
     except BaseException:
@@ -244,6 +246,7 @@ def _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp):
         raise
     finally:
         F_ofq.DW_DEFER = False
+        ops.amax_end()
     F_ofq.flush_dw()
     F_ofq.assert_step_queues_empty()            # nothing parked, queued or deferred may outlive the backward pass
     if loss.is_cuda:

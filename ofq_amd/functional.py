@@ -260,7 +260,9 @@ def queue_dw(dy2d, xcodes2d, lsq_s, S, gscale, baft, out, db_to_autograd=True):
     # the outputs are queued as raw addresses: autograd must hold the only reference to dW / db, or AccumulateGrad would
     # clone them (still unwritten) instead of adopting them as .grad; they stay alive as .grad / in autograd's input buffers
     q.append({"dy2d": dy2d, "xcodes2d": xcodes2d, "lsq_s": lsq_s, "S": S, "gscale": gscale, "baft": baft,
-              "dW": dW.data_ptr(), "db": db.data_ptr(), "db_keep": None if db_to_autograd else db})
+              "dW": dW.data_ptr(), "db": db.data_ptr(), "db_keep": None if db_to_autograd else db,
+              # (the maximum word travels as an attribute of the gradient tensor: looked up now, while that object is at hand)
+              "amax": ops._planes_amax(dy2d, None)})
     _DW_TILES[0] += ops.tn_tiles(M, N)
     if _DW_TILES[0] >= DW_FLUSH_TILES:
         flush_dw()

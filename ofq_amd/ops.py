@@ -190,9 +190,9 @@ def statsq_codes_fwd(W, bits, rvec=None, need_values=True, want_T=True):
     out = torch.empty_like(W) if need_values else None
     s = torch.empty(rows, dtype=torch.float32, device=dev)
     codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
-    codesT = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev) if want_T else None
+    codesT = torch.empty((cols, rows), dtype=torch.float16 if (GRAD_PLANES == 2 and "dx" in _DBG_F16) else torch.bfloat16, device=dev) if want_T else None
     r = torch.empty(rows, dtype=torch.float32, device=dev) if rvec is not None else None
-    _chk(lib().ofq_statsq_codes_fwd(W.data_ptr(), rows, cols, bits, _p(out), s.data_ptr(), codes.data_ptr(), _p(codesT),
+    _chk(lib().ofq_statsq_codes_fwd(W.data_ptr(), rows, cols, bits | (0x100 if (GRAD_PLANES == 2 and "dx" in _DBG_F16) else 0), _p(out), s.data_ptr(), codes.data_ptr(), _p(codesT),
                                     _p(rvec), _p(r), _stream()), "ofq_statsq_codes_fwd")
     if out is None:
         out = placeholder((rows, cols), dev)
@@ -214,10 +214,10 @@ def statsq_codes_multi(items):
         dev = Wc.device
         s = torch.empty(rows, dtype=torch.float32, device=dev)
         codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
-        codesT = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev) if want_T else None
+        codesT = torch.empty((cols, rows), dtype=torch.float16 if (GRAD_PLANES == 2 and "dx" in _DBG_F16) else torch.bfloat16, device=dev) if want_T else None
         r = torch.empty(rows, dtype=torch.float32, device=dev) if rvec is not None else None
         blob += struct.pack("<6Q3q", Wc.data_ptr(), s.data_ptr(), codes.data_ptr(), _p(codesT) or 0, _p(rvec) or 0, _p(r) or 0,
-                            rows, cols, int(bits))
+                            rows, cols, int(bits) | (0x100 if (GRAD_PLANES == 2 and "dx" in _DBG_F16) else 0))
         keep.append(Wc)
         outs.append((s, codes, codesT, r))
     buf = (C.c_char * len(blob)).from_buffer(blob)
@@ -370,11 +370,96 @@ def linear_bwd_weight(dy, x2d):
 
 
 # ------------------------------------------------------------------------------------------------ code GEMMs
+# Planes of the fp32 operand (dY) in the backward code GEMMs.  2 (default since round 5): two fp16 planes of the tensor scaled
+# by a power of two taken from its absolute maximum -- fp32-grade on the scale of the tensor (include/ofq_hip.h,
+# ofq_qgemm_bf16s_nt), two matrix-core products per element; 3: three bf16 planes, the exact fp32 product (rounds 1-4).
+# It decides the format of the TRANSPOSED weight codes the quantisers keep (fp16 / bf16); the GEMM wrappers below follow
+# the dtype of the codes they are handed, so tests can drive either form explicitly.
+GRAD_PLANES = 3 if os.environ.get("OFQ_GRAD_PLANES") == "3" else 2
+_DBG_F16 = set(os.environ.get("OFQ_DEBUG_F16", "dx,dw,dqkx,dxq").split(","))      # (debugging: which GEMM families may take the two-plane form)
+
+
 def codes_transpose_bf16(codes):
     rows, cols = codes.shape
     out = torch.empty((cols, rows), dtype=torch.bfloat16, device=codes.device)
     _chk(lib().ofq_codes_transpose_bf16(codes.data_ptr(), out.data_ptr(), rows, cols, _stream()), "ofq_codes_transpose_bf16")
     return out
+
+
+def codes_transpose_f16(codes):
+    rows, cols = codes.shape
+    out = torch.empty((cols, rows), dtype=torch.float16, device=codes.device)
+    _chk(lib().ofq_codes_transpose_f16(codes.data_ptr(), out.data_ptr(), rows, cols, _stream()), "ofq_codes_transpose_f16")
+    return out
+
+
+def codes_transpose_16(codes):
+    """The transposed codes in the format of the configured backward form (GRAD_PLANES)."""
+    return codes_transpose_f16(codes) if (GRAD_PLANES == 2 and "dx" in _DBG_F16) else codes_transpose_bf16(codes)
+
+
+# ---- absolute maxima of gradient tensors (the power-of-two scale of the two-plane form) --------------------------------------
+# A word per gradient tensor, holding the bits of max |x|: written by the backward kernel that produces the tensor (its amax_out
+# argument) or by ofq_absmax_f32, read by the GEMMs that consume the tensor.  It travels as an attribute of the tensor object
+# (autograd hands a Function's output to the next Function as the same object, and a reshape in between keeps it as `._base`);
+# a tensor without one (an ATen op in between, an accumulated gradient) gets its maximum computed on the spot.
+# Inside engine's step the words come from a pool that is zeroed once per backward pass (one fill instead of one per tensor, and
+# fixed addresses for a captured step).
+_AMAX_POOL = {}
+_AMAX_STATE = {"active": False, "next": 0}
+AMAX_POOL_WORDS = 4096
+
+
+def amax_begin(device):
+    """engine._step_compute, right before loss.backward(): zero the pool, hand its words out from the start again."""
+    pool = _AMAX_POOL.get(device.index)
+    if pool is None:
+        pool = _AMAX_POOL[device.index] = torch.zeros(AMAX_POOL_WORDS, dtype=torch.int32, device=device)
+    else:
+        pool.zero_()
+    _AMAX_STATE["active"], _AMAX_STATE["next"] = True, 0
+
+
+def amax_end():
+    _AMAX_STATE["active"] = False
+
+
+def amax_word(device):
+    """A zeroed device word for one tensor's maximum."""
+    if _AMAX_STATE["active"] and _AMAX_STATE["next"] < AMAX_POOL_WORDS and device.index in _AMAX_POOL and not os.environ.get("OFQ_DEBUG_NO_POOL"):
+        i = _AMAX_STATE["next"]
+        _AMAX_STATE["next"] = i + 1
+        return _AMAX_POOL[device.index][i:i + 1]
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def tag_amax(t, word):
+    t._ofq_amax = word
+    return t
+
+
+def amax_of(t):
+    """The maximum word a producer attached to `t` (or to the tensor `t` is a view of: an upper bound is all that is needed)."""
+    w = getattr(t, "_ofq_amax", None)
+    if w is None and t._base is not None:
+        w = getattr(t._base, "_ofq_amax", None)
+    return w
+
+
+def absmax(t2d):
+    """max |t2d| into a fresh word (ofq_absmax_f32); the word is attached to the tensor and returned."""
+    w = amax_word(t2d.device)
+    rows, cols = t2d.shape
+    if cols % 4 or t2d.stride(1) != 1 or t2d.stride(0) % 4 or t2d.data_ptr() % 16 or os.environ.get("OFQ_DEBUG_ABSMAX_TORCH"):
+        w.copy_(t2d.detach().abs().max().reshape(1).view(torch.int32))           # odd geometry: the stock reduction
+    else:
+        _chk(lib().ofq_absmax_f32(t2d.data_ptr(), rows, cols, t2d.stride(0), w.data_ptr(), _stream()), "ofq_absmax_f32")
+    return tag_amax(t2d, w)._ofq_amax
+
+
+def amax_for(t2d):
+    w = amax_of(t2d)
+    return w if w is not None else absmax(t2d)
 
 
 def rowdot_i8(codes, vec):
@@ -441,6 +526,7 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
 
 
 # ---- stream-K input-gradient GEMM (ofq_qgemm_bf16s_nt_sk) ----------------------------------------------------------------
+NT_CLASS = 'qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)'      # bench.py's timer class of the dX GEMMs
 NT_SK = os.environ.get("OFQ_NT_SK", "1") != "0"          # A/B switch: "0" = always the one-tile-per-workgroup kernel
 _NT_SK_FORCE = os.environ.get("OFQ_NT_SK") == "force"   # test hook: stream-K for every shape it accepts
 _sk_ws = {}
@@ -531,13 +617,21 @@ def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
     dev = out.device
     arr = (_lib.NtSeg * len(segs))()
     K = 0
+    f16 = segs[0][1].dtype == torch.float16           # fp16 codes: the two-plane form, every segment with its maximum word
+    keep = []
     for i, (A, B, ks, alpha) in enumerate(segs):
+        if (B.dtype == torch.float16) != f16:
+            raise RuntimeError("ofq_amd: qgemm_bf16s_nt_sk: the segments' codes must share one format (fp16 or bf16)")
         arr[i].A, arr[i].B_bf16, arr[i].k_scale = A.data_ptr(), B.data_ptr(), _p(ks)
         arr[i].K, arr[i].lda, arr[i].ldb, arr[i].alpha = A.shape[1], A.stride(0), B.stride(0), alpha
+        if f16:
+            w = amax_for(A)
+            keep.append(w)
+            arr[i].amax = w.data_ptr()
         K += A.shape[1]
     ws = _sk_workspace(dev)
     g = num_cus(dev) if wgs is None else -int(wgs)        # wgs: exactly that many workgroups (<= the CU count; tests)
-    with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+    with _Timed(NT_CLASS, 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt_sk(arr, len(segs), out.data_ptr(), int(accumulate), M, N, out.stride(0), g, ws.data_ptr(),
                                          ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_sk")
     return out
@@ -557,7 +651,7 @@ def nt_concat_ok(A, B_bf16, parked):
         return False
     ktot = K
     for (a, b, _, _) in (parked or ()):
-        if a.shape[0] != M or b.shape[0] != N:
+        if a.shape[0] != M or b.shape[0] != N or b.dtype != B_bf16.dtype:
             return False
         ktot += a.shape[1]
     return len(parked or ()) <= 1 and (not parked or ktot % 64 == 0)
@@ -581,11 +675,13 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     # (the stream-K launch shares PAIRS of 32-wide k-steps and addresses rows with 32-bit offsets: other shapes take the
     # one-tile-per-workgroup kernel also when sk=True)
     sk_able = N > 128 and K % 64 == 0 and M * A.stride(0) * 4 < 2 ** 32 and N * B_bf16.stride(0) * 2 < 2 ** 32
-    if nsplit == 3 and sk_able and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
+    f16 = B_bf16.dtype == torch.float16                # fp16 codes: the two-plane form (ops.GRAD_PLANES == 2 hands these out)
+    if (nsplit == 3 or f16) and sk_able and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
         return qgemm_bf16s_nt_sk([(A, B_bf16, k_scale, alpha)], out, accumulate)
-    with _Timed('qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * M * N * K):
+    amax = amax_for(A) if f16 else None
+    with _Timed(NT_CLASS, 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
-                                      nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _stream()),
+                                      2 if f16 else nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _p(amax), _stream()),
              "ofq_qgemm_bf16s_nt")
     return out
 
@@ -610,9 +706,15 @@ def qgemm_bf16s_nt_lsq(dy2d, B_bf16, k_scale, alpha, x2d, s, b4, g, want_bias_gr
     return dx, ds, db4, dbaft
 
 
-def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False, out=None):
+def _planes_amax(t2d, planes):
+    """The maximum word of `t2d` when the two-plane form is asked for (planes None: ops.GRAD_PLANES), else None."""
+    return amax_for(t2d) if ((GRAD_PLANES if planes is None else planes) == 2 and "dw" in _DBG_F16) else None
+
+
+def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compute_db=False, out=None, planes=None):
     """dW[o,c] = sum_m (dy[m,o]*a_eff[m % S]) * codes[m,c] + db[o]*baft[c];  compute_db: also returns db = colsum(dy).
-    out: write dW there (a contiguous (o, c) fp32 tensor, e.g. the weight's slice of a gradient bucket)."""
+    out: write dW there (a contiguous (o, c) fp32 tensor, e.g. the weight's slice of a gradient bucket).
+    planes: 2 / 3 planes of dy (None: ops.GRAD_PLANES; the wide kernels only, the narrow one always takes three)."""
     Ktok, M = dy2d.shape
     N = xcodes2d.shape[1]
     if split is None:
@@ -629,10 +731,11 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
     if compute_db:
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
+    amax = _planes_amax(dy2d, planes)
     with _Timed('qgemm_bf16s_tn_wide (linear dW, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * Ktok * M * N):
         _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
                                       _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
-                                      split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn")
+                                      split, ws.data_ptr(), ws.numel(), _p(amax), _stream()), "ofq_qgemm_bf16s_tn")
     return (dW, db) if compute_db else dW
 
 
@@ -650,13 +753,14 @@ def tn_groupable(Ktok, M, N, S, lda, ldb):
             and Ktok * lda < (1 << 31) and Ktok * ldb < (1 << 31))
 
 
-def qgemm_bf16s_tn_group(jobs, split=None):
-    """jobs: list of dicts (dy2d, xcodes2d, lsq_s, S, gscale, baft, dW, db) -- dW (M, N) / db (M) are OUTPUT tensors the
+def qgemm_bf16s_tn_group(jobs, split=None, planes=None):
+    """jobs: list of dicts (dy2d, xcodes2d, lsq_s, S, gscale, baft, dW, db[, amax]) -- dW (M, N) / db (M) are OUTPUT tensors the
     caller has allocated; every job computes what qgemm_bf16s_tn(compute_db=db is not None) would.  One GEMM launch and
-    one reduce launch for all of them."""
+    one reduce launch for all of them.  planes: as qgemm_bf16s_tn (a job's "amax" word, if present, is used as it is)."""
     n = len(jobs)
     assert 1 <= n <= TN_GROUP_MAX
     arr = (_lib.TnJob * n)()
+    keep = []
     tiles = 0
     flops = 0.0
     nkt = 1
@@ -677,6 +781,11 @@ def qgemm_bf16s_tn_group(jobs, split=None):
         a.baft = _p(j["baft"])
         a.S, a.Ktok, a.M, a.N, a.lda, a.ldb = j["S"], Ktok, M, N, dy.stride(0), xc.stride(0)
         a.gscale, a.compute_db = j["gscale"], int(pb is not None)
+        w = j.get("amax")
+        if w is None:
+            w = _planes_amax(dy, planes)
+        keep.append(w)
+        a.amax = _p(w)
     if split is None:
         split = max(1, min(256 // tiles, nkt // 4))
     dev = jobs[0]["dy2d"].device
@@ -822,20 +931,34 @@ def qattn_dv(dO, pcodes, sp, gp, B, H, N, d, Np):
     return dV
 
 
-def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS):
+def scores_amax(dS, N, planes=None):
+    """The maximum word of a score-gradient tensor (B, H, N, ld) over its N REAL columns (the pad columns up to ld are never
+    read and may hold anything): the producer's word when it attached one, else a reduction over the strided view."""
+    if (GRAD_PLANES if planes is None else planes) != 2:
+        return None
+    w = amax_of(dS)
+    if w is None:
+        w = absmax(dS.view(-1, dS.shape[-1])[:, :N])
+        tag_amax(dS, w)
+    return w
+
+
+def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS, planes=None):
     dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
+    amax = scores_amax(dS, N, planes) if "dqkx" in _DBG_F16 else None
     with _Timed('qgemm_bf16s_tn_wide_stream (attention dqkx, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
-                                        ldS, _stream()), "ofq_qattn_dqkx_bf16s")
+                                        ldS, _p(amax), _stream()), "ofq_qattn_dqkx_bf16s")
     return dq
 
 
-def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False):
+def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False, planes=None):
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
+    amax = scores_amax(dS, N, planes) if "dxq" in _DBG_F16 else None
     with _Timed('qgemm_bf16s_nn_wide (attention dxq, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
-                                       H, N, C, ldS, _stream()), "ofq_qattn_dxq_bf16s")
+                                       H, N, C, ldS, _p(amax), _stream()), "ofq_qattn_dxq_bf16s")
     return out
 
 

@@ -64,7 +64,7 @@ class StatsQuantizer(nn.Module):
     def codes_T(self):
         """Weight codes transposed to [in][out] as bf16 (exact small integers) for dX = dY @ W_hat."""
         if self._codesT is None:
-            self._codesT = ops.codes_transpose_bf16(self._codes)
+            self._codesT = ops.codes_transpose_16(self._codes)      # fp16 (two-plane backward) or bf16, ops.GRAD_PLANES
         return self._codesT
 
     @property
