@@ -30,6 +30,8 @@ extern "C" {
 #define OFQ_ABI_VERSION 2
 #define OFQ_EINVAL (-1)  /* bad argument (shape, alignment, null pointer) */
 #define OFQ_ENOWS  (-2)  /* workspace too small */
+#define OFQ_AMAX_WORDS 64  /* slots per absolute-maximum group (ofq_absmax_f32, amax / amax_out arguments) ... */
+#define OFQ_AMAX_STRIDE 32 /* ... one every 32 words (its own 128-byte line): a group is 64 * 32 * 4 = 8192 bytes */
 
 typedef void* ofq_stream_t;
 
@@ -85,7 +87,7 @@ size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, int64_t bia
 int ofq_lsq_bwd(const float* g, const float* x, const float* s, const float* b4, float* dx, float* ds,
                 float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
                 int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue, void* ws,
-                size_t ws_bytes, ofq_stream_t stream);
+                size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /* ---- K10  scale + softmax + unsigned LSQ on attention scores:
  *  QAttention*.forward attention.py:96-99 / :213-216.  scores [rows][ld] (ld >= n, row r belongs to
@@ -102,7 +104,7 @@ size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows);
 /*  backward: g = dL/dy -> dscores (may alias g), ds[S] overwritten. */
 int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
                         int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
-                        float* ds_rowsum, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                        float* ds_rowsum, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
                         /* ds_rowsum (optional, [rows]): sum_m dscores[r][m], used by ofq_qattn_dxq's offset term */
 
 /* ---- K6-K9, K11  fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chain):
@@ -163,7 +165,7 @@ int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, co
                          int64_t lda, int64_t ldb, const float* gy, int64_t ldg, float* dy, int64_t ldd,
                          const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
                          int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, float* ds, float* db4, float* dbaft,
-                         void* ws, size_t ws_bytes, ofq_stream_t stream);
+                         void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
  *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.
@@ -251,8 +253,10 @@ int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int split, void*
 int ofq_codes_transpose_bf16(const int8_t* codes, void* out_bf16, int64_t rows, int64_t cols, ofq_stream_t stream);
 /*  the same with the codes as FP16 (B operand of the two-plane form: ofq_qgemm_bf16s_nt / _nt_sk with amax) */
 int ofq_codes_transpose_f16(const int8_t* codes, void* out_f16, int64_t rows, int64_t cols, ofq_stream_t stream);
-/*  *amax = max(*amax, bits of max |x[r][c]|) over x fp32 [rows][cols] (ld), by atomic maxima on the bit patterns (order-independent:
- *            deterministic; a NaN in x gives the NaN pattern).  The caller zeroes *amax.  Serves the two-plane fp16 backward GEMMs
+/*  amax: a GROUP of OFQ_AMAX_WORDS (64) slots OFQ_AMAX_STRIDE words apart (8 KB), zeroed by the caller; afterwards max over the slots = the bits of
+ *            max |x[r][c]| over x fp32 [rows][cols] (ld) (atomic maxima on the bit patterns, spread over the group so that the
+ *            waves of a launch do not queue up behind one address; order-independent: deterministic; a NaN in x gives the NaN
+ *            pattern).  Every `amax` / `amax_out` argument of this header is such a group.  Serves the two-plane fp16 backward GEMMs
  *            (autograd of F.linear, qlinear.py:69) for gradient tensors whose producer did not write the word itself.
  *            cols % 4 == 0, ld % 4 == 0, x 16-byte aligned. */
 int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* amax, ofq_stream_t stream);
@@ -303,7 +307,7 @@ size_t ofq_qattn_dp_softmax_bwd_ws_bytes(int64_t B, int64_t H, int64_t N);
 int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, const float* sv, float gscale_v, const float* bav,
                              const float* prob, const float* sm_s, float sm_gscale, float alpha, int hi, float* dS,
                              float* ds, float* ds_rowsum, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ld,
-                             void* ws, size_t ws_bytes, ofq_stream_t stream);
+                             void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 int ofq_qattn_dv_bf16s(const float* dO, const int8_t* pcodes, float* dV, const float* sp, float gscale_p, int64_t B,
                        int64_t H, int64_t N, int64_t d, int64_t Np, ofq_stream_t stream);
 /*  (dqkx, dxq) amax: NULL = three bf16 planes of dS; else the device word with the bits of an upper bound of max |dS| over the
@@ -349,7 +353,7 @@ int ofq_layernorm_fwd(const float* x, const float* res, const float* gamma, cons
 size_t ofq_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols);
 int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, int64_t ldx,
-                      int64_t ldy, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                      int64_t ldy, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /*  LayerNorm fused with the per-token LSQ that consumes its output (Block.norm1 -> attention input quantiser
  *  attention.py:177, Block.norm2 -> fc1's input quantiser qlinear.py:66-68): codes[r][c] = LSQ(LN(x [+ res])[r][c] +
@@ -365,7 +369,7 @@ size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t rows, int64_t cols);
 int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale, const float* b4,
                           int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds, float* dbaft,
-                          int64_t rows, int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                          int64_t rows, int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /* ---- AdamW over many tensors in one launch (train.py:662, :933: timm create_optimizer_v2 -> torch.optim.AdamW), with
  *  the CGA freeze folded in (cga.py:962-964, :994-997): where frozen[i] != 0 the gradient is masked before the moment
@@ -399,6 +403,12 @@ int ofq_cga_mask_grad_save(float* grad, const float* W, const float* frozen, flo
 /*  W = W*(1-frozen) + saved               (after optimizer.step) */
 int ofq_cga_restore(float* W, const float* frozen, const float* saved, int64_t n, ofq_stream_t stream);
 
+/* ---- amax_out of the backward kernels that WRITE a gradient tensor (ofq_lsq_bwd: dx, ofq_layernorm_bwd / _lsq_bwd: dx,
+ *  ofq_softmax_lsq_bwd / ofq_qattn_dp_softmax_bwd: dscores, ofq_qgemm_i8_lsq_bwd: dy): optional device word, zeroed by the
+ *  caller; the kernel raises it to the bits of max |element written| (atomic maxima on the bit patterns: order-independent,
+ *  deterministic).  The two-plane fp16 GEMMs that consume the tensor (ofq_qgemm_bf16s_nt / _nt_sk / _tn / _tn_group,
+ *  ofq_qattn_dqkx_bf16s / _dxq_bf16s with `amax`) take their power-of-two scale from it; ofq_absmax_f32 computes the same word
+ *  for a tensor whose producer did not. */
 /* ---- deferred second-stage sums.  The backward kernels of the quantisers (ofq_lsq_bwd, ofq_layernorm_lsq_bwd,
  *  ofq_layernorm_bwd, ofq_qgemm_i8_lsq_bwd, ofq_softmax_lsq_bwd, ofq_qattn_dp_softmax_bwd) finish with a small fixed-order
  *  reduction of their per-workgroup partials into d(step) / d(offset) / d(gamma) / d(beta) -- parameter gradients

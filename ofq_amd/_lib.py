@@ -44,10 +44,10 @@ SIGNATURES = {
     "ofq_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
-                          vp, sz, vp]),
+                          vp, sz, vp, vp]),
     "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, vp, i64, vp]),
     "ofq_softmax_lsq_bwd_ws_bytes": (sz, [i64]),
-    "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, sz, vp]),
+    "ofq_softmax_lsq_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, sz, vp, vp]),
     "ofq_gemm_ws_bytes": (sz, [C.POINTER(GemmDesc)]),
     "ofq_gemm_f32": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
     "ofq_qgemm_i8_nt": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, i64, vp]),
@@ -55,7 +55,7 @@ SIGNATURES = {
                                 vp, i64, vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp]),
     "ofq_qgemm_i8_lsq_bwd_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_i8_lsq_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, vp, i64, vp, i64,
-                                   vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
+                                   vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp]),
     "ofq_qgemm_bf16s_nt_sk_ws_bytes": (sz, [i32]),
     "ofq_qgemm_bf16s_nt_sk_pays": (i32, [i64, i64, i64, i32]),
@@ -83,7 +83,7 @@ SIGNATURES = {
     "ofq_qattn_dp_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dv_bf16s": (i32, [vp, vp, vp, vp, f32, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_dp_softmax_bwd_ws_bytes": (sz, [i64, i64, i64]),
-    "ofq_qattn_dp_softmax_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, f32, f32, i32, vp, vp, vp, i64, i64, i64, i64, i64, vp, sz, vp]),
+    "ofq_qattn_dp_softmax_bwd": (i32, [vp, vp, vp, f32, vp, vp, vp, f32, f32, i32, vp, vp, vp, i64, i64, i64, i64, i64, vp, sz, vp, vp]),
     "ofq_qattn_dqkx_bf16s": (i32, [vp, vp, vp, vp, f32, vp, i64, i64, i64, i64, i64, vp, vp]),
     "ofq_qattn_dxq_bf16s": (i32, [vp, vp, vp, vp, f32, i32, i64, i64, i64, i64, i64, vp, vp]),
     "ofq_rowdot_i8_multi": (i32, [vp, vp, vp, i64, i64, i32, vp]),
@@ -94,11 +94,11 @@ SIGNATURES = {
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
     "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp]),
     "ofq_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
-    "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp]),
+    "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp, vp]),
     "ofq_layernorm_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, i64, i64, i64, f32, vp]),
     "ofq_layernorm_lsq_bwd_ws_bytes": (sz, [i64, i64]),
     "ofq_layernorm_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64,
-                                    i64, i64, vp, sz, vp]),
+                                    i64, i64, vp, sz, vp, vp]),
     "ofq_adamw_tensor_entry_bytes": (i64, []),
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_adamw_hyper_pack": (i32, [vp, f32, f64, f64, f32, f32, f64, f64]),

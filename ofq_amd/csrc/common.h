@@ -163,6 +163,36 @@ __device__ __forceinline__ float ofq_wave_max(float v) {
   return v;
 }
 
+// By-product of the backward kernels that WRITE a gradient tensor: max |element| as the bits of a float, into a group of
+// OFQ_AMAX_WORDS slots, OFQ_AMAX_STRIDE words apart (8 KB, zeroed by the caller), from which the two-plane fp16 GEMMs that consume the tensor take their
+// power-of-two scale (csrc/qgemm.hip, split2_f16).  m = this lane's running fmaxf(|x|) (>= 0).  One wave-wide reduction, then
+// one fire-and-forget atomic maximum per wave on the word picked by the wave's position (64 words: the ~10^4 waves of a launch
+// do not queue up behind one address, and nobody waits for a returned value).  The maximum of the group is the tensor's
+// maximum; maxima commute, so the group does not depend on the order of the updates.
+#define OFQ_AMAX_WORDS 64
+#define OFQ_AMAX_STRIDE 32          // words between the slots of a group: every slot on its own 128-byte line (atomic units work per line)
+__device__ __forceinline__ void ofq_amax_publish(unsigned* amax, float m) {
+  m = ofq_wave_max(m);
+  const unsigned b = __float_as_uint(m);
+  if ((threadIdx.x & 63) == 0 && b != 0u) {
+    const unsigned slot = (blockIdx.x * 5u + blockIdx.y * 3u + (threadIdx.x >> 6)) & (OFQ_AMAX_WORDS - 1);
+    __hip_atomic_fetch_max(amax + slot * OFQ_AMAX_STRIDE, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// the maximum of a word group, by every wave that asks (all 64 lanes active): the value as a float (NaN pattern included)
+__device__ __forceinline__ float ofq_amax_load(const unsigned* amax) {
+  unsigned b = amax[(threadIdx.x & (OFQ_AMAX_WORDS - 1)) * OFQ_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(b, o, 64);
+    b = t > b ? t : b;
+  }
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ float ofq_absmax4(float m, float a, float b, float c, float d) {
+  return fmaxf(fmaxf(m, fabsf(a)), fmaxf(fabsf(b), fmaxf(fabsf(c), fabsf(d))));
+}
+
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // second stage: dst[c] = scale * sum_{r<nrows} sum_{t<cnt} src[r*row_stride + c*cnt + t], fixed order.

@@ -18,6 +18,7 @@ struct LnArgs {
   const float* x; const float* res; const float* gamma; const float* beta;
   float* y; float* xs; float* mean; float* rstd;
   const float* dy; const float* dres; float* dx; float* colpart;      // colpart [gx][2][C]
+  unsigned* amax;        // backward, optional: bits of max |dx| (see ofq_amax_publish)
   int64_t R, C, ldx, ldy;
   int TX, TY;
   float eps;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   const int tx = threadIdx.x % TXW, ty = threadIdx.x / TXW;
   const int64_t w4 = a.C / 4;
   const float invC = 1.0f / (float)a.C;
+  float dxmax = 0.f;
   float4 gam[J], bet[J];
   bool cok[J];
 #pragma unroll
@@ -218,10 +220,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         o.w = rs * (g[j].w - ma - xh[j].w * mb);
         if (a.dres) { o.x += dv[j].x; o.y += dv[j].y; o.z += dv[j].z; o.w += dv[j].w; }
         *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = o;
+        dxmax = ofq_absmax4(dxmax, o.x, o.y, o.z, o.w);
       }
     }
   }
   if (!BWD) return;
+  if (a.amax) ofq_amax_publish(a.amax, dxmax);
   // column partials: [TY][NACC][ncol] through LDS, summed over the row lanes in a fixed order
   constexpr int NACC = Q ? 3 : 2;
   const int ncol = TXW * J * 4;
@@ -310,7 +314,7 @@ extern "C" size_t ofq_layernorm_bwd_ws_bytes(int64_t R, int64_t C) {
 
 extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* dres, float* dx, float* dgamma, float* dbeta, int64_t R, int64_t C,
-                                 int64_t ldx, int64_t ldy, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                 int64_t ldx, int64_t ldy, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
   if (!dy || !x || !mean || !rstd || !dx || !ws) return OFQ_EINVAL;
   if (ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
   LnGeom g;
@@ -319,7 +323,7 @@ extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* m
   if (ws_bytes < ofq_layernorm_bwd_ws_bytes(R, C)) return OFQ_ENOWS;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = dy; a.dres = dres; a.dx = dx;
-  a.colpart = (float*)ws;
+  a.colpart = (float*)ws; a.amax = (unsigned*)amax_out;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX;
   hipStream_t st = (hipStream_t)stream;
   rc = ln_launch<true, false>(g, a, st);
@@ -362,7 +366,7 @@ extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const floa
                                      const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
                                      const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds,
                                      float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
-                                     ofq_stream_t stream) {
+                                     void* amax_out, ofq_stream_t stream) {
   if (!gq || !x || !mean || !rstd || !dx || !ws || !lsq_s || S <= 0 || R % S) return OFQ_EINVAL;
   if (ldx < C || ldg < C || (ldx & 3) || (ldg & 3)) return OFQ_EINVAL;
   LnGeom g;
@@ -371,7 +375,7 @@ extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const floa
   if (ws_bytes < ofq_layernorm_lsq_bwd_ws_bytes(R, C)) return OFQ_ENOWS;
   LnArgs a = {};
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = (float*)mean; a.rstd = (float*)rstd; a.dy = gq; a.dres = dres; a.dx = dx;
-  a.colpart = (float*)ws; a.rowpart = (float*)ws + (size_t)g.gx * 3 * C;
+  a.colpart = (float*)ws; a.rowpart = (float*)ws + (size_t)g.gx * 3 * C; a.amax = (unsigned*)amax_out;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldg; a.TX = g.TX; a.TY = 256 / g.TX;
   a.qs = lsq_s; a.qS = S; a.qgscale = gscale; a.qb4 = b4; a.qlo = (float)lo; a.qhi = (float)hi;
   hipStream_t st = (hipStream_t)stream;

@@ -66,6 +66,7 @@ static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g, bool
 struct LsqArgs {
   const float* x; const float* g; const float* s; const float* b4; const float* baft;
   float* y; float* dx; int8_t* codes;
+  unsigned* amax;   // backward, optional: bits of max |dx| (see ofq_amax_publish)
   float* rowpart;   // [R][gy*nslot]
   float* colpart;   // [gx][nacc][k*inner]
   int64_t R, S, inner, ldx, ldy;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
   }
   const float lo = a.lo, hi = a.hi;
   const int nslot = TX >= 64 ? TX / 64 : 1;
+  float dxmax = 0.f;
 
   if (active_row_group) {
     // software-pipelined row walk: the next row's loads are issued before the current row is processed, so a wave
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
             dxo[e] = GELU ? dq * ofq_gelu_grad(xin[e]) : dq;
           }
           *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
+          dxmax = ofq_absmax4(dxmax, dxo[0], dxo[1], dxo[2], dxo[3]);
         }
       }
       if (BWD && !COLMODE) {
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
     }
   }
   if (!BWD) return;
+  if (a.amax) ofq_amax_publish(a.amax, dxmax);
 
   const int nacc = a.nacc;
   if (a.widek) {
@@ -321,7 +325,7 @@ extern "C" size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, 
 extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds,
                            float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx,
                            int64_t ldy, int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
-                           void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                           void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
   if (!gy || !x || !s || !dx || !ws || outer <= 0 || S <= 0) return OFQ_EINVAL;
   if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
   if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
@@ -333,7 +337,7 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
   lsq_ws_layout(g, outer * S, inner, nacc, &rf, &cf);
   if (ws_bytes < (rf + cf) * sizeof(float)) return OFQ_ENOWS;
   LsqArgs a = {};
-  a.x = x; a.g = gy; a.s = s; a.b4 = b4; a.dx = dx;
+  a.x = x; a.g = gy; a.s = s; a.b4 = b4; a.dx = dx; a.amax = (unsigned*)amax_out;
   a.rowpart = (float*)ws; a.colpart = (float*)ws + rf;
   a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
   a.colmode = scale_mode; a.prologue = prologue; a.nacc = nacc; a.widek = g.widek;

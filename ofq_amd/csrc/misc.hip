@@ -240,8 +240,9 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t st
   return 0;
 }
 
-// ---- max |x| of a gradient tensor, as the bits of a float in a device word (atomicMax over the bit patterns of |x|: they order
-// like the values, and a maximum does not depend on the order of its updates -- deterministic).  The two-plane fp16 form of the
+// ---- max |x| of a gradient tensor, as the bits of a float in a group of OFQ_AMAX_WORDS device words whose maximum is the result
+// (atomic maxima over the bit patterns of |x|: they order like the values, and a maximum does not depend on the order of its
+// updates -- deterministic; see ofq_amax_publish).  The two-plane fp16 form of the
 // backward GEMMs (csrc/qgemm.hip, split2_f16) takes its power-of-two scale from such a word; the backward kernels that PRODUCE a
 // gradient tensor write it as a by-product (their amax_out argument), this kernel serves producers that do not.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols4, int64_t ld,
@@ -262,7 +263,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     const unsigned other = __shfl_xor(b, o, 64);
     b = other > b ? other : b;
   }
-  if ((threadIdx.x & 63) == 0 && b != 0u) atomicMax(amax, b);
+  if ((threadIdx.x & 63) == 0 && b != 0u)
+    __hip_atomic_fetch_max(amax + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (OFQ_AMAX_WORDS - 1)) * OFQ_AMAX_STRIDE, b, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 extern "C" int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* amax, ofq_stream_t stream) {
   if (!x || !amax || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || ld < cols || ((uintptr_t)x & 15) || cols >= (1ll << 31))

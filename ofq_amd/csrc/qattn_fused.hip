@@ -263,6 +263,7 @@ extern "C" int ofq_qattn_scores_softmax_i8(const int8_t* acodes, const int8_t* b
 struct QDpArgs {
   const float* dO; const int8_t* vcodes; const float* sv; const float* bav;
   const float* prob; const float* sm_s; float* dS; float* rowpart; float* ds_rowsum;
+  unsigned* amax;        // optional: bits of max |dS| (see ofq_amax_publish; the pad columns are written as zeros)
   int64_t ld;
   int B, H, N, d, C, S;
   float gscale_v, sm_gscale, alpha, hi;
@@ -425,6 +426,7 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
   __syncthreads();
   // ---- phase 2: LSQ backward + softmax backward per row (ofq_softmax_lsq_bwd's arithmetic)
   const float tol = ofq_lsq_level_tol(0.f, q.hi), half_m_tol = 0.5f - tol;
+  float omax = 0.f;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     if (m0 + wn * 16 + it * 4 >= N) continue;              // wave-uniform: none of the four rows exists
@@ -503,18 +505,22 @@ void qattn_dp_softmax_bwd_kernel(QDpArgs q) {
         o[e] = (dq[4 * k + e] - dot) * p[4 * k + e] * q.alpha;              // (padding columns: p = 0)
         rsum += o[e];
       }
-      if (rok && c0 < q.ld) *reinterpret_cast<float4*>(q.dS + R * q.ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      if (rok && c0 < q.ld) {
+        *reinterpret_cast<float4*>(q.dS + R * q.ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        omax = ofq_absmax4(omax, o[0], o[1], o[2], o[3]);
+      }
     }
     if (TAIL) {
       const float o = (dq[NE - 1] - dot) * p[NE - 1] * q.alpha;
       rsum += o;
-      if (rok && ct < q.ld) q.dS[R * q.ld + ct] = o;
+      if (rok && ct < q.ld) { q.dS[R * q.ld + ct] = o; omax = fmaxf(omax, fabsf(o)); }
     }
     if (q.ds_rowsum) {
       rsum = ofq_group_sum<16>(rsum);
       if (lr == 0 && rok) q.ds_rowsum[R] = rsum;
     }
   }
+  if (q.amax) ofq_amax_publish(q.amax, omax);
 }
 
 extern "C" size_t ofq_qattn_dp_softmax_bwd_ws_bytes(int64_t B, int64_t H, int64_t N) {
@@ -528,7 +534,7 @@ extern "C" size_t ofq_qattn_dp_softmax_bwd_ws_bytes(int64_t B, int64_t H, int64_
 extern "C" int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, const float* sv, float gscale_v, const float* bav,
                                         const float* prob, const float* sm_s, float sm_gscale, float alpha, int hi, float* dS,
                                         float* ds, float* ds_rowsum, int64_t B, int64_t H, int64_t N, int64_t d, int64_t ld,
-                                        void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                        void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
   if (!dO || !vcodes || !sv || !prob || !sm_s || !dS || !ws || B <= 0 || H <= 0 || N <= 0) return OFQ_EINVAL;
   if (N > 256 || ld < N || ld > 256 || (ld & 3) || (d & 15) || d <= 0 || hi < 1 || hi > 255) return OFQ_EINVAL;
   const int64_t C = H * d;
@@ -536,7 +542,7 @@ extern "C" int ofq_qattn_dp_softmax_bwd(const float* dO, const int8_t* vcodes, c
   if (ws_bytes < ofq_qattn_dp_softmax_bwd_ws_bytes(B, H, N)) return OFQ_ENOWS;
   QDpArgs q = {};
   q.dO = dO; q.vcodes = vcodes; q.sv = sv; q.bav = bav; q.prob = prob; q.sm_s = sm_s; q.dS = dS; q.rowpart = (float*)ws;
-  q.ds_rowsum = ds_rowsum; q.ld = ld; q.B = (int)B; q.H = (int)H; q.N = (int)N; q.d = (int)d; q.C = (int)C; q.S = (int)N;
+  q.ds_rowsum = ds_rowsum; q.amax = (unsigned*)amax_out; q.ld = ld; q.B = (int)B; q.H = (int)H; q.N = (int)N; q.d = (int)d; q.C = (int)C; q.S = (int)N;
   q.gscale_v = gscale_v; q.sm_gscale = sm_gscale; q.alpha = alpha; q.hi = (float)hi;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));

@@ -35,6 +35,7 @@ struct QGemmArgs {
   const float* r;        // i8 linear: offset term [N] (optional)
   const float* s;        // i8: LSQ step vector of the rows [S];  bf16s: k-scale ks (optional)
   const unsigned* amax;  // bf16s, two-plane fp16 form: bits of an upper bound of max |A| (device word)
+  unsigned* amax_out;    // i8 recompute backward, optional: bits of max |dy| written (ofq_amax_publish)
   // attention epilogues (i8) / extras (bf16s)
   const float* s2;       // second LSQ step vector (columns: qkx steps [N*nb1] / v steps [C])
   const float* u;        // scores: [nb0][M][nb1]      bf16s-nt: per-row addend [nb0][M][nb1]
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned char* A = (const unsigned char*)p.A;
   const unsigned char* B = (const unsigned char*)p.B;
   float pre_ra, pre_rb = 1.f, pre_c[2][5];
+  float dymax = 0.f;
   int ncol[2];
   {
     const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
@@ -654,13 +656,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           cba[j] += gev[ee][j];
           if (QMODE == 2) cds[j] += dsc[ee][j]; else rds[i * 16 + e] += dsc[ee][j];
           const float dy = GELU ? dq[ee][j] * ofq_gelu_grad(yv[ee][j]) : dq[ee][j];
-          if (m < p.M && cok[j]) p.C[(int64_t)m * p.ldc + ncol[j]] = dy;
+          if (m < p.M && cok[j]) { p.C[(int64_t)m * p.ldc + ncol[j]] = dy; dymax = fmaxf(dymax, fabsf(dy)); }
         }
       }
     }
   };
   half(g0, std::integral_constant<int, 0>());
   half(g1, std::integral_constant<int, 1>());
+  if (p.amax_out) ofq_amax_publish(p.amax_out, dymax);       // max |dy| of the written elements (two-plane GEMMs downstream)
   // ---- row partials (row mode): sum over the 32 lanes that hold the columns of one row; transpose-reduce, 31 exchanges:
   // after the step with mask w a lane keeps the half of its slots selected by its bit w, so lane l31 ends with slot l31
   if (QMODE == 1) {
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3
   float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see qgemm_bf16s_nt_wide_sk_kernel)
   if constexpr (F16) {
     const float m = ksp ? block_absmax<256>(ksp, K, reinterpret_cast<float*>(smem), tid) : 1.f;
-    const float a = __uint_as_float(*p.amax);
+    const float a = ofq_amax_load(p.amax);
     f16_plane_scale(a == a ? a * m : a, sE, inv_sE);
   }
   f32x4v ra[4], rks;
@@ -1626,7 +1629,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
   const unsigned c64 = 0x64646464u;
   if constexpr (F16) {
     const float m = fmaxf(block512_absmax(p.s, p.S, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
-    const float am = __uint_as_float(*p.amax);
+    const float am = ofq_amax_load(p.amax);
     f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
   }
   const int nkt = (p.Ktok + QTN_BK - 1) / QTN_BK;
@@ -2085,7 +2088,7 @@ __device__ __forceinline__ void tn_wide_stream_body(const QTnArgs& p, const int 
   const unsigned c64 = 0x64646464u;
   if constexpr (F16) {
     const float m = fmaxf(block512_absmax(p.s, p.S, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
-    const float am = __uint_as_float(*p.amax);
+    const float am = ofq_amax_load(p.amax);
     f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
   }
   int b_row[NJ], b_col[NJ];
@@ -3159,7 +3162,7 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
                                     int64_t lda, int64_t ldb, const float* gy, int64_t ldg, float* dy, int64_t ldd,
                                     const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
                                     int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, float* ds, float* db4, float* dbaft,
-                                    void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                    void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
   if (!A || !B || !col_scale || !lsq_s || !gy || !dy || !q_s || !ws || M <= 0 || N <= 0 || K <= 0 || S <= 0 || q_S <= 0)
     return OFQ_EINVAL;
   if ((K & 15) || (lda & 15) || (ldb & 15) || !al16(A) || !al16(B) || M >= (1ll << 30) || N >= (1ll << 30) || ldg < N || ldd < N)
@@ -3177,7 +3180,7 @@ extern "C" int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const floa
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
   a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4; a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu;
   a.qrowmul = q_rowmul; a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
-  a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf;
+  a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf; a.amax_out = (unsigned*)amax_out;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
   auto launch = [&](auto QM, auto GE) {
@@ -3266,7 +3269,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
   float sE = 1.f, inv_sE = 1.f;        // F16: the launch's power of two (see qgemm_bf16s_nt_wide_sk_kernel)
   if constexpr (F16) {
     const float m = p.s ? block512_absmax(p.s, K, reinterpret_cast<float*>(smem), tid) : 1.f;
-    const float a = __uint_as_float(*p.amax);
+    const float a = ofq_amax_load(p.amax);
     f16_plane_scale(a == a ? a * m : a, sE, inv_sE);
   }
   f32x4v ra[2][2], rks[2];
@@ -3762,7 +3765,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
       const float m = p.seg[sg].s ? block512_absmax(p.seg[sg].s, p.seg[sg].nkt * QBS_BK, reinterpret_cast<float*>(smem), tid) : 1.f;
-      const float a = __uint_as_float(*p.seg[sg].amax);
+      const float a = ofq_amax_load(p.seg[sg].amax);
       t = fmaxf(t, a * m * (NSEG > 1 ? fabsf(p.seg[sg].alpha) : 1.f));
       if (!(a == a)) t = a;                                  // a NaN bound stays one
     }
@@ -5269,7 +5272,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nn_wide_kernel(QNnArgs p) {
   const unsigned c64 = 0x64646464u;
   if constexpr (F16) {
     const float m = fmaxf(block512_absmax(p.s, K * p.ks_stride, reinterpret_cast<float*>(smem), tid), 1e-5f) * 1.0001f;
-    const float am = __uint_as_float(*p.amax);
+    const float am = ofq_amax_load(p.amax);
     f16_plane_scale(am == am ? am * m : am, sE, inv_sE);
   }
   unsigned rowoff[2];

@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
                                                               const float* __restrict__ s, float* __restrict__ dsc,
                                                               float* __restrict__ rowpart, int64_t rows, int n,
                                                               int64_t ld, int64_t S, float alpha, float hi,
-                                                              float gscale, float* __restrict__ ds_rowsum) {
+                                                              float gscale, float* __restrict__ ds_rowsum,
+                                                              unsigned* __restrict__ amax) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  float omax = 0.f;
   const float a = ofq_lsq_eff_scale(s[r % S], gscale);
   float p[SM_MAXE], dq[SM_MAXE];
   float rowds = 0.f, dot = 0.f;
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_kernel(const float* __res
     const float o = (c < n) ? (dq[e] - dot) * p[e] * alpha : 0.f;
     if (c < ld) dsc[r * ld + c] = o;
     rsum += o;
+    omax = fmaxf(omax, fabsf(o));
   }
+  if (amax) ofq_amax_publish(amax, omax);
   if (ds_rowsum) {       // ~0 in exact arithmetic; kept so that the offset term of dx_hat matches the reference's fp32 value
     rsum = ofq_wave_sum(rsum);
     if (lane == 0) ds_rowsum[r] = rsum;
@@ -191,8 +195,10 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
                                                                  const float* __restrict__ s, float* __restrict__ dsc,
                                                                  float* __restrict__ rowpart, int64_t rows, int n,
                                                                  int64_t ld, int64_t S, float alpha, float hi,
-                                                                 float gscale, float* __restrict__ ds_rowsum) {
+                                                                 float gscale, float* __restrict__ ds_rowsum,
+                                                                 unsigned* __restrict__ amax) {
   constexpr int GPB = 256 / LPR;
+  float omax = 0.f;
   const int lane = threadIdx.x % LPR;
   const int64_t r0 = ((int64_t)blockIdx.x * GPB + threadIdx.x / LPR) * SM_RPW;
   const int c0 = lane * 4;
@@ -238,12 +244,14 @@ __global__ __launch_bounds__(256) void softmax_lsq_bwd_v4_kernel(const float* __
         rsum += o[e];
       }
       *reinterpret_cast<float4*>(dsc + r * ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      omax = ofq_absmax4(omax, o[0], o[1], o[2], o[3]);
     }
     if (ds_rowsum) {
       rsum = ofq_group_sum<LPR>(rsum);
       if (lane == 0 && rok) ds_rowsum[r] = rsum;
     }
   }
+  if (amax) ofq_amax_publish(amax, omax);
 }
 
 extern "C" int ofq_softmax_lsq_fwd(const float* scores, const float* s, float* prob, float* y, int64_t rows, int64_t n,
@@ -277,7 +285,7 @@ extern "C" size_t ofq_softmax_lsq_bwd_ws_bytes(int64_t rows) { return (size_t)ro
 
 extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const float* s, float* dscores, float* ds,
                                    int64_t rows, int64_t n, int64_t ld, int64_t S, float alpha, int hi, float gscale,
-                                   float* ds_rowsum, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                   float* ds_rowsum, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
   if (!g || !prob || !s || !dscores || !ws || rows <= 0 || n <= 0 || n > 64 * SM_MAXE || ld < n || ld > 64 * SM_MAXE ||
       S <= 0 || rows % S)
     return OFQ_EINVAL;
@@ -287,14 +295,14 @@ extern "C" int ofq_softmax_lsq_bwd(const float* g, const float* prob, const floa
   {
     if (ld <= 64)
       hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel<16>, dim3((unsigned)ceil_div(rows, 16 * SM_RPW)), dim3(256), 0, st, g, prob, s,
-                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum, (unsigned*)amax_out);
     else
       hipLaunchKernelGGL(softmax_lsq_bwd_v4_kernel<64>, dim3((unsigned)ceil_div(rows, 4 * SM_RPW)), dim3(256), 0, st, g, prob, s,
-                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+                         dscores, (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum, (unsigned*)amax_out);
   }
   else
     hipLaunchKernelGGL(softmax_lsq_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, g, prob, s, dscores,
-                       (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum);
+                       (float*)ws, rows, (int)n, ld, S, alpha, (float)hi, gscale, ds_rowsum, (unsigned*)amax_out);
   OFQ_LAUNCH_CHECK();
   if (ds) {
     SumJobs jobs = {};

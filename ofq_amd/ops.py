@@ -273,9 +273,12 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
     dbaft = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
     nbytes = lib().ofq_lsq_bwd_ws_bytes(g.outer, g.S, g.inner, g.bias_len, g.mode)
     ws = workspace(nbytes, dev)
+    am = amax_out(dev)
     _chk(lib().ofq_lsq_bwd(gy.data_ptr(), x.data_ptr(), s.data_ptr(), _p(b4), dx.data_ptr(), ds.data_ptr(), _p(db4),
                            _p(dbaft), g.outer, g.S, g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale,
-                           g.prologue, ws.data_ptr(), ws.numel(), _stream()), "ofq_lsq_bwd")
+                           g.prologue, ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_lsq_bwd")
+    if am is not None:
+        tag_amax(dx, am)
     return dx, ds, db4, dbaft
 
 
@@ -301,9 +304,12 @@ def softmax_lsq_bwd(g, prob, s, rows, n, ld, S, alpha, hi, M, inplace=True, want
     gscale = 1.0 / math.sqrt(hi * M)
     rs = torch.empty(rows, dtype=torch.float32, device=g.device) if want_rowsum else None
     ws = workspace(lib().ofq_softmax_lsq_bwd_ws_bytes(rows), g.device)
+    am = amax_out(g.device)
     _chk(lib().ofq_softmax_lsq_bwd(g.data_ptr(), prob.data_ptr(), s.data_ptr(), dsc.data_ptr(), ds.data_ptr(), rows, n,
-                                   ld, S, alpha, hi, gscale, _p(rs), ws.data_ptr(), ws.numel(), _stream()),
+                                   ld, S, alpha, hi, gscale, _p(rs), ws.data_ptr(), ws.numel(), _p(am), _stream()),
          "ofq_softmax_lsq_bwd")
+    if am is not None:
+        tag_amax(dsc, am)
     if want_rowsum:
         return dsc, ds, rs
     return dsc, ds
@@ -407,7 +413,8 @@ def codes_transpose_16(codes):
 # fixed addresses for a captured step).
 _AMAX_POOL = {}
 _AMAX_STATE = {"active": False, "next": 0}
-AMAX_POOL_WORDS = 4096
+AMAX_GROUP = 64 * 32            # device words per tensor: OFQ_AMAX_WORDS slots, OFQ_AMAX_STRIDE words apart (one 128-byte line each)
+AMAX_POOL_WORDS = 1024 * AMAX_GROUP     # 8 MB, zeroed once per backward pass
 
 
 def amax_begin(device):
@@ -425,12 +432,12 @@ def amax_end():
 
 
 def amax_word(device):
-    """A zeroed device word for one tensor's maximum."""
-    if _AMAX_STATE["active"] and _AMAX_STATE["next"] < AMAX_POOL_WORDS and device.index in _AMAX_POOL and not os.environ.get("OFQ_DEBUG_NO_POOL"):
+    """A zeroed group of AMAX_GROUP device words for one tensor's maximum."""
+    if _AMAX_STATE["active"] and _AMAX_STATE["next"] + AMAX_GROUP <= AMAX_POOL_WORDS and device.index in _AMAX_POOL:
         i = _AMAX_STATE["next"]
-        _AMAX_STATE["next"] = i + 1
-        return _AMAX_POOL[device.index][i:i + 1]
-    return torch.zeros(1, dtype=torch.int32, device=device)
+        _AMAX_STATE["next"] = i + AMAX_GROUP
+        return _AMAX_POOL[device.index][i:i + AMAX_GROUP]
+    return torch.zeros(AMAX_GROUP, dtype=torch.int32, device=device)
 
 
 def tag_amax(t, word):
@@ -450,8 +457,8 @@ def absmax(t2d):
     """max |t2d| into a fresh word (ofq_absmax_f32); the word is attached to the tensor and returned."""
     w = amax_word(t2d.device)
     rows, cols = t2d.shape
-    if cols % 4 or t2d.stride(1) != 1 or t2d.stride(0) % 4 or t2d.data_ptr() % 16 or os.environ.get("OFQ_DEBUG_ABSMAX_TORCH"):
-        w.copy_(t2d.detach().abs().max().reshape(1).view(torch.int32))           # odd geometry: the stock reduction
+    if cols % 4 or t2d.stride(1) != 1 or t2d.stride(0) % 4 or t2d.data_ptr() % 16:
+        w[:1].copy_(t2d.detach().abs().max().reshape(1).view(torch.int32))       # odd geometry: the stock reduction
     else:
         _chk(lib().ofq_absmax_f32(t2d.data_ptr(), rows, cols, t2d.stride(0), w.data_ptr(), _stream()), "ofq_absmax_f32")
     return tag_amax(t2d, w)._ofq_amax
@@ -460,6 +467,11 @@ def absmax(t2d):
 def amax_for(t2d):
     w = amax_of(t2d)
     return w if w is not None else absmax(t2d)
+
+
+def amax_out(device):
+    """The word a gradient-producing backward kernel is to raise (its amax_out argument), or None in three-plane mode."""
+    return amax_word(device) if GRAD_PLANES == 2 else None
 
 
 def rowdot_i8(codes, vec):
@@ -514,14 +526,17 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
     dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     colmode = int(q.get("colmode", 0))
     ws = workspace(lib().ofq_qgemm_i8_lsq_bwd_ws_bytes(M, N, colmode), dev)
+    am = amax_out(dev)
     with _Timed('qgemm_i8_lsqbwd (int8 recompute + LSQ backward epilogue)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_i8_lsq_bwd(xc.data_ptr(), wc.data_ptr(), _p(prod["bias"]), prod["w_scale"].data_ptr(),
                                         prod["w_mult"], _p(prod["r"]), prod["act_s"].data_ptr(), prod["act_S"],
                                         prod["act_gscale"], M, N, K, xc.stride(0), wc.stride(0), gy2d.data_ptr(),
                                         gy2d.stride(0), dy.data_ptr(), N, q["s"].data_ptr(), q["S"], q["gscale"], _p(q["b4"]),
                                         q["lo"], q["hi"], int(q["gelu"]), int(q.get("rowmul", 1)), int(q.get("coldiv", N)),
-                                        colmode, ds.data_ptr(), _p(db4), _p(dbaft), ws.data_ptr(), ws.numel(), _stream()),
+                                        colmode, ds.data_ptr(), _p(db4), _p(dbaft), ws.data_ptr(), ws.numel(), _p(am), _stream()),
              "ofq_qgemm_i8_lsq_bwd")
+    if am is not None:
+        tag_amax(dy, am)
     return dy, ds, db4, dbaft
 
 
@@ -916,10 +931,13 @@ def qattn_dp_softmax_bwd(dO, vcodes, sv, gv, bav, prob, sm_s, alpha, hi, B, H, N
     rs = torch.empty(B * H * N, dtype=torch.float32, device=dO.device) if want_rowsum else None
     gscale = 1.0 / math.sqrt(hi * (B * H * N))
     ws = workspace(lib().ofq_qattn_dp_softmax_bwd_ws_bytes(B, H, N), dO.device)
+    am = amax_out(dO.device)
     with _Timed('qattn_dp_softmax_bwd (dP GEMM + softmax-LSQ backward)', 2.0 * B * H * N * N * d):
         _chk(lib().ofq_qattn_dp_softmax_bwd(dO.data_ptr(), vcodes.data_ptr(), sv.data_ptr(), float(gv), _p(bav), prob.data_ptr(),
                                             sm_s.data_ptr(), gscale, float(alpha), int(hi), dS.data_ptr(), ds.data_ptr(), _p(rs),
-                                            B, H, N, d, ld, ws.data_ptr(), ws.numel(), _stream()), "ofq_qattn_dp_softmax_bwd")
+                                            B, H, N, d, ld, ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_qattn_dp_softmax_bwd")
+    if am is not None:
+        tag_amax(dS, am)
     return dS, ds, rs
 
 
@@ -1026,9 +1044,12 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres2d=None, want_affine_grads=T
     dg = torch.empty(cols, dtype=torch.float32, device=dev) if want_affine_grads else None
     db = torch.empty(cols, dtype=torch.float32, device=dev) if want_affine_grads else None
     ws = workspace(lib().ofq_layernorm_bwd_ws_bytes(rows, cols), dev)
+    am = amax_out(dev)
     _chk(lib().ofq_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(dres2d),
                                  dx.data_ptr(), _p(dg), _p(db), rows, cols, x2d.stride(0), dy2d.stride(0), ws.data_ptr(),
-                                 ws.numel(), _stream()), "ofq_layernorm_bwd")
+                                 ws.numel(), _p(am), _stream()), "ofq_layernorm_bwd")
+    if am is not None:
+        tag_amax(dx, am)
     return dx, dg, db
 
 
@@ -1058,10 +1079,13 @@ def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None)
     dba = torch.empty(cols, dtype=torch.float32, device=dev)
     ds = torch.empty_like(s)
     ws = workspace(lib().ofq_layernorm_lsq_bwd_ws_bytes(rows, cols), dev)
+    am = amax_out(dev)
     _chk(lib().ofq_layernorm_lsq_bwd(gq2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                      _p(dres2d), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, dx.data_ptr(), _p(dg),
                                      db.data_ptr(), _p(db4), ds.data_ptr(), dba.data_ptr(), rows, cols, x2d.stride(0),
-                                     gq2d.stride(0), ws.data_ptr(), ws.numel(), _stream()), "ofq_layernorm_lsq_bwd")
+                                     gq2d.stride(0), ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_layernorm_lsq_bwd")
+    if am is not None:
+        tag_amax(dx, am)
     return dx, dg, db, db4, ds, dba
 
 

@@ -456,7 +456,9 @@ def test_qmlp_lsq_backward_in_dx_gemm_epilogue(env, dims):
         return {"y": y.detach().clone(), "dx": xg.grad.clone(), **{n: p.grad.clone() for n, p in q.named_parameters()
                                                                   if p.grad is not None}}
 
-    prev = ql.FUSE_LSQ_BWD
+    from ofq_amd import ops as _ops
+    prev, prev_planes = ql.FUSE_LSQ_BWD, _ops.GRAD_PLANES
+    _ops.GRAD_PLANES = 3        # the fused epilogue exists for the three-plane form (bf16 weight codes) only
     try:
         ql.FUSE_LSQ_BWD = True
         fused = run()
@@ -464,6 +466,7 @@ def test_qmlp_lsq_backward_in_dx_gemm_epilogue(env, dims):
         plain = run()
     finally:
         ql.FUSE_LSQ_BWD = prev
+        _ops.GRAD_PLANES = prev_planes
     assert fused.keys() == plain.keys()
     assert torch.equal(fused["y"], plain["y"])
     if C > 128:

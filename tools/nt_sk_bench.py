@@ -16,6 +16,8 @@ torch.manual_seed(0)
 
 def operands(o, c):
     dy = torch.randn(M, o, device="cuda") * 1e-3 * torch.logspace(-4, 0, M, device="cuda")[torch.randperm(M, device="cuda")].unsqueeze(1)   # rows over 4 decades
+    if os.environ.get("DYN"):       # element-wise dynamic range of DYN decades (what real gradient tensors look like)
+        dy = torch.randn(M, o, device="cuda") * 1e-3 * torch.pow(10.0, -float(os.environ["DYN"]) * torch.rand(M, o, device="cuda"))
     qw = (2 * torch.randint(-2, 2, (o, c), device="cuda") + 1).to(torch.int8)
     wT = ops.codes_transpose_16(qw)       # fp16 codes (two-plane form) unless OFQ_GRAD_PLANES=3
     ks = torch.rand(o, device="cuda") + 0.5
