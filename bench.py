@@ -37,7 +37,7 @@ PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
          "qgemm_i8": 5000.0,       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
          "qattn_scores_softmax": 5000.0,   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
          "qattn_dp_softmax_bwd": 2500.0}   # (fused dP GEMM + softmax backward: VALU / HBM-bound)
-PROFILE_JSON = "r04_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
+PROFILE_JSON = "r05_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
 
 
 def parse():
@@ -399,12 +399,13 @@ def main():
                 pass
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    # the bf16-split kernels issue three bf16 MFMA FMAs per algorithmic FMA (what makes them fp32-exact)
-                    "mfma_pipe_frac": round((3.0 if name.startswith("qgemm_bf16s") else 1.0) * achieved / peak, 4),
+                    # the split kernels issue two fp16 (round 5) or three bf16 MFMA FMAs per algorithmic FMA
+                    "mfma_pipe_frac": round((2.0 if "2x v_mfma" in name else 3.0 if name.startswith("qgemm_bf16s") else 1.0) * achieved / peak, 4),
                     "mfma_util_pmc": mfma_util,
                     "note": "achieved = algorithmic 2*M*N*K of the launches / HIP-event time of the launches, over a second, "
                             "instrumented pass of the same --steps steps (the throughput pass carries no events: they cost "
-                            "2-4 ms/step); for the bf16-split kernels every algorithmic FMA is 3 bf16 MFMA FMAs (fp32-exact); traffic = "
+                            "2-4 ms/step); the split kernels issue 2 fp16 (fp32-grade on the tensor's scale, ops.GRAD_PLANES = 2) or 3 bf16 (exact "
+                            "fp32 product) MFMA FMAs per algorithmic FMA -- see the class name; traffic = "
                             "bytes per launch, 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes: " + traffic_note,
                     "launches_per_step": sm["launches"] / args.steps, "avg_launch_ms": round(sm["avg_ms"], 4),
                     "avg_gflop_per_launch": round(sm["avg_units"] / 1e9, 3),

@@ -424,7 +424,8 @@ class WqkFn(torch.autograd.Function):
         C = Wq.shape[1]
         d = Wq.shape[0] // H
         out = torch.empty((H * C, C), dtype=torch.float32, device=Wq.device)
-        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0))
+        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
         ctx.save_for_backward(Wq, Wk)
         ctx.H = H
         return out
@@ -463,7 +464,9 @@ class AllWqkFn(torch.autograd.Function):
         C = Wq.shape[2]
         d = Wq.shape[1] // H
         out = torch.empty((L, H * C, C), dtype=torch.float32, device=Wq.device)
-        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=L * H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0))
+        # (K = d = 64: 64 x 64 tiles -- the 128 x 128 default takes 185 us for the 72 products of DeiT-S, tools/wqk_bench.py)
+        ops.gemm(Wq, Wk, out, C, C, d, C, C, C, transA=True, nb0=L * H, sA=(d * C, 0), sB=(d * C, 0), sC=(C * C, 0),
+                 tile_hint=64 if d <= 64 else 0)
         ctx.save_for_backward(Wq, Wk)
         ctx.H = H
         ctx.set_materialize_grads(False)

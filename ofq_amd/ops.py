@@ -541,7 +541,13 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
 
 
 # ---- stream-K input-gradient GEMM (ofq_qgemm_bf16s_nt_sk) ----------------------------------------------------------------
-NT_CLASS = 'qgemm_bf16s_nt_wide (linear dX, 3x v_mfma_f32_32x32x16_bf16)'      # bench.py's timer class of the dX GEMMs
+def _pl(two):
+    """What a backward code GEMM issues per algorithmic multiply-add: two fp16 products (round 5) or three bf16 ones."""
+    return "2x v_mfma_f32_32x32x16_f16" if two else "3x v_mfma_f32_32x32x16_bf16"
+
+
+def nt_class(two):
+    return 'qgemm_bf16s_nt_wide (linear dX, %s)' % _pl(two)      # bench.py's timer class of the dX GEMMs
 NT_SK = os.environ.get("OFQ_NT_SK", "1") != "0"          # A/B switch: "0" = always the one-tile-per-workgroup kernel
 _NT_SK_FORCE = os.environ.get("OFQ_NT_SK") == "force"   # test hook: stream-K for every shape it accepts
 _sk_ws = {}
@@ -646,7 +652,7 @@ def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
         K += A.shape[1]
     ws = _sk_workspace(dev)
     g = num_cus(dev) if wgs is None else -int(wgs)        # wgs: exactly that many workgroups (<= the CU count; tests)
-    with _Timed(NT_CLASS, 2.0 * M * N * K):
+    with _Timed(nt_class(f16), 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt_sk(arr, len(segs), out.data_ptr(), int(accumulate), M, N, out.stride(0), g, ws.data_ptr(),
                                          ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_sk")
     return out
@@ -694,7 +700,7 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     if (nsplit == 3 or f16) and sk_able and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
         return qgemm_bf16s_nt_sk([(A, B_bf16, k_scale, alpha)], out, accumulate)
     amax = amax_for(A) if f16 else None
-    with _Timed(NT_CLASS, 2.0 * M * N * K):
+    with _Timed(nt_class(f16), 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
                                       2 if f16 else nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _p(amax), _stream()),
              "ofq_qgemm_bf16s_nt")
@@ -747,7 +753,7 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
     amax = _planes_amax(dy2d, planes)
-    with _Timed('qgemm_bf16s_tn_wide (linear dW, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * Ktok * M * N):
+    with _Timed('qgemm_bf16s_tn_wide (linear dW, %s)' % _pl(amax is not None), 2.0 * Ktok * M * N):
         _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
                                       _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
                                       split, ws.data_ptr(), ws.numel(), _p(amax), _stream()), "ofq_qgemm_bf16s_tn")
@@ -805,7 +811,7 @@ def qgemm_bf16s_tn_group(jobs, split=None, planes=None):
         split = max(1, min(256 // tiles, nkt // 4))
     dev = jobs[0]["dy2d"].device
     ws = workspace(lib().ofq_qgemm_bf16s_tn_group_ws_bytes(arr, n, split), dev)
-    with _Timed('qgemm_bf16s_tn_wide_group (linear dW of a block, 3x v_mfma_f32_32x32x16_bf16)', flops):
+    with _Timed('qgemm_bf16s_tn_wide_group (linear dW of a block, %s)' % _pl(keep[0] is not None), flops):
         _chk(lib().ofq_qgemm_bf16s_tn_group(arr, n, split, ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_tn_group")
 
 
@@ -964,7 +970,7 @@ def scores_amax(dS, N, planes=None):
 def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS, planes=None):
     dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
     amax = scores_amax(dS, N, planes) if "dqkx" in _DBG_F16 else None
-    with _Timed('qgemm_bf16s_tn_wide_stream (attention dqkx, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+    with _Timed('qgemm_bf16s_tn_wide_stream (attention dqkx, %s)' % _pl(amax is not None), 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
                                         ldS, _p(amax), _stream()), "ofq_qattn_dqkx_bf16s")
     return dq
@@ -974,7 +980,7 @@ def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False, p
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
     amax = scores_amax(dS, N, planes) if "dxq" in _DBG_F16 else None
-    with _Timed('qgemm_bf16s_nn_wide (attention dxq, 3x v_mfma_f32_32x32x16_bf16)', 2.0 * B * H * N * N * C):
+    with _Timed('qgemm_bf16s_nn_wide (attention dxq, %s)' % _pl(amax is not None), 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
                                        H, N, C, ldS, _p(amax), _stream()), "ofq_qattn_dxq_bf16s")
     return out
