@@ -175,10 +175,12 @@ int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, co
  *            The launch scales A*k_scale by the power of two that puts its largest magnitude into [2^14, 2^15), splits it into
  *            hi = rne_f16(x), lo = rne_f16(x - hi) -- |x - hi - lo| <= 2^-24 |x| for elements within 2^-17 of the maximum,
  *            <= 2^-39 of the maximum below -- and un-scales in the epilogue: fp32-grade on the scale of the tensor with two
- *            matrix-core products per element instead of three (reference op: autograd of F.linear, qlinear.py:69). */
+ *            matrix-core products per element instead of three (reference op: autograd of F.linear, qlinear.py:69).
+ *            col_scale / col_bias (optional, N > 128): C[m,n] = col_scale[n] * alpha * (...) + col_bias[n] -- the FORWARD of a
+ *            layer whose weight is step[n] * code[n,k] on fp32 activations (the W8A8 patch embedding, qlinear.py:166-177). */
 int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha, int accumulate,
                        int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* amax,
-                       ofq_stream_t stream);
+                       const float* col_scale, const float* col_bias, ofq_stream_t stream);
 /*  stream-K form of the same product, for shapes whose 128 x 384 tiles do not fill the chip (M = 25 344 tokens: 198 row
  *            tiles on 256 CUs): `num_wgs` workgroups (pass the CU count) share the tiles x k-steps of the launch evenly, each walking its share as one continuous k-step stream;
  *            a tile cut by a share boundary is finished by the workgroup holding its k = 0 piece, which adds the other

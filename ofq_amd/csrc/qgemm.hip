@@ -3513,6 +3513,14 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 
   if constexpr (!LSQ) {
     const float alpha_e = p.alpha * inv_sE;
+    // optional per-column scale and bias (the W8A8 stem's forward: C = cs[n] * (A . codes^T) + bias[n]; p.cs / p.bias)
+    float csv[NJ], cbv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nc = min(n0 + wn * 32 * NJ + j * 32 + l31, p.N - 1);
+      csv[j] = p.cs ? p.cs[nc] * alpha_e : alpha_e;
+      cbv[j] = p.bias ? p.bias[nc] : 0.f;
+    }
     // interior tiles (every tile of the DeiT shapes): uniform tile base + one 32-bit lane offset per access, no
     // per-element bounds checks (each one is an exec-mask branch around a single store)
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
@@ -3536,7 +3544,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
           for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-              const float v = acc[i][j][eb * 4 + ee] * alpha_e;
+              const float v = acc[i][j][eb * 4 + ee] * csv[j] + cbv[j];
               Cs[mlb + ee * ldc + j * 32] = p.accumulate ? v + old[ee][j] : v;
             }
         }
@@ -3550,7 +3558,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[i][j][e] * alpha_e;
+            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[i][j][e] * csv[j] + cbv[j];
           }
       }
     } else {
@@ -3580,7 +3588,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
             const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lh;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * alpha_e + old[ee][j];
+              if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = (acc[i][j][eb * 4 + ee] * csv[j] + cbv[j]) + old[ee][j];
           }
         }
     }
@@ -3668,20 +3676,21 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 
 extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, const float* k_scale, float alpha,
                                   int accumulate, int nsplit, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                                  int64_t ldc, const void* amax, ofq_stream_t stream) {
+                                  int64_t ldc, const void* amax, const float* col_scale, const float* col_bias,
+                                  ofq_stream_t stream) {
   if (!A || !B_bf16 || !C || M <= 0 || N <= 0 || K <= 0) return OFQ_EINVAL;
   if ((K & 7) || (lda & 3) || (ldb & 7) || !al16(A) || !al16(B_bf16) || (k_scale && !al16(k_scale)) || M >= (1ll << 30) ||
       N >= (1ll << 30) || (nsplit != 2 && nsplit != 3) || (amax && nsplit != 2))
     return OFQ_EINVAL;
   QGemmArgs a = {};
-  a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale; a.amax = (const unsigned*)amax;
+  a.A = A; a.B = B_bf16; a.C = C; a.s = k_scale; a.amax = (const unsigned*)amax; a.cs = col_scale; a.bias = col_bias;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.alpha = alpha; a.accumulate = accumulate; a.nb1 = 1;
   static const bool narrow_only = getenv("OFQ_NT_NARROW") != nullptr;      // A/B switch for tools/tn_bench.py
   const int nj = N > 256 ? 3 : 2;
   // few rows (late Swin stages): 128-column tiles of the 4-wave kernel give 2-3x more workgroups, which matters more than
   // the shared split (measured: 185 vs 207 us at M=6272, N=768, K=3072; an 8-wave 128x128 variant lost to it as well)
-  const bool too_few = (int64_t)a.tiles_m * ceil_div(N, 128 * nj) < 160 && (int64_t)a.tiles_m * a.tiles_n >= 192;
+  const bool too_few = (int64_t)a.tiles_m * ceil_div(N, 128 * nj) < 160 && (int64_t)a.tiles_m * a.tiles_n >= 192 && !col_scale && !col_bias;
   if ((nsplit == 3 || amax) && N > 128 && !narrow_only && !too_few) {      // wide tiles: the dY panel is split once per 384 (256) columns
     a.tiles_n = (int)ceil_div(N, 128 * nj);
     dim3 gridw((unsigned)(a.tiles_m * a.tiles_n));
@@ -3695,6 +3704,7 @@ extern "C" int ofq_qgemm_bf16s_nt(const float* A, const void* B_bf16, float* C, 
     OFQ_LAUNCH_CHECK();
     return 0;
   }
+  if (col_scale || col_bias) return OFQ_EINVAL;      // the column epilogue exists in the wide kernels only (N > 128)
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   if (amax) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<2, false, 1, 5, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (nsplit == 3) hipLaunchKernelGGL((qgemm_bf16s_nt_kernel<3, false>), grid, dim3(256), 0, (hipStream_t)stream, a);

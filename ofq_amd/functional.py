@@ -42,6 +42,69 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(ctx.in_shape) if dx is not None else None), dW, db
 
 
+class CodeWeightLinearFn(torch.autograd.Function):
+    """LinearFn for a layer whose fake-quantised weight is step[n] * integer code (the W8A8 patch embedding, qlinear.py:166-177:
+    LSQ weights; 25 088 x 768 x 384 for DeiT: 173 / 198 / 178 us as fp32 GEMMs).  Forward and input gradient run as code GEMMs
+    of the linear layers' kind, and with `xaux` (the image quantiser's int8 codes) the weight gradient as well,
+        y[m, n]  = step[n] * sum_k x[m, k] * code[n, k] + bias[n]  (ofq_qgemm_bf16s_nt with col_scale / col_bias: x split)
+        dx[m, k] = sum_n (dy[m, n] * step[n]) * code[n, k]         (ofq_qgemm_bf16s_nt: dy split, k-scale = steps)
+    -- the products the fp32 GEMMs form with W_hat[n, k] = step[n] * code[n, k], up to fp32 rounding of that factorisation."""
+
+    @staticmethod
+    def forward(ctx, xq, Wq, bias, codes, steps, xaux=None):
+        x2d = xq.reshape(-1, xq.shape[-1])
+        N, K = codes.shape
+        ctx.xaux = xaux
+        if N > 128 and K % 8 == 0 and x2d.is_contiguous():
+            # y = steps[n] * (x . code[n, :]) + bias[n]: the activations as planes (two fp16 / three bf16) against the codes
+            c16 = codes.to(torch.float16 if ops.GRAD_PLANES == 2 else torch.bfloat16)
+            y = ops.qgemm_bf16s_nt(x2d, c16, None, 1.0, col_scale=steps, col_bias=bias)
+        else:
+            y = ops.linear_fwd(x2d, Wq, bias)
+        ctx.save_for_backward(x2d, codes, steps)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = xq.shape
+        return y.view(*xq.shape[:-1], Wq.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, codes, steps = ctx.saved_tensors
+        am = ops.amax_of(dy)                       # (the producer's maximum word survives the copy below)
+        dy2d = dy.reshape(-1, dy.shape[-1])
+        if not dy2d.is_contiguous():
+            dy2d = dy2d.contiguous()
+        if am is not None and ops.amax_of(dy2d) is None:
+            ops.tag_amax(dy2d, am)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.qgemm_bf16s_nt(dy2d, ops.codes_transpose_16(codes), steps, 1.0).view(ctx.in_shape)
+        dW = db = None
+        xa = ctx.xaux
+        if ctx.needs_input_grad[1] and xa is not None:
+            # x_hat[m, k] = ax[k] * qx[m, k] + boff[m % P, k] (P = rows sharing one offset pattern: the patches of an image):
+            #   dW[n, k] = ax[k] * sum_m dy[m, n] qx[m, k]  +  sum_p (sum_b dy[b P + p, n]) * boff[p, k]
+            # the first sum is the code GEMM of the linear layers' weight gradients (its column sums of dy are the bias gradient),
+            # the second a (N x P) . (P x K) product of the batch-summed gradient
+            ones = xa["ones"]
+            dWc, db = ops.qgemm_bf16s_tn(dy2d, xa["qx"], ones, ones.numel(), 0.0, None, None, compute_db=True)
+            dW = dWc.mul_(xa["ax"])
+            P = xa["boff"].shape[0]
+            dys = ops.colsum(dy2d.view(-1, P * dy2d.shape[1])).view(P, dy2d.shape[1])
+            ops.gemm(dys, xa["boff"], dW, dW.shape[0], dW.shape[1], P, dys.stride(0), xa["boff"].stride(0), dW.stride(0), transA=True,
+                     accumulate=True)
+            if not (ctx.has_bias and ctx.needs_input_grad[2]):
+                db = None
+        else:
+            dW = ops.linear_bwd_weight(dy2d, x2d) if ctx.needs_input_grad[1] else None
+            db = ops.colsum(dy2d) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dW, db, None, None, None
+
+
+def code_weight_linear_ok(out_features, in_features, quant):
+    """codes in int8 and shapes the code GEMM takes (K = out_features % 8, N = in_features)"""
+    return out_features % 8 == 0 and in_features % 4 == 0 and quant.thd_neg >= -128 and quant.thd_pos <= 127
+
+
 # attention scores backward: also add the (mathematically zero) row-sum term of dx_hat, as the reference's autograd does
 KEEP_ZERO_ROWSUM_TERM = os.environ.get("OFQ_KEEP_ZERO_ROWSUM_TERM", "0") == "1"
 

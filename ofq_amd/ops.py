@@ -686,7 +686,7 @@ def nt_sk_pays(M, N, K, device):
     return bool(lib().ofq_qgemm_bf16s_nt_sk_pays(M, N, K, num_cus(device)))
 
 
-def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3, sk=None):
+def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit=3, sk=None, col_scale=None, col_bias=None, amax=None):
     """out[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k],  A fp32, B bf16 integer codes
     sk: None = stream-K where it pays (ofq_qgemm_bf16s_nt_sk_pays), False / True = never / always"""
     M, K = A.shape
@@ -697,12 +697,18 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
     # one-tile-per-workgroup kernel also when sk=True)
     sk_able = N > 128 and K % 64 == 0 and M * A.stride(0) * 4 < 2 ** 32 and N * B_bf16.stride(0) * 2 < 2 ** 32
     f16 = B_bf16.dtype == torch.float16                # fp16 codes: the two-plane form (ops.GRAD_PLANES == 2 hands these out)
+    if col_scale is not None or col_bias is not None:
+        sk = False                                   # (the per-column epilogue lives in the one-tile-per-workgroup kernel)
     if (nsplit == 3 or f16) and sk_able and (sk if sk is not None else nt_sk_pays(M, N, K, A.device)):
         return qgemm_bf16s_nt_sk([(A, B_bf16, k_scale, alpha)], out, accumulate)
-    amax = amax_for(A) if f16 else None
+    if f16 and amax is None:
+        amax = amax_for(A)
+    if not f16:
+        amax = None
     with _Timed(nt_class(f16), 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
-                                      2 if f16 else nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _p(amax), _stream()),
+                                      2 if f16 else nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _p(amax),
+                                      _p(col_scale), _p(col_bias), _stream()),
              "ofq_qgemm_bf16s_nt")
     return out
 

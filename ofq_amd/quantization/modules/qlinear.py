@@ -12,7 +12,9 @@ from ..quantizer.statsq import StatsQuantizer
 from ..quantizer.lsq import (LsqQuantizer, LsqQuantizerWeight, LsqQuantizer4img, LsqQuantizer4Conv2d,
                              LsqQuantizer4head_input)
 from ...deit_vision_transformer import Mlp, to_2tuple
-from ...functional import LinearFn, codes_linear, codes_linear_ok, codes_only_ok
+from ... import ops
+from ...functional import (LinearFn, codes_linear, codes_linear_ok, codes_only_ok, CodeWeightLinearFn,
+                           code_weight_linear_ok)
 
 
 # Exact integer-code GEMMs (int8 forward, bf16-split dX) instead of the fp32-MFMA GEMM on fake-quant values.
@@ -206,14 +208,43 @@ class LSQ_QConv2d(nn.Conv2d):
             raise ValueError("LSQ_QConv2d: only the non-overlapping patch-embedding conv is on the hot path")
 
     def forward(self, input):
-        weight = self.lsqw_fn(self.weight)                                       # qlinear.py:168
-        xq = self.input_quant_fn.quant(input, self.move_b4.bias, self.move_aft.bias)   # :171-173
+        K = self.weight[0].numel()
+        code_dx = (USE_CODE_GEMM and input.is_cuda and torch.is_grad_enabled() and self.lsqw_fn.initialized_alpha
+                   and code_weight_linear_ok(self.out_channels, K, self.lsqw_fn))
+        if code_dx:
+            # W_hat = step[o] * code[o, k]: the codes (int8) feed the two-plane code GEMM of the input gradient
+            weight, wcodes, wgeom = self.lsqw_fn.quant(self.weight, want_codes=True)      # qlinear.py:168
+        else:
+            weight = self.lsqw_fn(self.weight)                                   # qlinear.py:168
+        xin = self.input_quant_fn
+        # the weight gradient on the image quantiser's codes as well: int8 codes (a signed, latched quantiser), geometry the
+        # wide dW kernel takes
+        code_dw = (code_dx and xin.initialized_alpha and xin.s is not None and xin.latched() and xin.bit <= 8
+                   and K % 384 == 0 and self.out_channels % 4 == 0 and self.weight.requires_grad)
+        xcodes = None
+        if code_dw:
+            xq, xcodes, xgeom = xin.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=True)   # :171-173
+        else:
+            xq = xin.quant(input, self.move_b4.bias, self.move_aft.bias)          # :171-173
         B, Cin, Hh, Ww = xq.shape
         kh, kw = self.kernel_size
         gh, gw = Hh // kh, Ww // kw
         # im2col of a stride==kernel conv is a pure permutation: (B, gh*gw, Cin*kh*kw)
         cols = xq.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
-        out = LinearFn.apply(cols, weight.view(self.out_channels, -1), self.bias)      # :174
+        if code_dx:
+            steps = ops.lsq_eff_scale(self.lsqw_fn.s.detach(), wgeom.gscale)      # the step VALUE the fake-quant weights carry
+            xaux = None
+            if xcodes is not None and xin.thd_neg >= -128 and xin.thd_pos <= 127:
+                qx = xcodes.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
+                ax = ops.lsq_eff_scale(xin.s.detach(), xgeom.gscale).repeat_interleave(kh * kw)               # step of column k
+                boff = self.move_aft.bias.detach().view(gh, kh, gw, kw).permute(0, 2, 1, 3).reshape(gh * gw, kh * kw).repeat(1, Cin)
+                if getattr(self, "_ones32", None) is None or self._ones32.device != input.device:
+                    self._ones32 = torch.ones(32, dtype=torch.float32, device=input.device)
+                xaux = {"qx": qx, "ax": ax, "boff": boff.contiguous(), "ones": self._ones32}
+            out = CodeWeightLinearFn.apply(cols, weight.view(self.out_channels, -1), self.bias, wcodes.view(self.out_channels, K),
+                                           steps, xaux)                          # :174
+        else:
+            out = LinearFn.apply(cols, weight.view(self.out_channels, -1), self.bias)      # :174
         return out.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
 
     def extra_repr(self):

@@ -152,6 +152,37 @@ def test_stem_and_head_golden(env):
     _run(q, g, T(det_normalish((B, I), seed, 1.0)))
 
 
+def test_stem_input_gradient_on_the_code_gemm_equals_the_fp32_gemm(env):
+    """LSQ_QConv2d at the DeiT-S width (qlinear.py:166-177): the input gradient through ofq_qgemm_bf16s_nt on the LSQ weight
+    codes and the forward on the same codes (functional.CodeWeightLinearFn) against the fp32-MFMA GEMMs on the fake-quant
+    weights: output and every gradient to 2e-6."""
+    from ofq_amd.quantization.modules import qlinear as ql
+    torch.manual_seed(4)
+    q = ql.LSQ_QConv2d(m=nn.Conv2d(3, 384, kernel_size=16, stride=16), weight_bits=8, input_bits=8, weight_quant_method="lsq",
+                       input_quant_method="lsq", pretrained_initialized=True).cuda().train()
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        q(x)
+        q.move_b4.bias.uniform_(-0.05, 0.05)
+        q.move_aft.bias.uniform_(-0.05, 0.05)
+    w = torch.randn(4, 384, 14, 14, device="cuda")
+    res = {}
+    prev = ql.USE_CODE_GEMM
+    try:
+        for mode in (True, False):
+            ql.USE_CODE_GEMM = mode
+            for p in q.parameters():
+                p.grad = None
+            y = q(x)
+            (y * w).sum().backward()
+            res[mode] = {"y": y.detach().clone(), **{n: p.grad.clone() for n, p in q.named_parameters() if p.grad is not None}}
+    finally:
+        ql.USE_CODE_GEMM = prev
+    assert res[True].keys() == res[False].keys() and len(res[True]) >= 6
+    for n in res[True]:
+        assert rel_err(res[True][n].cpu(), res[False][n].cpu()) < 2e-6, n
+
+
 def _qconfigs(names, wb, ab):
     return {n: {"weight": {"mode": "statsq", "bit": wb, "all_positive": False, "symmetric": True, "per_channel": True,
                            "normalize_first": False, "learnable": True},
