@@ -217,6 +217,11 @@ class LSQ_QConv2d(nn.Conv2d):
         else:
             weight = self.lsqw_fn(self.weight)                                   # qlinear.py:168
         xin = self.input_quant_fn
+        if xin.initialized_alpha and not xin.latched() and not torch.cuda.is_current_stream_capturing():
+            # the signedness latch (lsq.py:338-355) is taken HERE, before the choice below reads it: quant() would take it a
+            # moment later, and the step in which it flips would pick another weight-gradient kernel than the captured step
+            # that engine.GraphedTrainStep re-captures for the same batch
+            xin._latch(xin.latch_input(input, self.move_b4.bias))
         # the weight gradient on the image quantiser's codes as well: int8 codes (a signed, latched quantiser), geometry the
         # wide dW kernel takes
         code_dw = (code_dx and xin.initialized_alpha and xin.s is not None and xin.latched() and xin.bit <= 8
