@@ -77,7 +77,7 @@ def test_every_block_and_merging_layer_of_swin_t_teacher_forced():
     assert sum(k == "block" for k, *_ in layers) == 12 and sum(k == "merge" for k, *_ in layers) == 3
     mods = dict(model.named_modules())
     gen = torch.Generator().manual_seed(7)
-    clean, rows = 0, []
+    clean, rows, explained = 0, [], []
     for kind, pre, si, li, xin in layers:
         hip = mods[pre[:-1]]
         p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "clip_val" not in k) for k, v in O._sub(sd, pre).items()}
@@ -106,11 +106,27 @@ def test_every_block_and_merging_layer_of_swin_t_teacher_forced():
         ok = flips == 0 and max(errs.values()) < TOL
         clean += int(ok and kind == "block")
         rows.append((pre, flips, l2_rest, _l2(yh, yo), max(errs.values()), max(errs, key=errs.get)))
+        if flips == 0 and not ok and kind == "block":
+            # A flip-free block with a gradient off by more than 1e-3 (round 4 left two of them unexplained: 5e-3 / 6e-3 on a
+            # step size).  The same block through the oracle in FP64: if the fp32 oracle is as far from fp64 as the HIP path
+            # is, the deviation is the fp32 rounding of an ill-conditioned sum -- d(step) = sum_i g_i (q_i - v_i) over 10^5-10^6
+            # elements of either sign, whose total is orders of magnitude below sum_i |g_i (q_i - v_i)| -- and no
+            # implementation of the reference in fp32 pins it.  
+            worst = max(errs, key=errs.get)
+            p64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v) for k, v in p.items()}
+            x64 = xin.double().requires_grad_(True)
+            (_oracle_block(x64, p64, cfg, si, li) * up.double()).sum().backward()
+            g64 = p64[worst].grad
+            e_hip, e_o32 = _l2(dict(hip.named_parameters())[worst].grad, g64), _l2(p[worst].grad, g64)
+            explained.append((pre, worst, errs[worst], e_hip, e_o32))
+            assert e_hip <= 3.0 * e_o32 + TOL, (pre, worst, errs[worst], e_hip, e_o32)
         if kind == "merge":                   # LayerNorm + one quantised linear layer: no attention to spread a flip
             assert flips <= 8 and _l2(yh, yo) < 5e-3, rows[-1]
     print("\nSwin-T W3A3 QKR: layer, tokens touched by a flip, l2(y) on the rest, l2(y) overall, worst gradient l2 (which)")
     for r in rows:
         print("   %-16s %4d  %.2e  %.2e  %.2e  %s" % r)
+    for r in explained:
+        print("   flip-free, gradient > 1e-3: %s %s  HIP vs fp32 oracle %.2e | HIP vs fp64 oracle %.2e | fp32 oracle vs fp64 oracle %.2e" % r)
     assert clean >= 6, rows
 
 
