@@ -382,7 +382,7 @@ def linear_bwd_weight(dy, x2d):
 # It decides the format of the TRANSPOSED weight codes the quantisers keep (fp16 / bf16); the GEMM wrappers below follow
 # the dtype of the codes they are handed, so tests can drive either form explicitly.
 GRAD_PLANES = 3 if os.environ.get("OFQ_GRAD_PLANES") == "3" else 2
-_DBG_F16 = set(os.environ.get("OFQ_DEBUG_F16", "dx,dw,dqkx,dxq").split(","))      # (debugging: which GEMM families may take the two-plane form)
+_DBG_F16 = {"dx", "dw", "dqkx", "dxq"}      # which GEMM families take the two-plane form (tools/two_rank_determinism.py narrows it)
 
 
 def codes_transpose_bf16(codes):
