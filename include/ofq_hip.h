@@ -262,6 +262,9 @@ int ofq_codes_transpose_f16(const int8_t* codes, void* out_f16, int64_t rows, in
  *            (autograd of F.linear, qlinear.py:69) for gradient tensors whose producer did not write the word itself.
  *            cols % 4 == 0, ld % 4 == 0, x 16-byte aligned. */
 int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* amax, ofq_stream_t stream);
+/*  out[i * repeat + r] = the effective LSQ step (a - a g) + a g, a = max(s[i], 1e-5) (lsq.py:6-18, grad_scale's value form) for
+ *            i < n, r < repeat: the step vectors the W8A8 patch embedding (qlinear.py:166-177) hands to the code GEMMs */
+int ofq_lsq_eff_scale_vec(const float* s, float gscale, float* out, int64_t n, int64_t repeat, ofq_stream_t stream);
 int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols, ofq_stream_t stream);
 
 /* ---- attention products on the integer codes (QAttention_qkreparam.forward attention.py:200-219 and autograd).

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ofq_codes_transpose_bf16": (i32, [vp, vp, i64, i64, vp]),
     "ofq_codes_transpose_f16": (i32, [vp, vp, i64, i64, vp]),
     "ofq_absmax_f32": (i32, [vp, i64, i64, i64, vp, vp]),
+    "ofq_lsq_eff_scale_vec": (i32, [vp, f32, vp, i64, i64, vp]),
     "ofq_rowdot_i8": (i32, [vp, vp, vp, i64, i64, vp]),
     "ofq_qattn_scores_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_qattn_scores_plain_i8": (i32, [vp, vp, vp, vp, f32, vp, f32, vp, vp, vp, i64, i64, i64, i64, i64, vp]),

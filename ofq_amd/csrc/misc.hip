@@ -279,6 +279,22 @@ extern "C" int ofq_absmax_f32(const float* x, int64_t rows, int64_t cols, int64_
   return 0;
 }
 
+// ---- effective LSQ steps as a vector: out[i * repeat + r] = (a - a g) + a g, a = max(s[i], 1e-5)  (lsq.py:6-18: the VALUE the
+// quantiser kernels divide and multiply by).  The W8A8 patch embedding hands its weight steps (as column scale / k-scale) and its
+// per-channel image steps (one per im2col column: repeat = kh * kw) to the code GEMMs; one launch instead of six ATen ones.
+__global__ __launch_bounds__(256) void lsq_eff_scale_vec_kernel(const float* __restrict__ s, float gscale, float* __restrict__ out,
+                                                                int64_t n, int repeat) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n * repeat) out[i] = ofq_lsq_eff_scale(s[i / repeat], gscale);
+}
+extern "C" int ofq_lsq_eff_scale_vec(const float* s, float gscale, float* out, int64_t n, int64_t repeat, ofq_stream_t stream) {
+  if (!s || !out || n <= 0 || repeat <= 0 || repeat >= (1ll << 30) || n * repeat >= (1ll << 40)) return OFQ_EINVAL;
+  hipLaunchKernelGGL(lsq_eff_scale_vec_kernel, dim3((unsigned)ceil_div(n * repeat, 256)), dim3(256), 0, (hipStream_t)stream, s, gscale, out,
+                     n, (int)repeat);
+  OFQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- KD loss of the shipped recipes, forward and gradients in one pass ------------------------------------------------------------
 // KDLossSoftandHard (src/quantization/utils.py:59-77, `--kd_hard_and_soft 1`):
 //   loss = mean_b( -sum_k softmax(t_b)[k] * log_softmax(d_b)[k] ) + mean_b( -log_softmax(c_b)[y_b] )

@@ -427,6 +427,9 @@ class CodesLinearFn(torch.autograd.Function):
             # dY also yields the bias gradient (column sums)
             xc2 = aux["xcodes"].view(-1, K_in)
             slot = _parallel.grad_slot(aux.get("w_leaf"))
+            if slot is None and aux.get("w_grad_out") is not None and not aux["w_grad_out_used"][0]:
+                slot = aux["w_grad_out"]           # (W_qk: its slice of AllWqkFn's gradient buffer; one writer per backward)
+                aux["w_grad_out_used"][0] = True
             # a queued result is still unwritten when autograd accumulates it: that is only sound when accumulating means
             # adopting the tensor (no gradient there yet), never adding to one
             w_leaf, b_leaf = aux.get("w_leaf"), ctx.bias_leaf
@@ -475,7 +478,8 @@ def codes_linear(xq, xcodes, geom, act_quant, baft, weight, wquant, bias, fuse=N
            "act_s": act_quant.s.detach(), "act_S": geom.S, "act_gscale": geom.gscale, "fuse": fuse, "lsq_link": lsq_link, "xgrad_acc": xgrad_acc,
            # StatsQ's backward is the identity (statsq.py:148), so dW of a leaf weight IS its .grad: see parallel.grad_slot
            "w_leaf": weight if (weight.is_leaf and weight.requires_grad) else None,
-           "w_flushes": bool(getattr(weight, "_ofq_flushes", False))}
+           "w_flushes": bool(getattr(weight, "_ofq_flushes", False)),
+           "w_grad_out": getattr(weight, "_ofq_grad_out", None), "w_grad_out_used": [False]}
     return CodesLinearFn.apply(xq, Wq, bias, aux)
 
 
@@ -533,6 +537,10 @@ class AllWqkFn(torch.autograd.Function):
         ctx.save_for_backward(Wq, Wk)
         ctx.H = H
         ctx.set_materialize_grads(False)
+        # one buffer for the L gradients that come back: the dW GEMMs of the W_qk layers write their slices of it directly
+        # (all_wqk hands the slices out as `_ofq_grad_out`), and the backward below reads it without a 42 MB torch.stack
+        ctx.gbuf = torch.empty((L, H * C, C), dtype=torch.float32, device=Wq.device)
+        _WQK_GBUF[0] = ctx.gbuf
         return tuple(out.unbind(0))
 
     @staticmethod
@@ -542,7 +550,11 @@ class AllWqkFn(torch.autograd.Function):
         H = ctx.H
         L, _, C = Wq.shape
         d = Wq.shape[1] // H
-        g = torch.stack([gi if gi is not None else torch.zeros((H * C, C), dtype=Wq.dtype, device=Wq.device) for gi in gs])
+        gb = getattr(ctx, "gbuf", None)
+        if gb is not None and all(gi is not None and gi.data_ptr() == gb[l].data_ptr() and gi.is_contiguous() for l, gi in enumerate(gs)):
+            g = gb                     # every block's dW GEMM wrote its slice in place
+        else:
+            g = torch.stack([gi if gi is not None else torch.zeros((H * C, C), dtype=Wq.dtype, device=Wq.device) for gi in gs])
         dWq = torch.empty_like(Wq)
         dWk = torch.empty_like(Wk)
         ops.gemm(Wk, g, dWq, d, C, C, C, C, C, transB=True, nb0=L * H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
@@ -555,6 +567,7 @@ class AllWqkFn(torch.autograd.Function):
         return tuple(grads)
 
 
+_WQK_GBUF = [None]                 # AllWqkFn.forward -> all_wqk: the gradient buffer of the products just formed
 BULK_WQK = os.environ.get("OFQ_NO_BULK_WQK", "0") != "1"
 STEP_CACHE_ACTIVE = False          # set by engine.train_step around the forward (see engine.refresh_weight_codes)
 
@@ -573,8 +586,11 @@ def all_wqk(attns):
     for a in attns:
         ws += [a.q.weight, a.k.weight]
     outs = AllWqkFn.apply(a0.num_heads, *ws)
-    for a, w in zip(attns, outs):
+    gbuf, _WQK_GBUF[0] = _WQK_GBUF[0], None
+    for l, (a, w) in enumerate(zip(attns, outs)):
         w._ofq_flushes = True              # AllWqkFn.backward flushes the dW queue before it reads this tensor's gradient
+        if gbuf is not None and torch.is_grad_enabled():
+            w._ofq_grad_out = gbuf[l]      # where this block's W_qk gradient is to be written (CodesLinearFn.backward)
         a._wqk_pre = w
     if STEP_CACHE_ACTIVE:
         # the StatsQ operands of the 12 W_qk in one launch (their per-block launches are as latency-bound as the GEMMs)

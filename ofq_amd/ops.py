@@ -829,6 +829,13 @@ def lsq_eff_scale(s, gscale):
     return (a - t) + t
 
 
+def lsq_eff_scale_vec(s, gscale, repeat=1):
+    """lsq_eff_scale as ONE launch, each value `repeat` times in a row (ofq_lsq_eff_scale_vec)."""
+    out = torch.empty(s.numel() * repeat, dtype=torch.float32, device=s.device)
+    _chk(lib().ofq_lsq_eff_scale_vec(s.data_ptr(), float(gscale), out.data_ptr(), s.numel(), int(repeat), _stream()), "ofq_lsq_eff_scale_vec")
+    return out
+
+
 def rowdot_i8_multi(codes2d, vecs2d):
     R, K = codes2d.shape
     V = vecs2d.shape[0]

@@ -237,11 +237,11 @@ class LSQ_QConv2d(nn.Conv2d):
         # im2col of a stride==kernel conv is a pure permutation: (B, gh*gw, Cin*kh*kw)
         cols = xq.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
         if code_dx:
-            steps = ops.lsq_eff_scale(self.lsqw_fn.s.detach(), wgeom.gscale)      # the step VALUE the fake-quant weights carry
+            steps = ops.lsq_eff_scale_vec(self.lsqw_fn.s.detach(), wgeom.gscale)  # the step VALUE the fake-quant weights carry
             xaux = None
             if xcodes is not None and xin.thd_neg >= -128 and xin.thd_pos <= 127:
                 qx = xcodes.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
-                ax = ops.lsq_eff_scale(xin.s.detach(), xgeom.gscale).repeat_interleave(kh * kw)               # step of column k
+                ax = ops.lsq_eff_scale_vec(xin.s.detach(), xgeom.gscale, kh * kw)                             # step of column k
                 boff = self.move_aft.bias.detach().view(gh, kh, gw, kw).permute(0, 2, 1, 3).reshape(gh * gw, kh * kw).repeat(1, Cin)
                 if getattr(self, "_ones32", None) is None or self._ones32.device != input.device:
                     self._ones32 = torch.ones(32, dtype=torch.float32, device=input.device)
