@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--split-graph", action="store_true",
                     help="with several ranks: round 4's form -- one graph for the whole backward, then every bucket all-reduce "
                          "(exposed), then the optimiser graph -- instead of the sub-graphs cut at the bucket boundaries")
-    ap.add_argument("--teacher-gemm", default="bf16x9", choices=["f32", "bf16x9", "bf16x6"],
+    ap.add_argument("--teacher-gemm", default="f16x4", choices=["f32", "bf16x9", "bf16x6", "f16x4"],
                     help="with --with-teacher: fp32-MFMA GEMMs, or the weights pre-split into bf16 planes (9 / 6 plane products)")
     ap.add_argument("--stock-teacher", action="store_true",
                     help="with --with-teacher: run the teacher through stock PyTorch-ROCm (hipBLASLt) instead of the HIP kernels")

@@ -213,7 +213,11 @@ typedef struct ofq_nt_seg {
 size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs);
 int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs);
 int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumulate, int64_t M, int64_t N, int64_t ldc,
-                          int num_wgs, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                          int num_wgs, void* ws, size_t ws_bytes, const float* col_bias, ofq_stream_t stream);
+/*            col_bias (optional): + col_bias[n] on every finished element.  With it the two-segment form is also the FORWARD of an
+ *            fp32 linear layer on the fp16 matrix cores (the frozen KD teacher, train.py:428-442, :906-910): the weight split ONCE
+ *            into W 2^Ew = Wh + Wl (two fp16 planes), the launch computes [x | x] . [Wh | Wl]^T with x split in the kernel --
+ *            four plane products instead of the nine of ofq_gemm_bf16x3x3_nt, alpha_seg = 2^-Ew (ofq_amd/teacher.py "f16x4"). */
 int ofq_qgemm_bf16s_nt_sk_check(const void* ws, float* loss, ofq_stream_t stream);
 int ofq_qgemm_bf16s_nt_sk_reset(void* ws, ofq_stream_t stream);
 /*  dX GEMM fused with the backward of the layer's own input quantiser (qlinear.py:66-69: x -> move_b4 -> LSQ -> move_aft
@@ -354,7 +358,7 @@ int ofq_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t l
  *  dgamma = sum_r dy*xh, dbeta = sum_r dy (fixed-order two-stage sums).  cols % 4 == 0, cols <= 2048. */
 int ofq_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xsum,
                       float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps,
-                      ofq_stream_t stream);
+                      void* amax_out, ofq_stream_t stream);      /* amax_out: optional word group, max |y| */
 size_t ofq_layernorm_bwd_ws_bytes(int64_t rows, int64_t cols);
 int ofq_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t cols, int64_t ldx,
@@ -431,7 +435,7 @@ int ofq_sum_flush(ofq_stream_t stream);
 /* ---- exact (erf) GELU, y = gelu(x) elementwise (x may alias y): activation of the fp32 KD teacher's MLP
  *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
-int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream);
+int ofq_gelu_fwd(const float* x, float* y, int64_t n, void* amax_out, ofq_stream_t stream);      /* amax_out: optional word group, max |y| */
 
 /*  KD loss of the shipped recipes (KDLossSoftandHard, src/quantization/utils.py:59-77, train.py:906-913), value and gradients:
  *            loss = mean_b(-sum_k softmax(teacher_b)[k] log_softmax(dist_b)[k]) + mean_b(-log_softmax(cls_b)[target_b]);

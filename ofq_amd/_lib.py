@@ -59,7 +59,7 @@ SIGNATURES = {
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp]),
     "ofq_qgemm_bf16s_nt_sk_ws_bytes": (sz, [i32]),
     "ofq_qgemm_bf16s_nt_sk_pays": (i32, [i64, i64, i64, i32]),
-    "ofq_qgemm_bf16s_nt_sk": (i32, [C.POINTER(NtSeg), i32, vp, i32, i64, i64, i64, i32, vp, sz, vp]),
+    "ofq_qgemm_bf16s_nt_sk": (i32, [C.POINTER(NtSeg), i32, vp, i32, i64, i64, i64, i32, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_nt_sk_check": (i32, [vp, vp, vp]),
     "ofq_qgemm_bf16s_nt_sk_reset": (i32, [vp, vp]),
     "ofq_qgemm_bf16s_nt_lsq_ws_bytes": (sz, [i64, i64]),
@@ -93,7 +93,7 @@ SIGNATURES = {
     "ofq_qattn_prep": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_colsum_ws_bytes": (sz, [i64, i64]),
     "ofq_colsum": (i32, [vp, vp, i64, i64, i64, vp, sz, vp]),
-    "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp]),
+    "ofq_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, vp, vp]),
     "ofq_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "ofq_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, sz, vp, vp]),
     "ofq_layernorm_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, i64, i64, i64, f32, vp]),
@@ -113,7 +113,7 @@ SIGNATURES = {
     "ofq_sum_defer": (None, [i32]),
     "ofq_sum_pending": (i32, []),
     "ofq_sum_flush": (i32, [vp]),
-    "ofq_gelu_fwd": (i32, [vp, vp, i64, vp]),
+    "ofq_gelu_fwd": (i32, [vp, vp, i64, vp, vp]),
     "ofq_permute_tokens": (i32, [vp, vp, vp, i64, i64, i64, vp]),
     "ofq_kd_loss_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "ofq_kd_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp]),

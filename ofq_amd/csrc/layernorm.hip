@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         o.y = (xv[j].y - mu) * rs * gam[j].y + bet[j].y;
         o.z = (xv[j].z - mu) * rs * gam[j].z + bet[j].z;
         o.w = (xv[j].w - mu) * rs * gam[j].w + bet[j].w;
-        if (!Q || a.y) *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
+        if (!Q || a.y) {
+          *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = o;
+          dxmax = ofq_absmax4(dxmax, o.x, o.y, o.z, o.w);          // forward: max |y| for a consumer on fp16 planes (the teacher's GEMMs)
+        }
         if (a.res) *reinterpret_cast<float4*>(a.xs + r * a.ldx + col) = xv[j];
         if (Q) {
           // only the level leaves this kernel: x * fl(1/al) decides it unless the product sits within a few ulp of a
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       }
     }
   }
-  if (!BWD) return;
   if (a.amax) ofq_amax_publish(a.amax, dxmax);
+  if (!BWD) return;
   // column partials: [TY][NACC][ncol] through LDS, summed over the row lanes in a fixed order
   constexpr int NACC = Q ? 3 : 2;
   const int ncol = TXW * J * 4;
@@ -294,7 +297,7 @@ static int ln_launch(const LnGeom& g, const LnArgs& a, hipStream_t st) {
 
 extern "C" int ofq_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                  float* xsum, float* mean, float* rstd, int64_t R, int64_t C, int64_t ldx, int64_t ldy,
-                                 float eps, ofq_stream_t stream) {
+                                 float eps, void* amax_out, ofq_stream_t stream) {
   if (!x || !y || !mean || !rstd || (res && !xsum)) return OFQ_EINVAL;
   if (ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
   LnGeom g;
@@ -303,6 +306,7 @@ extern "C" int ofq_layernorm_fwd(const float* x, const float* res, const float* 
   LnArgs a = {};
   a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xs = xsum; a.mean = mean; a.rstd = rstd;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldy; a.TX = g.TX; a.TY = 256 / g.TX; a.eps = eps;
+  a.amax = (unsigned*)amax_out;
   return ln_launch<false, false>(g, a, (hipStream_t)stream);
 }
 

@@ -224,18 +224,23 @@ extern "C" int ofq_cga_restore(float* W, const float* frozen, const float* saved
 
 // exact (erf) GELU, elementwise: the fp32 KD teacher's MLP activation (deit_vision_transformer.py:61, nn.GELU()); the
 // quantised student folds its GELU into fc2's quantiser kernels instead
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                       unsigned* __restrict__ amax) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  float m = 0.f;
   if (i4 + 3 < n && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
     const float4 v = *reinterpret_cast<const float4*>(x + i4);
-    *reinterpret_cast<float4*>(y + i4) = make_float4(ofq_gelu(v.x), ofq_gelu(v.y), ofq_gelu(v.z), ofq_gelu(v.w));
+    const float4 o = make_float4(ofq_gelu(v.x), ofq_gelu(v.y), ofq_gelu(v.z), ofq_gelu(v.w));
+    *reinterpret_cast<float4*>(y + i4) = o;
+    m = ofq_absmax4(m, o.x, o.y, o.z, o.w);
   } else {
-    for (int64_t i = i4; i < n && i < i4 + 4; ++i) y[i] = ofq_gelu(x[i]);
+    for (int64_t i = i4; i < n && i < i4 + 4; ++i) { y[i] = ofq_gelu(x[i]); m = fmaxf(m, fabsf(y[i])); }
   }
+  if (amax) ofq_amax_publish(amax, m);           // max |y| for a consumer on fp16 planes (the teacher's fc2)
 }
-extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, ofq_stream_t stream) {
+extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, void* amax_out, ofq_stream_t stream) {
   if (!x || !y || n <= 0) return OFQ_EINVAL;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n, (unsigned*)amax_out);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

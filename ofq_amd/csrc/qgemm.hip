@@ -3741,6 +3741,7 @@ struct QNtSkSeg {
 struct QNtSkArgs {
   QNtSkSeg seg[2];
   float* C; int64_t ldc;
+  const float* col_bias;     // optional: + col_bias[n] on the finished tile (a forward product: y = x . W^T + b)
   int M, N, nkt, tiles_n, accumulate;
   unsigned long long units;  // tiles * nkt / 2: the workgroups share PAIRS of k-steps (every piece starts on LDS stage 0)
   float* ws; int* flags;     // [G][8 * 3 * 512 * 4] partial tiles; flags[w], error word flags[4096]
@@ -4124,6 +4125,9 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
       if (ke != nkt) NTSK_STAMP(4);
       // ---- store the finished tile ----
       const float alpha = (NSEG > 1 ? 1.f : p.seg[0].alpha) * inv_sE;
+      float cbv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) cbv[j] = p.col_bias ? p.col_bias[min(n0 + wn * 32 * NJ + j * 32 + l31e, p.N - 1)] : 0.f;
       const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (int64_t)BM * p.ldc < (1ll << 28);
       if (interior) {
         float* Cs = p.C + (int64_t)m0 * p.ldc + n0;
@@ -4145,7 +4149,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
             for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
               for (int j = 0; j < NJ; ++j) {
-                const float v = acc[i][j][eb * 4 + ee] * alpha;
+                const float v = acc[i][j][eb * 4 + ee] * alpha + cbv[j];
                 Cs[mlb + ee * ldc + j * 32] = p.accumulate ? v + old[ee][j] : v;
               }
           }
@@ -4174,7 +4178,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
               const int m = m0 + wm * 64 + i * 32 + ee + 8 * eb + 4 * lhe;
 #pragma unroll
               for (int j = 0; j < NJ; ++j)
-                if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = acc[i][j][eb * 4 + ee] * alpha + old[ee][j];
+                if (m < p.M && nok[j]) p.C[(int64_t)m * p.ldc + ncc[j]] = (acc[i][j][eb * 4 + ee] * alpha + cbv[j]) + old[ee][j];
             }
           }
       }
@@ -4234,7 +4238,7 @@ extern "C" int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int n
 }
 
 extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumulate, int64_t M, int64_t N, int64_t ldc,
-                                     int num_wgs, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                     int num_wgs, void* ws, size_t ws_bytes, const float* col_bias, ofq_stream_t stream) {
   const bool forced = num_wgs < 0;               // exactly -num_wgs workgroups (tests, tools/nt_sk_sweep.py)
   if (forced) num_wgs = -num_wgs;
   if (!segs || (nseg != 1 && nseg != 2) || !C || !ws || M <= 0 || N <= 128 || num_wgs <= 0 || num_wgs > 4096) return OFQ_EINVAL;
@@ -4258,6 +4262,7 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
   const int64_t tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128 * nj);
   if (tiles_m * tiles_n * nkt >= (1ll << 31) || (nkt & 1)) return OFQ_EINVAL;      // units are pairs of k-steps
   a.C = C; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.nkt = nkt; a.tiles_n = (int)tiles_n; a.accumulate = accumulate;
+  a.col_bias = col_bias;
   a.units = (unsigned long long)(tiles_m * tiles_n) * (unsigned long long)(nkt / 2);
   a.flags = (int*)ws;
   a.ws = (float*)((char*)ws + QNT_SK_FLAG_BYTES);

@@ -632,7 +632,7 @@ def nt_sk_inject_fault(device, wg):
     buf[:32768].view(torch.int32)[4097] = wg + 1 if wg >= 0 else 0
 
 
-def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
+def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None, col_bias=None):
     """out[m,n] (+)= sum over segs of alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]; segs = [(A, B_bf16, k_scale, alpha), ...] (1 or 2)"""
     M, N = out.shape
     dev = out.device
@@ -654,7 +654,7 @@ def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None):
     g = num_cus(dev) if wgs is None else -int(wgs)        # wgs: exactly that many workgroups (<= the CU count; tests)
     with _Timed(nt_class(f16), 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt_sk(arr, len(segs), out.data_ptr(), int(accumulate), M, N, out.stride(0), g, ws.data_ptr(),
-                                         ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_sk")
+                                         ws.numel(), _p(col_bias), _stream()), "ofq_qgemm_bf16s_nt_sk")
     return out
 
 
@@ -1040,8 +1040,8 @@ def colsum(x2d):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
-def layernorm_fwd(x2d, gamma, beta, eps, res2d=None):
-    """y = LN(x [+ res]); returns (y, xsum or None, mean, rstd)"""
+def layernorm_fwd(x2d, gamma, beta, eps, res2d=None, want_amax=False):
+    """y = LN(x [+ res]); returns (y, xsum or None, mean, rstd); want_amax: y carries its maximum word (ops.amax_of)"""
     _dev(x2d, "x")
     rows, cols = x2d.shape
     dev = x2d.device
@@ -1049,9 +1049,12 @@ def layernorm_fwd(x2d, gamma, beta, eps, res2d=None):
     xsum = torch.empty((rows, cols), dtype=torch.float32, device=dev) if res2d is not None else None
     mean = torch.empty(rows, dtype=torch.float32, device=dev)
     rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    am = amax_word(dev) if want_amax else None
     _chk(lib().ofq_layernorm_fwd(x2d.data_ptr(), _p(res2d), _p(gamma), _p(beta), y.data_ptr(), _p(xsum), mean.data_ptr(),
-                                 rstd.data_ptr(), rows, cols, x2d.stride(0), cols, float(eps), _stream()),
+                                 rstd.data_ptr(), rows, cols, x2d.stride(0), cols, float(eps), _p(am), _stream()),
          "ofq_layernorm_fwd")
+    if am is not None:
+        tag_amax(y, am)
     return y, xsum, mean, rstd
 
 
@@ -1164,10 +1167,13 @@ def permute_tokens(x, idx32):
 
 
 # ------------------------------------------------------------------------------------------------ fp32 teacher helpers
-def gelu_(x):
-    """exact GELU in place"""
+def gelu_(x, want_amax=False):
+    """exact GELU in place; want_amax: x carries its maximum word afterwards (ops.amax_of)"""
     _dev(x, "x")
-    _chk(lib().ofq_gelu_fwd(x.data_ptr(), x.data_ptr(), x.numel(), _stream()), "ofq_gelu_fwd")
+    am = amax_word(x.device) if want_amax else None
+    _chk(lib().ofq_gelu_fwd(x.data_ptr(), x.data_ptr(), x.numel(), _p(am), _stream()), "ofq_gelu_fwd")
+    if am is not None:
+        tag_amax(x, am)
     return x
 
 
@@ -1178,6 +1184,27 @@ def split_f32_bf16x3(W):
     planes = torch.empty((3,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
     _chk(lib().ofq_split_f32_bf16x3(W.data_ptr(), planes.data_ptr(), W.numel(), W.numel(), _stream()), "ofq_split_f32_bf16x3")
     return planes
+
+
+def split_f32_f16x2(W):
+    """A frozen fp32 weight as two fp16 planes of W * 2^E (E puts max |W| into [2^14, 2^15)): returns (hi, lo, 2^-E) with
+    W = (hi + lo) * 2^-E up to 2^-24 |W| for entries within 2^-17 of the maximum (torch ops: a one-off at load time)."""
+    _dev(W, "weight")
+    import math
+    amax = float(W.detach().abs().max())
+    E = 14 - math.frexp(amax)[1] + 1 if amax > 0 else 0            # frexp: amax = m * 2^e, m in [0.5, 1)
+    Ws = W.detach().double() * (2.0 ** E)
+    hi = Ws.to(torch.float16)
+    lo = (Ws - hi.double()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous(), 2.0 ** (-E)
+
+
+def linear_f16x4(x2d, planes, bias=None):
+    """y = x2d @ W^T + bias with W as split_f32_f16x2's planes: [x | x] . [hi | lo]^T as ONE two-segment code GEMM
+    (ofq_qgemm_bf16s_nt_sk; x split into two fp16 planes inside the kernel: four plane products, fp32 accumulation)."""
+    hi, lo, inv = planes
+    y = torch.empty((x2d.shape[0], hi.shape[0]), dtype=torch.float32, device=x2d.device)
+    return qgemm_bf16s_nt_sk([(x2d, hi, None, inv), (x2d, lo, None, inv)], y, col_bias=bias)
 
 
 def gemm_bf16x3x3_nt(x2d, planes, bias=None, products=9):

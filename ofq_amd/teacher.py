@@ -15,7 +15,10 @@ from .functional import pad4
 
 
 class HipTeacher:
-    """gemm: "f32" -- the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak); "bf16x9" / "bf16x6" -- the four
+    """gemm: "f16x4" (round 5) -- weights as two fp16 planes of W 2^E, activations as two fp16 planes of x 2^E' (E' from the
+    maximum word of the kernel that produced x): y = [x | x] . [Wh | Wl]^T as one two-segment code GEMM, four plane products
+    (error 2^-22-grade: tests hold it to the 1e-4 of the nine-product mode); "f32" -- the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32,
+    157 TFLOP/s peak); "bf16x9" / "bf16x6" -- the four
     linear layers of every block on the bf16 matrix cores: the frozen weights are split ONCE into three bf16 planes
     (W = W0 + W1 + W2 exactly), the activations are split per tile inside the kernel, and all nine (six leading) plane
     products are accumulated in fp32 -- the exact product of the fp32 values (up to 2^-24), at 16x the fp32-MFMA
@@ -27,8 +30,8 @@ class HipTeacher:
             p.requires_grad_(False)
         if getattr(model, "dist_token", None) is None:
             raise ValueError("HipTeacher: the KD recipes use the distilled DeiT (deit.py:19)")
-        if gemm not in ("f32", "bf16x9", "bf16x6"):
-            raise ValueError("HipTeacher: gemm must be 'f32', 'bf16x9' or 'bf16x6'")
+        if gemm not in ("f32", "bf16x9", "bf16x6", "f16x4"):
+            raise ValueError("HipTeacher: gemm must be 'f32', 'bf16x9', 'bf16x6' or 'f16x4'")
         self.gemm = gemm
         self._ones = None
         self._planes = {}
@@ -41,17 +44,24 @@ class HipTeacher:
         K = lin.weight.shape[1]
         if self.gemm == "f32" or K % 8 or not lin.weight.is_cuda:
             return ops.linear_fwd(x2d, lin.weight, lin.bias)
-        pl = self._planes.get(id(lin))
+        N = lin.weight.shape[0]
+        if self.gemm == "f16x4" and N > 128 and K % 32 == 0 and x2d.shape[0] * x2d.stride(0) * 4 < 2 ** 32:
+            # round 5: weight = two fp16 planes of W 2^E (split once), activations two fp16 planes of x 2^E' (split in the kernel,
+            # E' from the maximum word the producing kernel left): four plane products instead of nine, one launch
+            pl = self._planes.get((id(lin), 2))
+            if pl is None:
+                pl = self._planes[(id(lin), 2)] = ops.split_f32_f16x2(lin.weight)
+            return ops.linear_f16x4(x2d, pl, lin.bias)
+        pl = self._planes.get((id(lin), 3))
         if pl is None:
-            pl = self._planes[id(lin)] = ops.split_f32_bf16x3(lin.weight.detach())
-        return ops.gemm_bf16x3x3_nt(x2d, pl, lin.bias, products=9 if self.gemm == "bf16x9" else 6)
+            pl = self._planes[(id(lin), 3)] = ops.split_f32_bf16x3(lin.weight.detach())
+        return ops.gemm_bf16x3x3_nt(x2d, pl, lin.bias, products=6 if self.gemm == "bf16x6" else 9)
 
     def parameters(self):
         return self.m.parameters()
 
-    @staticmethod
-    def _ln(norm, x2d, res2d=None):
-        y, xs, _, _ = ops.layernorm_fwd(x2d, norm.weight, norm.bias, norm.eps, res2d=res2d)
+    def _ln(self, norm, x2d, res2d=None):
+        y, xs, _, _ = ops.layernorm_fwd(x2d, norm.weight, norm.bias, norm.eps, res2d=res2d, want_amax=self.gemm == "f16x4")
         return y, xs
 
     def _attention(self, attn, n1, B, N, C):
@@ -72,7 +82,7 @@ class HipTeacher:
 
     def _mlp(self, mlp, n2):
         h = self._linear(n2, mlp.fc1)
-        ops.gelu_(h)
+        ops.gelu_(h, want_amax=self.gemm == "f16x4")
         return self._linear(h, mlp.fc2)
 
     @torch.no_grad()
@@ -81,6 +91,15 @@ class HipTeacher:
         if not images.is_cuda:
             raise RuntimeError("HipTeacher: input must be on a HIP device; there is no CPU fallback")
         B = images.shape[0]
+        if self.gemm == "f16x4":
+            ops.amax_begin(images.device)        # the maximum words of this forward from the pool (zeroed once), not one fill each
+        try:
+            return self._forward(images, m, B)
+        finally:
+            if self.gemm == "f16x4":
+                ops.amax_end()
+
+    def _forward(self, images, m, B):
         pe = m.patch_embed.proj
         kh, kw = pe.kernel_size
         gh, gw = images.shape[2] // kh, images.shape[3] // kw

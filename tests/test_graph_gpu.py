@@ -583,7 +583,7 @@ def test_hip_teacher_forward_equals_the_fp32_deit():
         model.blocks[3].mlp.fc1.bias.normal_(0, 0.3)
     x = torch.randn(3, 3, 224, 224, device="cuda")
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    for gemm in ("f32", "bf16x9", "bf16x6"):              # exact-fp32 MFMA; weights pre-split into bf16 planes (9 / 6 products)
+    for gemm in ("f32", "bf16x9", "bf16x6", "f16x4"):     # exact-fp32 MFMA; weights pre-split into bf16 planes (9 / 6 products); two fp16 planes each side
         teacher = HipTeacher(model, gemm=gemm)
         for training in (True, False):
             model.train(training)
