@@ -166,6 +166,24 @@ int ofq_qgemm_i8_lsq_bwd(const int8_t* A, const int8_t* B, const float* bias, co
                          const float* q_s, int64_t q_S, float q_gscale, const float* q_b4, int q_lo, int q_hi,
                          int q_gelu, int q_rowmul, int64_t q_coldiv, int q_colmode, float* ds, float* db4, float* dbaft,
                          void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
+/*  QKR attention (attention.py:200-210 + lsq.py:571-602): the backward of [scores <- qkx quantiser <- qkx = x_hat . W_qk^T]
+ *  from dS in ONE launch.  The incoming gradient of the quantiser, dqkx[(b, m), (h, c)] = sum_n dS[b, h, n, m] *
+ *  (a_eff[n] * xcodes[b, n, c] + bax[c]), is formed inside the recompute kernel (two fp16 planes of dS on the scale of
+ *  `amax`, as ofq_qattn_dqkx_bf16s forms it) instead of being written by one kernel and read by the next: the result
+ *  equals ofq_qattn_dqkx_bf16s(amax) -> ofq_qgemm_i8_lsq_bwd bit for bit, 8 B per qkx element less HBM traffic.
+ *  xcodes [B Ntok][lda] int8 (C used columns), wcodes [H C][ldb] int8; sx [Ntok] steps of x_hat (per token); dS
+ *  [B][H][Ntok][ldS]; q_s [q_S = Ntok H] steps of the qkx quantiser, (token, head); dy [B Ntok][ldd] (H C columns).
+ *  Needs Ntok >= 128 and even, C % 128 == 0, ldS even; workspace as ofq_qgemm_i8_lsq_bwd_ws_bytes(B Ntok, H C, 0).
+ *  MEASURED (round 5, tools/dqkx_fused_bench.py, one DeiT-S block at 128 images): 278 us against 257 us for the pair --
+ *  1.68 GB -> 0.75 GB of traffic, but the dS panel is split once per 128-column tile (three times per head) and a
+ *  one-tile workgroup does not hide the panel's load latency behind the quantiser arithmetic; the training step
+ *  therefore keeps the pair (functional.ScoresSoftmaxCodesFn.backward), this entry is parity-tested and not on its path. */
+int ofq_qattn_dqkx_lsq_bwd(const int8_t* xcodes, const int8_t* wcodes, const float* bias, const float* col_scale,
+                           float col_mult, const float* r, const float* sx, float gscale_x, const float* bax,
+                           const float* dS, int64_t ldS, const void* amax, int64_t B, int64_t H, int64_t Ntok, int64_t C,
+                           int64_t lda, int64_t ldb, float* dy, int64_t ldd, const float* q_s, int64_t q_S,
+                           float q_gscale, const float* q_b4, int q_lo, int q_hi, float* ds, float* db4, float* dbaft,
+                           void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /*  backward: C[m,n] (+)= alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]   A fp32 [M][K] (e.g. dY), B bf16 codes [N][K]
  *            (the transposed weight codes), A*k_scale split into nsplit (2|3) bf16 pieces; 3 = exact fp32 product.

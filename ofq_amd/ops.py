@@ -540,6 +540,43 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
     return dy, ds, db4, dbaft
 
 
+def dqkx_lsq_fusable(prod, q, sx, gx, N, C, ldS):
+    """May the qkx quantiser's backward form its incoming gradient itself (ofq_qattn_dqkx_lsq_bwd)?  The producer of qkx must
+    be the GEMM on THESE x codes / steps, the quantiser the per-(token, head) one, the shapes what the kernel tiles."""
+    return (GRAD_PLANES == 2 and "dqkx" in _DBG_F16 and prod is not None and N >= 128 and N % 2 == 0 and C % 128 == 0
+            and ldS % 2 == 0 and not q.get("colmode", 0) and not q["gelu"] and prod["act_S"] == N
+            and prod["act_s"].data_ptr() == sx.data_ptr() and float(prod["act_gscale"]) == float(gx)
+            and prod["xcodes"].shape[1] == C and prod["xcodes"].stride(0) % 16 == 0)
+
+
+def qattn_dqkx_lsq_bwd(dS, prod, q, bax, B, H, N, C, ldS, want_bias_grads=True, planes=None):
+    """ofq_qattn_dqkx_lsq_bwd: (dy, ds, db4, dbaft) of qattn_dqkx -> qgemm_i8_lsq_bwd without the dqkx tensor."""
+    xc, wc = prod["xcodes"], prod["wcodes"]
+    M, Nout = B * N, H * C
+    if xc.shape[0] != M or wc.shape[0] != Nout or q["S"] != N * H or int(q.get("rowmul", 1)) != H:
+        raise RuntimeError("ofq_amd: qattn_dqkx_lsq_bwd: operands do not describe a (%d, %d, %d, %d) QKR attention" % (B, H, N, C))
+    dev = dS.device
+    dy = torch.empty((M, Nout), dtype=torch.float32, device=dev)
+    ds = torch.empty_like(q["s"])
+    has_bias = q["b4"] is not None and want_bias_grads
+    db4 = torch.empty(Nout, dtype=torch.float32, device=dev) if has_bias else None
+    dbaft = torch.empty(Nout, dtype=torch.float32, device=dev) if has_bias else None
+    ws = workspace(lib().ofq_qgemm_i8_lsq_bwd_ws_bytes(M, Nout, 0), dev)
+    amax = scores_amax(dS, N, planes)
+    am = amax_out(dev)
+    with _Timed('qattn_dqkx_lsqbwd (dqkx GEMM on 2 fp16 planes + int8 recompute + LSQ backward epilogue)',
+                2.0 * B * H * N * N * C + 2.0 * M * Nout * C):
+        _chk(lib().ofq_qattn_dqkx_lsq_bwd(xc.data_ptr(), wc.data_ptr(), _p(prod["bias"]), prod["w_scale"].data_ptr(),
+                                          prod["w_mult"], _p(prod["r"]), prod["act_s"].data_ptr(), prod["act_gscale"], _p(bax),
+                                          dS.data_ptr(), ldS, amax.data_ptr(), B, H, N, C, xc.stride(0), wc.stride(0),
+                                          dy.data_ptr(), Nout, q["s"].data_ptr(), q["S"], q["gscale"], _p(q["b4"]), q["lo"],
+                                          q["hi"], ds.data_ptr(), _p(db4), _p(dbaft), ws.data_ptr(), ws.numel(), _p(am),
+                                          _stream()), "ofq_qattn_dqkx_lsq_bwd")
+    if am is not None:
+        tag_amax(dy, am)
+    return dy, ds, db4, dbaft
+
+
 # ---- stream-K input-gradient GEMM (ofq_qgemm_bf16s_nt_sk) ----------------------------------------------------------------
 def _pl(two):
     """What a backward code GEMM issues per algorithmic multiply-add: two fp16 products (round 5) or three bf16 ones."""

@@ -1160,6 +1160,59 @@ def test_i8_recompute_lsq_backward_equals_stored_activation_pair(ops, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (name, images, heads, tokens, channels, lo, hi)
+    ("three_images", 3, 2, 198, 128, -2, 1),          # 594 rows: 128-row tiles that straddle both image boundaries
+    ("deit_s_block", 16, 6, 198, 384, -2, 1),         # the headline block's heads / width
+    ("w4a4_256", 5, 3, 256, 256, -8, 7),              # DeiT-T at 256 px: 257 is odd -> not fusable; 256 tokens are
+    ("short_last_tile", 2, 2, 130, 128, -2, 1),       # 260 rows: the third tile holds 4 rows
+])
+def test_fused_dqkx_recompute_backward_equals_the_two_kernels(ops, case):
+    """ofq_qattn_dqkx_lsq_bwd (the qkx quantiser's backward forms its incoming gradient from dS itself) against the pair it
+    replaces, ofq_qattn_dqkx_bf16s on two fp16 planes followed by ofq_qgemm_i8_lsq_bwd (attention.py:200-210, lsq.py:571-602):
+    the same products in the same order, so dy and the reduced gradients are bit-identical; the maximum word of dy as well."""
+    name, B, H, N, C, lo, hi = case
+    g = torch.Generator(device="cuda").manual_seed(len(name) + 13 * N)
+    M, Nout = B * N, H * C
+    ldS = (N + 15) // 16 * 16
+    xc = torch.randint(-2, 2, (M, C), dtype=torch.int8, device="cuda", generator=g)
+    wc = (2 * torch.randint(-2, 2, (Nout, C), device="cuda", generator=g) + 1).to(torch.int8)
+    bias = torch.randn(Nout, device="cuda", generator=g) * 0.1
+    cs = torch.rand(Nout, device="cuda", generator=g) * 0.05 + 0.01
+    r = torch.randn(Nout, device="cuda", generator=g) * 0.3
+    sx = torch.rand(N, device="cuda", generator=g) * 0.3 + 0.05
+    gx = 0.013
+    bax = torch.randn(C, device="cuda", generator=g) * 0.2
+    qs = torch.rand(N * H, device="cuda", generator=g) * 0.3 + 0.1
+    qb4 = torch.randn(Nout, device="cuda", generator=g) * 0.05
+    dS = torch.randn(B, H, N, ldS, device="cuda", generator=g) * torch.pow(
+        10.0, torch.randint(-4, 1, (B, H, N, ldS), device="cuda", generator=g).float())
+    dS[..., N:] = float("nan")                                    # the pad columns are never read
+    q = dict(s=qs, S=N * H, gscale=0.021, b4=qb4, lo=lo, hi=hi, gelu=0, rowmul=H, coldiv=C, colmode=0)
+    prod = {"xcodes": xc, "wcodes": wc, "bias": bias, "w_scale": cs, "w_mult": 0.25, "r": r, "act_s": sx, "act_S": N,
+            "act_gscale": gx}
+    assert ops.dqkx_lsq_fusable(prod, q, sx, gx, N, C, ldS)
+    ops.amax_begin(dS.device)
+    try:
+        gy = ops.qattn_dqkx(dS, xc, sx, gx, bax, B, H, N, C, ldS, planes=2)
+        dy_ref, ds_ref, db4_ref, dba_ref = ops.qgemm_i8_lsq_bwd(gy.view(M, Nout), prod, q)
+        w_ref = ops.amax_of(dy_ref)
+        dy, ds, db4, dba = ops.qattn_dqkx_lsq_bwd(dS, prod, q, bax, B, H, N, C, ldS, planes=2)
+        w = ops.amax_of(dy)
+        assert torch.isfinite(dy_ref).all() and float((dy_ref == 0).float().mean()) < 0.98
+        if C % 384 == 0:          # the pair's first kernel is the two-plane stream kernel: the same products in the same order
+            assert torch.equal(dy, dy_ref)
+            assert torch.equal(ds, ds_ref) and torch.equal(db4, db4_ref) and torch.equal(dba, dba_ref)
+        else:                     # elsewhere ofq_qattn_dqkx_bf16s multiplies three bf16 planes: fp32-grade agreement, same gates
+            assert torch.equal(dy == 0, dy_ref == 0)
+            assert rel_err(dy, dy_ref) < 2e-6
+            assert rel_err(ds, ds_ref) < 1e-5 and rel_err(db4, db4_ref) < 1e-5 and rel_err(dba, dba_ref) < 1e-5
+        assert float(w.view(torch.float32).max()) == float(dy.abs().max())
+    finally:
+        ops.amax_end()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [("qkr", 3, 6, 198, 384, 2), ("qkr_full", 128, 6, 197, 384, 2), ("qkr_small", 2, 3, 70, 96, 4), ("plain", 3, 3, 198, 64, 4),
                                  ("plain_256", 1, 2, 256, 32, 3),
                                  ("qkr_window", 64, 3, 49, 96, 3), ("plain_window", 32, 6, 49, 32, 3), ("qkr_win_tiny", 4, 2, 7, 32, 2),
