@@ -453,6 +453,12 @@ int ofq_sum_flush(ofq_stream_t stream);
 /* ---- exact (erf) GELU, y = gelu(x) elementwise (x may alias y): activation of the fp32 KD teacher's MLP
  *  (train.py:428-442, :906-910; deit_vision_transformer.py:44-62), whose forward otherwise runs on ofq_gemm_f32,
  *  ofq_layernorm_fwd and ofq_softmax_lsq_fwd's probabilities (ofq_amd/teacher.py). */
+/* ---- KD teacher (train.py:906-910: the frozen fp32 DistilledVisionTransformer runs in every step), its attention in ONE
+ *  launch: out[(b, n), h d + c] = sum_m softmax_m(scale * q[b,n,h,:] . k[b,m,h,:]) v[b,m,h,c] on the fp32 activations
+ *  qkv [B N][3 H d] (q | k | v column thirds).  d == 64, N <= 224.  Both products run as three fp16-plane products per
+ *  algorithmic one on tile-local power-of-two scales (fp32-grade: the dropped lo.lo term is 2^-22 of a product), the scores
+ *  and probabilities stay in registers. */
+int ofq_attn_f32_fwd(const float* qkv, float* out, int64_t B, int64_t H, int64_t N, int64_t d, float scale, ofq_stream_t stream);
 int ofq_gelu_fwd(const float* x, float* y, int64_t n, void* amax_out, ofq_stream_t stream);      /* amax_out: optional word group, max |y| */
 
 /*  KD loss of the shipped recipes (KDLossSoftandHard, src/quantization/utils.py:59-77, train.py:906-913), value and gradients:

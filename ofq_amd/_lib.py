@@ -56,6 +56,7 @@ SIGNATURES = {
     "ofq_qgemm_i8_lsq_bwd_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_i8_lsq_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, i64, f32, i64, i64, i64, i64, i64, vp, i64, vp, i64,
                                    vp, i64, f32, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp, vp]),
+    "ofq_attn_f32_fwd": (i32, [vp, vp, i64, i64, i64, i64, f32, vp]),
     "ofq_qattn_dqkx_lsq_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, i64, vp, i64, i64, i64, i64, i64, i64, vp, i64,
                                      vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_nt": (i32, [vp, vp, vp, vp, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp]),

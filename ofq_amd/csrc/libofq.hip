@@ -13,6 +13,7 @@ extern "C" const char* ofq_source_hash(void) { return "OFQ_SOURCE_HASH=" OFQ_SOU
 #include "gemm_f32.hip"
 #include "qgemm.hip"
 #include "qattn_fused.hip"
+#include "attn_f32.hip"
 #include "layernorm.hip"
 #include "misc.hip"
 #include "adamw.hip"

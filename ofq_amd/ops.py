@@ -540,6 +540,20 @@ def qgemm_i8_lsq_bwd(gy2d, prod, q, want_bias_grads=True):
     return dy, ds, db4, dbaft
 
 
+def attn_f32_ok(N, d):
+    return d == 64 and 0 < N <= 224
+
+
+def attn_f32_fwd(qkv2d, B, H, N, d, scale):
+    """softmax(scale q k^T) v per (image, head) on the fp32 teacher's qkv projection (ofq_attn_f32_fwd): (B N, H d)"""
+    if qkv2d.shape != (B * N, 3 * H * d) or not qkv2d.is_contiguous():
+        raise RuntimeError("ofq_amd: attn_f32_fwd: qkv of shape %s for (%d, %d, %d, %d)" % (tuple(qkv2d.shape), B, H, N, d))
+    out = torch.empty((B * N, H * d), dtype=torch.float32, device=qkv2d.device)
+    with _Timed('attn_f32_fwd (teacher attention, 3x v_mfma_f32_32x32x16_f16)', 4.0 * B * H * N * N * d):
+        _chk(lib().ofq_attn_f32_fwd(qkv2d.data_ptr(), out.data_ptr(), B, H, N, d, float(scale), _stream()), "ofq_attn_f32_fwd")
+    return out
+
+
 def dqkx_lsq_fusable(prod, q, sx, gx, N, C, ldS):
     """May the qkx quantiser's backward form its incoming gradient itself (ofq_qattn_dqkx_lsq_bwd)?  The producer of qkx must
     be the GEMM on THESE x codes / steps, the quantiser the per-(token, head) one, the shapes what the kernel tiles."""

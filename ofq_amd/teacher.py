@@ -69,6 +69,9 @@ class HipTeacher:
         d = C // H
         Np = pad4(N)
         qkv = self._linear(n1, attn.qkv)                                             # (B*N, 3C): q | k | v column thirds
+        if self.gemm == "f16x4" and ops.attn_f32_ok(N, d) and qkv.is_contiguous():
+            # round 5: scores, softmax and P.V in one launch on fp16 planes (scores / probabilities never reach HBM)
+            return self._linear(ops.attn_f32_fwd(qkv, B, H, N, d, attn.scale), attn.proj)
         S = torch.empty((B, H, N, Np), dtype=torch.float32, device=n1.device)
         ops.gemm(qkv, qkv, S, N, N, d, 3 * C, 3 * C, Np, transB=True, nb0=B, nb1=H, sA=(N * 3 * C, d), sB=(N * 3 * C, d),
                  sC=(H * N * Np, N * Np), offB=C)                                     # q k^T per (image, head)

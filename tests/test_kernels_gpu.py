@@ -1456,3 +1456,35 @@ def test_token_assembly_kernel_is_cat_plus_pos_embed(ops, dist):
     assert torch.equal(got[0], want[0])
     for a, b in zip(got[1:], want[1:]):
         assert a.shape == b.shape and rel_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("deit_s", 3, 6, 198), ("deit_t_197", 2, 3, 197), ("short", 2, 2, 33), ("full_224", 1, 2, 224),
+                                  ("one_key", 1, 1, 1)])
+def test_teacher_attention_in_one_launch_vs_fp64(ops, case):
+    """ofq_attn_f32_fwd (the KD teacher's softmax(scale q k^T) v, deit_vision_transformer.py:85-116 without quantisers, on fp16
+    planes with tile-local scales) against the same attention in fp64, and against the fp32 computation's own distance from
+    it: fp32-grade means within a small multiple of what plain fp32 loses.  Inputs with outliers (a few keys 30x the rest: a
+    peaked softmax) and columns spanning decades (the plane scale is per tile, not per column)."""
+    name, B, H, N = case
+    d, C = 64, H * 64
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + H)
+    qkv = torch.randn(B * N, 3 * C, device="cuda", generator=g)
+    qkv[:, :C] *= 2.0
+    qkv[::17, C:2 * C] *= 30.0                                        # outlier keys
+    qkv[:, 2 * C:] *= torch.pow(10.0, torch.randint(-3, 2, (3 * C - 2 * C,), device="cuda", generator=g).float())
+    scale = d ** -0.5
+    out = ops.attn_f32_fwd(qkv, B, H, N, d, scale)
+
+    def ref(x):
+        q, k, v = (x[:, i * C:(i + 1) * C].view(B, N, H, d).permute(0, 2, 1, 3) for i in range(3))
+        a = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+        return (a @ v).permute(0, 2, 1, 3).reshape(B * N, C)
+    r64 = ref(qkv.double())
+    r32 = ref(qkv)
+    assert torch.isfinite(out).all()
+    # per output column (the v columns span decades): error against the column's largest value
+    colmax = r64.abs().amax(dim=0).clamp_min(1e-30)
+    e_hip = ((out.double() - r64).abs() / colmax).max().item()
+    e_f32 = ((r32.double() - r64).abs() / colmax).max().item()
+    assert e_hip < 3 * e_f32 + 1e-6, (e_hip, e_f32)
