@@ -227,6 +227,9 @@ typedef struct ofq_nt_seg {
   float alpha;
   const void* amax;     /* NULL: three bf16 planes, B_bf16 = bf16 codes.  Else (every segment of the launch): the device word
                            holding the bits of an upper bound of max |A| -- the two-plane fp16 form, B_bf16 = FP16 codes */
+  int32_t hi_only;      /* segment 1 of a two-plane launch only: A's LEADING plane alone multiplies this segment's B (the
+                           trailing plane's product is skipped) -- with B = the trailing plane of a split weight this makes
+                           the forward below a three-product one (x_hi W_hi + x_lo W_hi + x_hi W_lo); K of segment 0 % 64 == 0 */
 } ofq_nt_seg;
 size_t ofq_qgemm_bf16s_nt_sk_ws_bytes(int num_wgs);
 int ofq_qgemm_bf16s_nt_sk_pays(int64_t M, int64_t N, int64_t K, int num_wgs);
@@ -235,7 +238,8 @@ int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C, int accumu
 /*            col_bias (optional): + col_bias[n] on every finished element.  With it the two-segment form is also the FORWARD of an
  *            fp32 linear layer on the fp16 matrix cores (the frozen KD teacher, train.py:428-442, :906-910): the weight split ONCE
  *            into W 2^Ew = Wh + Wl (two fp16 planes), the launch computes [x | x] . [Wh | Wl]^T with x split in the kernel --
- *            four plane products instead of the nine of ofq_gemm_bf16x3x3_nt, alpha_seg = 2^-Ew (ofq_amd/teacher.py "f16x4"). */
+ *            four plane products instead of the nine of ofq_gemm_bf16x3x3_nt (three with hi_only on the second segment: the
+ *            dropped x_lo W_lo term is 2^-22 of a product), alpha_seg = 2^-Ew (ofq_amd/teacher.py "f16x4"). */
 int ofq_qgemm_bf16s_nt_sk_check(const void* ws, float* loss, ofq_stream_t stream);
 int ofq_qgemm_bf16s_nt_sk_reset(void* ws, ofq_stream_t stream);
 /*  dX GEMM fused with the backward of the layer's own input quantiser (qlinear.py:66-69: x -> move_b4 -> LSQ -> move_aft

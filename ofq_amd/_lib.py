@@ -24,7 +24,8 @@ class GemmDesc(C.Structure):
 
 
 class NtSeg(C.Structure):
-    _fields_ = [("A", vp), ("B_bf16", vp), ("k_scale", vp), ("K", i64), ("lda", i64), ("ldb", i64), ("alpha", f32), ("amax", vp)]
+    _fields_ = [("A", vp), ("B_bf16", vp), ("k_scale", vp), ("K", i64), ("lda", i64), ("ldb", i64), ("alpha", f32), ("amax", vp),
+                ("hi_only", C.c_int32)]
 
 
 class TnJob(C.Structure):

@@ -3982,6 +3982,7 @@ struct QNtSkSeg {
   unsigned lda4, ldb2;       // row pitch of A / B in bytes
   int nkt;                   // k-steps of QBS_BK in this segment
   float alpha;
+  int hi_only;               // segment 1, F16 form: only A's leading plane multiplies this segment's B (a three-product forward)
 };
 struct QNtSkArgs {
   QNtSkSeg seg[2];
@@ -4169,8 +4170,11 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
   // F16 piece list per row chunk (10 pieces): per pair [x0 = a0*ks0, x1 = a1*ks1] [h = cvt_pk(x0, x1)] [r0 = x0 - h.lo, r1 = x1 - h.hi]
   // [l = cvt_pk(r0, r1)], then the two plane stores
   constexpr int NM = 4 * NS * NJ, NPA = F16 ? 10 : 17, NP = 2 * NPA + NB + NB + 3;
-  auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT) {
+  // ho (uniform; two-segment fp16 form): the k-step in `cur` belongs to a segment whose B multiplies A's LEADING plane only --
+  // the trailing plane's MFMAs are branched over (one body: a second instantiation of this step costs 200 spilled registers)
+  auto step = [&](const unsigned char* cur, unsigned char* nxt, auto SLOT, const bool ho) {
     constexpr int sl = decltype(SLOT)::value;
+    constexpr int NSE = NS, NME = NM;
     const unsigned char* a = &cur[(wm * 64 + l31) * QBS_LD + lh * 16];
     const unsigned char* b = &cur[NS * PLANE + (wn * 32 * NJ + l31) * QBS_LD + lh * 16];
     static_assert(QBS_BK == 32, "two MFMA steps per k-step");
@@ -4178,7 +4182,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bv[0][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * QBS_LD);
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
+    for (int q = 0; q < NSE; ++q)
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD);
     __builtin_amdgcn_sched_barrier(0);
@@ -4250,15 +4254,19 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
         }
       }
     };
-    static_for<NM>([&](auto G_) {
+    static_for<NME>([&](auto G_) {
       constexpr int Gi = decltype(G_)::value;
-      constexpr int ks = Gi / (2 * NS * NJ), q = (Gi / (2 * NJ)) % NS, i = (Gi / NJ) % 2, j = Gi % NJ;
-      acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
+      constexpr int ks = Gi / (2 * NSE * NJ), q = (Gi / (2 * NJ)) % NSE, i = (Gi / NJ) % 2, j = Gi % NJ;
+      if constexpr (NSEG > 1 && F16 && q == 1) {
+        if (!ho) acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
+      } else {
+        acc[i][j] = mfma_16b<F16>(av[q][i], bv[ks][j], acc[i][j]);
+      }
       if constexpr (ks == 0) {
         if constexpr (Gi < NJ) bv[1][Gi] = *reinterpret_cast<const bf16x8*>(b + Gi * 32 * QBS_LD + 32);
         if constexpr (j == NJ - 1) av[q][i] = *reinterpret_cast<const bf16x8*>(a + q * PLANE + i * 32 * QBS_LD + 32);
       }
-      constexpr int P0 = Gi * NP / NM, P1 = (Gi + 1) * NP / NM;
+      constexpr int P0 = Gi * NP / NME, P1 = (Gi + 1) * NP / NME;
       static_for<P1 - P0>([&](auto D_) { piece(std::integral_constant<int, P0 + decltype(D_)::value>{}); });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -4291,9 +4299,12 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_sk_kernel(QNtSkArgs p
     const int ke = min(nkt, kb + (int)(u_end - u));
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    for (int n2 = (ke - kb) >> 1; n2 > 0; --n2) {
-      step(smem, smem + STAGE, Slot1());
-      step(smem + STAGE, smem, Slot0());
+    int kc = kb;                                              // k-step being multiplied (pairs never straddle the segments)
+    for (int n2 = (ke - kb) >> 1; n2 > 0; --n2, kc += 2) {
+      bool ho = false;
+      if constexpr (NSEG > 1 && F16) ho = p.seg[1].hi_only && kc >= p.seg[0].nkt;
+      step(smem, smem + STAGE, Slot1(), ho);
+      step(smem + STAGE, smem, Slot0(), ho);
     }
 
     int l31e = l31, lhe = lh, tide = tid;
@@ -4501,6 +4512,9 @@ extern "C" int ofq_qgemm_bf16s_nt_sk(const ofq_nt_seg* segs, int nseg, float* C,
     if ((sg.amax != nullptr) != (segs[0].amax != nullptr)) return OFQ_EINVAL;      // one operand format per launch
     a.seg[i].lda4 = (unsigned)(sg.lda * 4); a.seg[i].ldb2 = (unsigned)(sg.ldb * 2);
     a.seg[i].nkt = (int)(sg.K / QBS_BK); a.seg[i].alpha = sg.alpha;
+    a.seg[i].hi_only = sg.hi_only;
+    // (a hi-only segment: the second of two, fp16 form, behind a whole number of k-step PAIRS)
+    if (sg.hi_only && (i != 1 || !sg.amax || (segs[0].K % (2 * QBS_BK)))) return OFQ_EINVAL;
     nkt += a.seg[i].nkt;
   }
   const int nj = N > 256 ? 3 : 2;

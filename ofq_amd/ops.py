@@ -683,8 +683,9 @@ def nt_sk_inject_fault(device, wg):
     buf[:32768].view(torch.int32)[4097] = wg + 1 if wg >= 0 else 0
 
 
-def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None, col_bias=None):
-    """out[m,n] (+)= sum over segs of alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]; segs = [(A, B_bf16, k_scale, alpha), ...] (1 or 2)"""
+def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None, col_bias=None, hi_only_last=False):
+    """out[m,n] (+)= sum over segs of alpha * sum_k (A[m,k]*k_scale[k]) * B[n,k]; segs = [(A, B_bf16, k_scale, alpha), ...] (1 or 2)
+    hi_only_last (two fp16-code segments): the second segment's B meets A's leading plane only (ofq_nt_seg.hi_only)."""
     M, N = out.shape
     dev = out.device
     arr = (_lib.NtSeg * len(segs))()
@@ -701,6 +702,10 @@ def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None, col_bias=None):
             keep.append(w)
             arr[i].amax = w.data_ptr()
         K += A.shape[1]
+    if hi_only_last:
+        if len(segs) != 2 or not f16 or segs[0][0].shape[1] % 64:
+            raise RuntimeError("ofq_amd: qgemm_bf16s_nt_sk: hi_only_last needs two fp16-code segments, the first with K % 64 == 0")
+        arr[1].hi_only = 1
     ws = _sk_workspace(dev)
     g = num_cus(dev) if wgs is None else -int(wgs)        # wgs: exactly that many workgroups (<= the CU count; tests)
     with _Timed(nt_class(f16), 2.0 * M * N * K):
@@ -1250,12 +1255,17 @@ def split_f32_f16x2(W):
     return hi.contiguous(), lo.contiguous(), 2.0 ** (-E)
 
 
-def linear_f16x4(x2d, planes, bias=None):
+F16X4_PRODUCTS = 3      # plane products of linear_f16x4: 3 = x_hi W_hi + x_lo W_hi + x_hi W_lo (the dropped x_lo W_lo is 2^-22 of a product)
+
+
+def linear_f16x4(x2d, planes, bias=None, products=None):
     """y = x2d @ W^T + bias with W as split_f32_f16x2's planes: [x | x] . [hi | lo]^T as ONE two-segment code GEMM
-    (ofq_qgemm_bf16s_nt_sk; x split into two fp16 planes inside the kernel: four plane products, fp32 accumulation)."""
+    (ofq_qgemm_bf16s_nt_sk; x split into two fp16 planes inside the kernel, fp32 accumulation): four plane products, or three
+    (the trailing planes' product skipped: half of the second segment's MFMAs) when K allows it."""
     hi, lo, inv = planes
     y = torch.empty((x2d.shape[0], hi.shape[0]), dtype=torch.float32, device=x2d.device)
-    return qgemm_bf16s_nt_sk([(x2d, hi, None, inv), (x2d, lo, None, inv)], y, col_bias=bias)
+    three = (F16X4_PRODUCTS if products is None else products) == 3 and x2d.shape[1] % 64 == 0
+    return qgemm_bf16s_nt_sk([(x2d, hi, None, inv), (x2d, lo, None, inv)], y, col_bias=bias, hi_only_last=three)
 
 
 def gemm_bf16x3x3_nt(x2d, planes, bias=None, products=9):

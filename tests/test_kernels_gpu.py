@@ -1488,3 +1488,30 @@ def test_teacher_attention_in_one_launch_vs_fp64(ops, case):
     e_hip = ((out.double() - r64).abs() / colmax).max().item()
     e_f32 = ((r32.double() - r64).abs() / colmax).max().item()
     assert e_hip < 3 * e_f32 + 1e-6, (e_hip, e_f32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mnk", [(25344, 1152, 384), (25344, 384, 1536), (1000, 1536, 384), (4096, 384, 96)])
+def test_teacher_linear_on_fp16_planes_three_and_four_products(ops, mnk):
+    """ops.linear_f16x4 (the KD teacher's fp32 linear layers: the weight split once into two fp16 planes, the activations
+    in the kernel; ofq_qgemm_bf16s_nt_sk with a column bias) with four plane products and with three (ofq_nt_seg.hi_only: the
+    trailing planes' product skipped) against the fp64 product: both within a small multiple of what a plain fp32 GEMM loses."""
+    M, N, K = mnk
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.pow(10.0, torch.randint(-2, 2, (K,), device="cuda", generator=g).float())
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g)
+    planes = ops.split_f32_f16x2(W)
+    ref = x.double() @ W.double().t() + b.double()
+    f32 = (x @ W.t() + b).double()
+    scale = ref.abs().max().item()
+    e32 = (f32 - ref).abs().max().item() / scale
+    for products in (4, 3):
+        ops.amax_begin(x.device)
+        try:
+            ops.absmax(x)
+            y = ops.linear_f16x4(x, planes, b, products=products)
+        finally:
+            ops.amax_end()
+        e = (y.double() - ref).abs().max().item() / scale
+        assert e < 3 * e32 + 2e-7, (products, e, e32)
