@@ -133,7 +133,7 @@ size_t ofq_gemm_ws_bytes(const ofq_gemm_desc* d);
 int ofq_gemm_f32(const ofq_gemm_desc* d, void* ws, size_t ws_bytes, ofq_stream_t stream);
 
 /* ---- exact integer-code GEMMs for the fake-quantised linear layers (same maths as F.linear on the fake-quant
- *  values, qlinear.py:69, with the scales factored out of the contraction; see ofq_amd/csrc/qgemm.hip)
+ *  values, qlinear.py:69, with the scales factored out of the contraction; see ofq_amd/csrc/qgemm_args.h)
  *  forward:  y[m,n] = col_mult*col_scale[n] * (a_eff[m % S] * sum_k A[m,k]*B[n,k] + r[n]) + bias[n]
  *            A = LSQ codes of the input [M][K] int8, B = weight codes [N][K] int8, a_eff from lsq_s/gscale as in
  *            ofq_lsq_fwd, r[n] = sum_k baft[k]*B[n,k] (ofq_rowdot_i8).  K, lda, ldb % 16 == 0.  i8 MFMA, exact. */

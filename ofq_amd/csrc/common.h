@@ -165,7 +165,7 @@ __device__ __forceinline__ float ofq_wave_max(float v) {
 
 // By-product of the backward kernels that WRITE a gradient tensor: max |element| as the bits of a float, into a group of
 // OFQ_AMAX_WORDS slots, OFQ_AMAX_STRIDE words apart (8 KB, zeroed by the caller), from which the two-plane fp16 GEMMs that consume the tensor take their
-// power-of-two scale (csrc/qgemm.hip, split2_f16).  m = this lane's running fmaxf(|x|) (>= 0).  One wave-wide reduction, then
+// power-of-two scale (csrc/qgemm_planes.hip, split2_f16).  m = this lane's running fmaxf(|x|) (>= 0).  One wave-wide reduction, then
 // one fire-and-forget atomic maximum per wave on the word picked by the wave's position (64 words: the ~10^4 waves of a launch
 // do not queue up behind one address, and nobody waits for a returned value).  The maximum of the group is the tensor's
 // maximum; maxima commute, so the group does not depend on the order of the updates.

@@ -11,7 +11,18 @@ extern "C" const char* ofq_source_hash(void) { return "OFQ_SOURCE_HASH=" OFQ_SOU
 #include "lsq.hip"
 #include "softmax_lsq.hip"
 #include "gemm_f32.hip"
-#include "qgemm.hip"
+#include "qgemm_args.h"
+#include "qgemm_i8.hip"
+#include "qgemm_planes.hip"
+#include "qgemm_tn.hip"
+#include "qgemm_nn.hip"
+#include "qgemm_codes.hip"
+#include "qgemm_i8_bwd.hip"
+#include "qgemm_nt_wide.hip"
+#include "qgemm_nt_sk.hip"
+#include "gemm_planes_f32.hip"
+#include "qgemm_nt_lsq.hip"
+#include "qattn_launch.hip"
 #include "qattn_fused.hip"
 #include "attn_f32.hip"
 #include "layernorm.hip"

@@ -22,8 +22,7 @@ static int lsq_geom(int64_t R, int64_t inner, int64_t bias_len, LsqGeom* g, bool
   int64_t w4 = inner / 4;
   // backward keeps three accumulator sets per float4 column: at more than two float4 per lane the kernel drops to two
   // waves per SIMD and loses the loads in flight it needs (tools/lsq_bench.py: 58 -> 38 us on 25216 x 384)
-  static const int maxj_env = getenv("OFQ_LSQ_MAXJ") ? atoi(getenv("OFQ_LSQ_MAXJ")) : 0;      // experiment knob
-  const int maxj = maxj_env ? maxj_env : (bwd ? 2 : 4);
+  const int maxj = bwd ? 2 : 4;
   int TX = 16;
   while (TX < 256 && ceil_div(w4, TX) > 4) TX <<= 1;
   int J = (int)ceil_div(w4, TX);

@@ -248,7 +248,7 @@ extern "C" int ofq_gelu_fwd(const float* x, float* y, int64_t n, void* amax_out,
 // ---- max |x| of a gradient tensor, as the bits of a float in a group of OFQ_AMAX_WORDS device words whose maximum is the result
 // (atomic maxima over the bit patterns of |x|: they order like the values, and a maximum does not depend on the order of its
 // updates -- deterministic; see ofq_amax_publish).  The two-plane fp16 form of the
-// backward GEMMs (csrc/qgemm.hip, split2_f16) takes its power-of-two scale from such a word; the backward kernels that PRODUCE a
+// backward GEMMs (csrc/qgemm_planes.hip, split2_f16) takes its power-of-two scale from such a word; the backward kernels that PRODUCE a
 // gradient tensor write it as a by-product (their amax_out argument), this kernel serves producers that do not.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int cols4, int64_t ld,
                                                      unsigned* __restrict__ amax) {

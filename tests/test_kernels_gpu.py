@@ -475,7 +475,7 @@ def test_two_segment_dx_gemm_is_the_sum_of_the_two_gemms(ops, mnkk):
 
 
 def test_stream_k_handoff_timeout_is_raised_sticky_and_recoverable(ops):
-    """The hand-off of a cut tile (csrc/qgemm.hip, qgemm_bf16s_nt_wide_sk_kernel): a publisher that never sets its flag (fault
+    """The hand-off of a cut tile (csrc/qgemm_nt_sk.hip, qgemm_bf16s_nt_wide_sk_kernel): a publisher that never sets its flag (fault
     injection word of the workspace) makes the owner's bounded wait run out.  Then: the error word is raised and STAYS raised over
     later launches; ops.nt_sk_poison turns a step's loss into NaN without a host sync; ops.nt_sk_poll raises on the host at the next
     step boundary and re-zeroes the flag area; and the launches after that give the right bits again."""

@@ -1,4 +1,4 @@
-"""The two-plane fp16 form of the backward code GEMMs (round 5; include/ofq_hip.h: ofq_qgemm_bf16s_nt with `amax`, csrc/qgemm.hip
+"""The two-plane fp16 form of the backward code GEMMs (round 5; include/ofq_hip.h: ofq_qgemm_bf16s_nt with `amax`, csrc/qgemm_planes.hip
 split2_f16) against fp64 and against the three-plane bf16 form (the exact fp32 product of rounds 1-4).  Reference ops: autograd of
 F.linear (qlinear.py:69) and of the QKR scores (attention.py:207-210).
 

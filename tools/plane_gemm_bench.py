@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""ofq_gemm_bf16x3x3_nt (the fp32 KD teacher's linear layers) on the DeiT-S shapes at 128 images; OFQ_PLANE_GEMM_NARROW=1
-selects the 128 x 128 kernel."""
+"""ofq_gemm_bf16x3x3_nt (the fp32 KD teacher's linear layers) on the DeiT-S shapes at 128 images."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
