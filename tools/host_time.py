@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the step host-bound?  Time the Python enqueue of N steps (no sync) against the GPU completion time, for the launch modes
 of bench.py / train.py:  MODE=eager (default: one ctypes launch per kernel), graph (whole step replayed), and with DP=1 (one rank
-over RCCL, the data-parallel wrapper active) eager / split (captured compute, eager collectives: the several-rank default) /
+over RCCL, the data-parallel wrapper active) eager / split (captured compute, eager collectives) / segmented (sub-graphs cut at the gradient buckets, each bucket's all-reduce behind its sub-graph: the several-rank default) /
 graph (collectives captured too)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
