@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-qkr", action="store_true")
     ap.add_argument("--cga", action="store_true", help="add the CGA mask/restore hooks (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recipe-line", action="store_true",
+                    help="skip the auxiliary measurement of the KD recipe step (fp32 teacher forward inside the step, train.py:906-910)")
     ap.add_argument("--no-c1-baseline", action="store_true", help="skip the second CPU line (BASELINE config 1, DeiT-T W4A4 B=32)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -230,6 +232,22 @@ def self_launch(args):
     sys.stdout.flush()
     codes = [p.wait() for p in procs]
     raise SystemExit(max(abs(c) for c in codes) if failed is None else (abs(failed[1]) or 1))
+
+
+def recipe_step_line():
+    """Auxiliary, outside the timed region: the same step with the reference recipe's fp32 teacher forward in it (train.py:906-910
+    calls `teacher(input)` every step; the headline metric feeds synthetic teacher logits instead), measured by a child
+    process of this script.  Reported next to the headline, never instead of it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--with-teacher", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+           "--no-roofline-events", "--no-recipe-line"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT)
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "what": "the same step with the fp32 KD teacher's forward inside it (bench.py --with-teacher: " + d["config"]["workload"] + ")"}
+    except Exception as e:                                           # noqa: BLE001  (an auxiliary line must not take the headline down)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def main():
@@ -437,6 +455,9 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
+        if (world == 1 and default_cfg and not args.with_teacher and not args.no_recipe_line and not args.no_cpu_baseline
+                and use_graph and not args.cga and not args.force_dp):
+            out["recipe_step"] = recipe_step_line()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
