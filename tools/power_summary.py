@@ -17,7 +17,7 @@ if pcis and mine and mine[0] in pcis[0]:
     c = pcis[0].index(mine[0])
 print("\n".join(head))
 print("card index %d (power swing %.0f W; the other cards: %s)" % (c, swing[c], " ".join("%.0f" % s for i, s in enumerate(swing) if i != c)))
-print("%-36s %8s %8s %8s %8s %8s %10s" % ("phase", "P_mean_W", "P_max_W", "f_mean", "f_min", "samples", "us/launch"))
+print("%-66s %8s %8s %8s %8s %8s %10s" % ("phase", "P_mean_W", "P_max_W", "f_mean", "f_min", "samples", "us/launch"))
 for l in open(phases):
     if not l.startswith("phase"):
         continue
@@ -26,8 +26,8 @@ for l in open(phases):
     name = " ".join(parts[1:-4])
     sel = [r for r in data if ts + 300 <= r[0] <= t1 - 100]
     if not sel:
-        print("%-36s (no samples)" % name)
+        print("%-66s (no samples)" % name)
         continue
     P = [r[1 + 2 * c] for r in sel]
     F = [r[2 + 2 * c] for r in sel]
-    print("%-36s %8.0f %8.0f %8.0f %8.0f %8d %10.1f" % (name, sum(P) / len(P), max(P), sum(F) / len(F), min(F), len(sel), us))
+    print("%-66s %8.0f %8.0f %8.0f %8.0f %8d %10.1f" % (name, sum(P) / len(P), max(P), sum(F) / len(F), min(F), len(sel), us))
