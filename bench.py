@@ -234,20 +234,38 @@ def self_launch(args):
     raise SystemExit(max(abs(c) for c in codes) if failed is None else (abs(failed[1]) or 1))
 
 
+def _child_line(extra_args, env_extra, what):
+    """One more measurement next to the headline, by a CHILD process of this script after the headline's timed region (a second
+    context on the GPU while the parent still holds its model: ~25 GB resident of 288).  Returns the child's numbers, or an
+    `error` object carrying the tail of the child's stderr (an auxiliary line must not take the headline down, nor fail silently)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ["--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                                                                      "--no-roofline-events", "--no-recipe-line"]
+    err = b""
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=dict(os.environ, **env_extra))
+        err = r.stderr
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+                "grad_planes": d["config"].get("grad_planes"), "what": what + " (" + d["config"]["workload"] + ")"}
+    except Exception as e:                                           # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e), "stderr_tail": err.decode("utf-8", "replace")[-600:]}
+
+
 def recipe_step_line():
     """Auxiliary, outside the timed region: the same step with the reference recipe's fp32 teacher forward in it (train.py:906-910
-    calls `teacher(input)` every step; the headline metric feeds synthetic teacher logits instead), measured by a child
-    process of this script.  Reported next to the headline, never instead of it."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--with-teacher", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-           "--no-roofline-events", "--no-recipe-line"]
-    try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT)
-        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                "what": "the same step with the fp32 KD teacher's forward inside it (bench.py --with-teacher: " + d["config"]["workload"] + ")"}
-    except Exception as e:                                           # noqa: BLE001  (an auxiliary line must not take the headline down)
-        return {"error": "%s: %s" % (type(e).__name__, e)}
+    calls `teacher(input)` every step; the headline metric feeds synthetic teacher logits instead).  Reported next to
+    the headline, never instead of it."""
+    return _child_line(["--with-teacher"], {}, "the same step with the fp32 KD teacher's forward inside it: bench.py --with-teacher")
+
+
+def exact_backward_line():
+    """Auxiliary, outside the timed region: the same step with every backward code GEMM on its fp32-EXACT form (the gradient operand
+    cut into three bf16 planes, OFQ_GRAD_PLANES=3) instead of the default two fp16 planes of the power-of-two-scaled tensor
+    (fp32-grade on the tensor's scale, not element-wise fp32) -- the reference recipe is `amp: False`
+    (configs/ours_imagenet_recipe.attn_q.yml:27), so the number on its own arithmetic is reported next to the headline."""
+    return _child_line([], {"OFQ_GRAD_PLANES": "3"},
+                       "the same step with exact-fp32-product backward GEMMs (3 bf16 planes): OFQ_GRAD_PLANES=3 python bench.py")
 
 
 def main():
@@ -436,7 +454,11 @@ def main():
                   else "images/sec QAT (%s W%dA%d, 224px synthetic)" % (args.model, args.wbits, args.abits))
         out = {"metric": metric, "value": round(value, 2), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               # fp32 storage and accumulation everywhere; the precision trade of the backward GEMMs is part of the record
+               "dtype": ("f32 (backward GEMM gradient operands as 2 fp16 planes of the 2^E-scaled tensor, fp32 accumulate)"
+                         if ops.GRAD_PLANES == 2 else "f32 (backward GEMM gradient operands as 3 bf16 planes: exact fp32 products)"),
+               "data": "synthetic",
                "config": {"workload": "%s W%dA%d%s%s QAT step (student fwd + KD loss + bwd + AdamW), %d img/GPU, "
                                       "%s, fp32, %s"
                                       % (args.model, args.wbits, args.abits, "" if args.no_qkr else " QKR",
@@ -445,6 +467,7 @@ def main():
                                          ("fp32 teacher forward in the step (%s)" % ("stock PyTorch-ROCm" if args.stock_teacher else "HIP kernels, GEMMs " + args.teacher_gemm))
                                          if args.with_teacher else "teacher logits synthetic"),
                           "global_batch": B * world, "parallelism": "dp%d" % world, "loss": float(loss_value),
+                          "grad_planes": ops.GRAD_PLANES,
                           "launch": ("eager (one ctypes launch per kernel)" if not use_graph else "hipGraph replay" if graph_mode == "full"
                                      else "hipGraph replay of the compute, bucket all-reduces eager between two graphs" if graph_mode == "split"
                                      else "hipGraph replay in %d sub-graphs cut at the gradient buckets, each bucket's all-reduce issued "
@@ -458,6 +481,8 @@ def main():
         if (world == 1 and default_cfg and not args.with_teacher and not args.no_recipe_line and not args.no_cpu_baseline
                 and use_graph and not args.cga and not args.force_dp):
             out["recipe_step"] = recipe_step_line()
+            if ops.GRAD_PLANES == 2:
+                out["exact_fp32_backward"] = exact_backward_line()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

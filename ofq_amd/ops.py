@@ -383,6 +383,15 @@ def linear_bwd_weight(dy, x2d):
 # the dtype of the codes they are handed, so tests can drive either form explicitly.
 GRAD_PLANES = 3 if os.environ.get("OFQ_GRAD_PLANES") == "3" else 2
 _DBG_F16 = {"dx", "dw", "dqkx", "dxq"}      # which GEMM families take the two-plane form (tools/two_rank_determinism.py narrows it)
+# Test hook (tests/test_planes_fullsize_gpu.py): PLANE_PROBE(kind, A2d, k_scale or None, scale_axis, ncols) is called with the fp32
+# gradient operand of every backward code GEMM that is about to be split into planes -- the operand as the kernel scales it is
+# A * k_scale along `scale_axis` (1: per column = contraction index of dX; 0: per row, period len(k_scale), = the tokens of dW).
+PLANE_PROBE = None
+
+
+def _probe(kind, A, k_scale, axis, ncols=None):
+    if PLANE_PROBE is not None:
+        PLANE_PROBE(kind, A, k_scale, axis, ncols)
 
 
 def codes_transpose_bf16(codes):
@@ -441,15 +450,29 @@ def amax_word(device):
 
 
 def tag_amax(t, word):
-    t._ofq_amax = word
+    """Attach a maximum word to the tensor object, together with the version counter and address it was valid for: autograd's
+    input buffers add a second gradient IN PLACE (`old.add_(new)`) when they hold the only reference, and the Python object -- with
+    its attribute -- survives that; the in-place add bumps the version counter, and amax_of() then ignores the stale word."""
+    t._ofq_amax = (word, t._version, t.data_ptr())
     return t
 
 
+def _amax_valid(t):
+    tag = getattr(t, "_ofq_amax", None)
+    if tag is None:
+        return None
+    word, version, ptr = tag
+    if t._version != version or t.data_ptr() != ptr:
+        return None                   # written by somebody else since the producer's kernel: the word is no bound any more
+    return word
+
+
 def amax_of(t):
-    """The maximum word a producer attached to `t` (or to the tensor `t` is a view of: an upper bound is all that is needed)."""
-    w = getattr(t, "_ofq_amax", None)
+    """The maximum word a producer attached to `t` (or to the tensor `t` is a view of: an upper bound is all that is needed), or
+    None when there is none or the tensor has been modified in place since (views share their base's version counter)."""
+    w = _amax_valid(t)
     if w is None and t._base is not None:
-        w = getattr(t._base, "_ofq_amax", None)
+        w = _amax_valid(t._base)
     return w
 
 
@@ -461,7 +484,8 @@ def absmax(t2d):
         w[:1].copy_(t2d.detach().abs().max().reshape(1).view(torch.int32))       # odd geometry: the stock reduction
     else:
         _chk(lib().ofq_absmax_f32(t2d.data_ptr(), rows, cols, t2d.stride(0), w.data_ptr(), _stream()), "ofq_absmax_f32")
-    return tag_amax(t2d, w)._ofq_amax
+    tag_amax(t2d, w)
+    return w
 
 
 def amax_for(t2d):
@@ -701,6 +725,7 @@ def qgemm_bf16s_nt_sk(segs, out, accumulate=False, wgs=None, col_bias=None, hi_o
             w = amax_for(A)
             keep.append(w)
             arr[i].amax = w.data_ptr()
+        _probe("dx", A, ks, 1)
         K += A.shape[1]
     if hi_only_last:
         if len(segs) != 2 or not f16 or segs[0][0].shape[1] % 64:
@@ -761,6 +786,7 @@ def qgemm_bf16s_nt(A, B_bf16, k_scale, alpha, out=None, accumulate=False, nsplit
         amax = amax_for(A)
     if not f16:
         amax = None
+    _probe("dx", A, k_scale, 1)
     with _Timed(nt_class(f16), 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt(A.data_ptr(), B_bf16.data_ptr(), out.data_ptr(), _p(k_scale), alpha, int(accumulate),
                                       2 if f16 else nsplit, M, N, K, A.stride(0), B_bf16.stride(0), out.stride(0), _p(amax),
@@ -815,6 +841,7 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
         db = torch.empty(M, dtype=torch.float32, device=dy2d.device)
     ws = workspace(lib().ofq_qgemm_bf16s_tn_ws_bytes(M, N, split), dy2d.device)
     amax = _planes_amax(dy2d, planes)
+    _probe("dw", dy2d, lsq_eff_scale(lsq_s, gscale) if PLANE_PROBE is not None else None, 0)
     with _Timed('qgemm_bf16s_tn_wide (linear dW, %s)' % _pl(amax is not None), 2.0 * Ktok * M * N):
         _chk(lib().ofq_qgemm_bf16s_tn(dy2d.data_ptr(), xcodes2d.data_ptr(), dW.data_ptr(), lsq_s.data_ptr(), S, gscale,
                                       _p(db), int(compute_db), _p(baft), Ktok, M, N, dy2d.stride(0), xcodes2d.stride(0),
@@ -869,6 +896,7 @@ def qgemm_bf16s_tn_group(jobs, split=None, planes=None):
             w = _planes_amax(dy, planes)
         keep.append(w)
         a.amax = _p(w)
+        _probe("dw", dy, lsq_eff_scale(j["lsq_s"], j["gscale"]) if PLANE_PROBE is not None else None, 0)
     if split is None:
         split = max(1, min(256 // tiles, nkt // 4))
     dev = jobs[0]["dy2d"].device
@@ -1039,6 +1067,7 @@ def scores_amax(dS, N, planes=None):
 def qattn_dqkx(dS, xcodes, sx, gx, bax, B, H, N, C, ldS, planes=None):
     dq = torch.empty((B, N, H, C), dtype=torch.float32, device=dS.device)
     amax = scores_amax(dS, N, planes) if "dqkx" in _DBG_F16 else None
+    _probe("dqkx", dS.view(-1, dS.shape[-1]), None, 1, N)
     with _Timed('qgemm_bf16s_tn_wide_stream (attention dqkx, %s)' % _pl(amax is not None), 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dqkx_bf16s(dS.data_ptr(), xcodes.data_ptr(), dq.data_ptr(), sx.data_ptr(), gx, _p(bax), B, H, N, C,
                                         ldS, _p(amax), _stream()), "ofq_qattn_dqkx_bf16s")
@@ -1049,6 +1078,7 @@ def qattn_dxq(dS, qcodes, sq, gq, B, H, N, C, ldS, out=None, accumulate=False, p
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dS.device)
     amax = scores_amax(dS, N, planes) if "dxq" in _DBG_F16 else None
+    _probe("dxq", dS.view(-1, dS.shape[-1]), None, 1, N)
     with _Timed('qgemm_bf16s_nn_wide (attention dxq, %s)' % _pl(amax is not None), 2.0 * B * H * N * N * C):
         _chk(lib().ofq_qattn_dxq_bf16s(dS.data_ptr(), qcodes.data_ptr(), out.data_ptr(), sq.data_ptr(), gq, int(accumulate), B,
                                        H, N, C, ldS, _p(amax), _stream()), "ofq_qattn_dxq_bf16s")

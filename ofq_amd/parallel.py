@@ -126,9 +126,20 @@ class DataParallel(torch.nn.Module):
     def _broadcast(self, flat):
         w = dist.broadcast(flat, src=0, group=self.group, async_op=True)
         w.wait()
-        if not hasattr(self, "_eager_works"):
-            self._eager_works = []
-        self._eager_works.append(w)
+        self._keep_work(w)
+
+    def _keep_work(self, w):
+        """Remember the Work handle of an eager collective for drain_collectives() -- but only while it may still be in flight:
+        a replayed step issues its collectives from the host on every step (modes "split" / "segmented") and nothing else
+        would ever trim the list (zero_grad / finish_gradient_sync sit inside the captured graphs).  Handles that report
+        completion are dropped as new ones arrive, so the list holds the last step's handles, not the run's, and no finished
+        collective keeps its tensors (the StatsQ mean vector, the broadcast's flat copy of the weights) alive."""
+        works = getattr(self, "_eager_works", None)
+        if works is None:
+            works = self._eager_works = []
+        if len(works) >= 8:
+            works[:] = [x for x in works if not x.is_completed()]
+        works.append(w)
 
     def _latch_quantizers(self):
         return [m for m in self.module.modules() if hasattr(m, "sync_latch") and hasattr(m, "latched")]
@@ -203,8 +214,6 @@ class DataParallel(torch.nn.Module):
         self.zero_grad()
 
     def _reset(self):
-        if len(self._eager_works) > 256:              # (eager training never drains: keep the tail, a drain synchronises anyway)
-            del self._eager_works[:-64]
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
@@ -249,7 +258,7 @@ class DataParallel(torch.nn.Module):
             b.flat.div_(self.world)
             w = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if not _capturing(b.flat):
-            self._eager_works.append(w)
+            self._keep_work(w)
         return w
 
     def all_reduce_bucket(self, i):
@@ -384,7 +393,7 @@ class DataParallel(torch.nn.Module):
             w.wait()
             mean.div_(self.world)
         if not _capturing(local):
-            self._eager_works.append(w)
+            self._keep_work(w)
         dev = (mean - local).abs().max()                 # stays on the device ...
         if self._statsq_pending is None:                 # (a persistent scalar: a captured step max-accumulates into the
             self._statsq_pending = torch.zeros((), dtype=dev.dtype, device=dev.device)     # same memory in every replay)

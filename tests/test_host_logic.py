@@ -288,3 +288,23 @@ def test_grad_slot_hands_out_bucket_slices_only_when_safe():
     for h in dp._hooks:
         h.remove()
 
+
+
+def test_amax_word_is_dropped_when_the_tensor_is_modified_in_place():
+    """ops.tag_amax / amax_of (the power-of-two scale of the two-plane backward GEMMs): autograd's input buffers add a second
+    gradient in place (`old.add_(new)`) when they hold the only reference, and the Python object -- with the producer's maximum
+    word on it -- survives; a too-small maximum would overflow the fp16 planes silently.  The tag carries the version
+    counter and address it was valid for."""
+    from ofq_amd import ops
+    t = torch.ones(4, 8)
+    word = torch.zeros(1, dtype=torch.int32)
+    ops.tag_amax(t, word)
+    assert ops.amax_of(t) is word
+    assert ops.amax_of(t.view(2, 16)) is word            # a reshape in between keeps the word (views share the version counter)
+    v = t.view(32)
+    t.add_(torch.full((4, 8), 100.0))                    # what InputBuffer::add does to a gradient it owns
+    assert ops.amax_of(t) is None and ops.amax_of(v) is None and ops.amax_of(t.view(2, 16)) is None
+    ops.tag_amax(t, word)
+    assert ops.amax_of(t) is word
+    t.set_(torch.zeros(4, 8))                            # other memory under the same object
+    assert ops.amax_of(t) is None

@@ -146,6 +146,14 @@ def _worker(rank, world, port, q):
     g_seg = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.requires_grad])
     assert torch.equal(g_seg, g_sync)
     assert dp.check_reduced_gradients() == 0.0           # every rank holds the same reduced bytes
+    # a REPLAYED step issues its collectives from the host every step and never passes through zero_grad / finish_gradient_sync
+    # (they sit inside the captured graphs): the Work handles kept for drain_collectives() must not pile up (ADVICE r5:
+    # len(buckets) + 1 handles leaked per step, each pinning an event and its tensors)
+    for _ in range(200):
+        for i in range(len(dp.buckets)):
+            dp.all_reduce_bucket(i)
+        dp.wait_collectives()
+    assert len(dp._eager_works) <= 8 + len(dp.buckets), len(dp._eager_works)
     assert dp.drain_collectives() > 0 and dp.drain_collectives() == 0       # every eager collective so far has completed
     if rank == 1:
         dp.buckets[0].flat[0] += 1.0                       # ... and a rank whose gradients differ is caught

@@ -9,7 +9,7 @@ import torch
 from ofq_amd import ops
 from tools.gemm_bench import bench  # noqa
 
-T, Bn, C, H = 197, 128, 384, 6
+T, Bn, C, H = 198, 128, 384, 6
 M = Bn * T
 torch.manual_seed(0)
 
