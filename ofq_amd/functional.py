@@ -56,8 +56,11 @@ class CodeWeightLinearFn(torch.autograd.Function):
         N, K = codes.shape
         ctx.xaux = xaux
         if N > 128 and K % 8 == 0 and x2d.is_contiguous():
-            # y = steps[n] * (x . code[n, :]) + bias[n]: the activations as planes (two fp16 / three bf16) against the codes
-            c16 = codes.to(torch.float16 if ops.GRAD_PLANES == 2 else torch.bfloat16)
+            # y = steps[n] * (x . code[n, :]) + bias[n]: the activations as THREE bf16 planes (the exact fp32 product) against the
+            # codes, whatever ops.GRAD_PLANES says: the two-plane trade of DESIGN 4b is a backward-only trade, the forward pass --
+            # values and integer levels -- is the same bits in both modes (round 5 ran this one forward GEMM on two fp16 planes
+            # under GRAD_PLANES = 2; tests/test_planes_fullsize_gpu.py compares the losses of the two modes and found it)
+            c16 = codes.to(torch.bfloat16)
             y = ops.qgemm_bf16s_nt(x2d, c16, None, 1.0, col_scale=steps, col_bias=bias)
         else:
             y = ops.linear_fwd(x2d, Wq, bias)

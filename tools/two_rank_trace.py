@@ -15,12 +15,11 @@ A repetition whose trace differs from the first repetition's is reported with it
     MODE=ranks   two ranks of one gloo group sharing GPU 0 (the failing case)
     MODE=solo    two INDEPENDENT processes sharing GPU 0, each with its own one-rank gloo group (or no wrapper: nodp)
 
-    CFGS="base|sync|hand|bigbucket|noslot|nodefer|nodp"  ('+' combines), REPS=n, STEPS=5
+    CFGS="base|sync|hand|bigbucket|nodefer|nodp"  ('+' combines), REPS=n, STEPS=5
 
     sync       torch.cuda.synchronize() before every all-reduce
     hand       hand-rolled all-reduce: synchronize, device -> host, dist.all_reduce on the CPU tensor, host -> device
     bigbucket  one bucket, reduced after the backward pass
-    noslot     dW kernels do not write into the bucket slices (parallel.grad_slot off)
     nodefer    no deferred dW groups, no deferred second-stage sums
     planes3    three bf16 planes (the exact backward GEMMs)
 """
@@ -47,6 +46,8 @@ def run_variant(torch, dist, engine, parallel, ops, Fn, base, batches, crit, fla
     Fn.SUM_DEFER = "nodefer" not in flags
     Fn.DW_GROUP = "nodefer" not in flags
     traces = []
+    full0, details = None, {}
+    want_full = os.environ.get("FULL") == "1"
     t0 = time.time()
     for rep in range(reps):
         model = copy.deepcopy(base).train()
@@ -54,14 +55,14 @@ def run_variant(torch, dist, engine, parallel, ops, Fn, base, batches, crit, fla
         dp = None
         if "nodp" not in flags:
             dp = parallel.DataParallel(model, bucket_mb=1000.0 if "bigbucket" in flags else 1.0, force_sync=True)
-            if "noslot" in flags:
-                parallel._GRAD_SLOTS.clear()
         opt = engine.make_optimizer(model, lr=5e-4, weight_decay=0.05)
-        keys, vals, step = [], [], [0]
+        keys, vals, step, full = [], [], [0], {}
 
         def rec(stage, name, t):
             keys.append((step[0], stage, name))
             vals.append(ck(t))
+            if want_full and stage in ("pre", "grad"):
+                full[(step[0], stage, name)] = t.detach().clone()
 
         if dp is not None:
             orig_ar, orig_fin = dp._all_reduce, dp.finish_gradient_sync
@@ -103,6 +104,26 @@ def run_variant(torch, dist, engine, parallel, ops, Fn, base, batches, crit, fla
                 rec("param", n, p)
         torch.cuda.synchronize()
         traces.append((keys, torch.stack(vals).cpu()))
+        if want_full:
+            if full0 is None:
+                full0 = full
+            elif not torch.equal(traces[-1][1], traces[0][1]) and keys == traces[0][0]:
+                # every differing gradient of the FIRST differing step, in record (= arrival) order: how many elements, how far
+                d = (traces[-1][1] != traces[0][1]).nonzero().reshape(-1).tolist()
+                first_step = keys[d[0]][0]
+                lines = []
+                for j in d:
+                    k = keys[j]
+                    if k[0] != first_step or k not in full or k not in full0:
+                        continue
+                    a, b = full[k].double(), full0[k].double()
+                    ne = (full[k] != full0[k])
+                    idx = ne.reshape(-1).nonzero().reshape(-1)
+                    lines.append("%s %-52s shape %-16s differing %d of %d, max |diff| %.3e, max |value| %.3e, first flat indices %s"
+                                 % (k[:2], k[2], tuple(a.shape), int(ne.sum()), a.numel(), float((a - b).abs().max()),
+                                    float(b.abs().max()), idx[:6].tolist()))
+                details[rep] = lines
+            del full
         if dp is not None:
             dp.release()
             del dp._all_reduce, dp.finish_gradient_sync
@@ -126,6 +147,8 @@ def run_variant(torch, dist, engine, parallel, ops, Fn, base, batches, crit, fla
                                                       "REPRODUCIBLE" if not bad else "%d of %d DIFFER" % (len(bad), reps - 1)), flush=True)
     for r, msg in bad[:6]:
         print("    rep %d: %s" % (r, msg), flush=True)
+        for ln in details.get(r, [])[:40]:
+            print("        " + ln, flush=True)
     return len(bad)
 
 
