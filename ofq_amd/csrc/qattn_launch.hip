@@ -168,7 +168,7 @@ extern "C" int ofq_qattn_prep(const int8_t* xcodes, const float* baq, float* u, 
                               ofq_stream_t stream) {
   if (!xcodes || !baq || !u || !qcodes || !bax || !tq || !vcodes || !vT || B <= 0 || H <= 0 || N <= 0 || Np < N) return OFQ_EINVAL;
   if ((C & 15) || (Np & 3) || C > 512 || !al16(xcodes) || !al16(qcodes) || !al16(baq) || !al16(bax) || !al16(vcodes) || !al16(vT) ||
-      B * N * H >= (1ll << 31))
+      B * N * H >= (1ll << 31) || B * N * H * C >= (1ll << 32))
     return OFQ_EINVAL;
   AttnPrepArgs a = {};
   a.xcodes = xcodes; a.baq = baq; a.u = u; a.qcodes = qcodes; a.bax = bax; a.tq = tq; a.vcodes = vcodes; a.vT = vT;

@@ -51,29 +51,42 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
   };
   if (K <= 512) {
     // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
-    // for the four rows of the group
+    // for the four rows of the group.  Row offsets are 32-bit (rows x K < 2^31, host check) on the uniform base pointer, the
+    // loads unconditional on clamped offsets, and every offset register stays LIVE until its data has been consumed (the empty
+    // asm statements below): round 6 traced the one non-reproducible result of a training step on a shared GPU to this
+    // routine -- tq of rows (row % 64) in {35, 39, 43, 47}, i.e. lanes 48..63 of the THIRD row load, the one whose destination
+    // registers the compiler had laid over the load's own 64-bit address pair (global_load_dwordx4 v[2:5], v[2:3], off) --
+    // wrong in 1-4 of 2376 rows about once in 400 calls, with the inputs in memory verified before and after the launch
+    // (tools/two_rank_trace.py DUMP_OP=qattn_prep).
     const bool in0 = k0 < K, in1 = k0 + 256 < K;
     i32x4 c0[RD16_RPG], c1[RD16_RPG];
+    unsigned off0[RD16_RPG], off1[RD16_RPG];
 #pragma unroll
     for (int j = 0; j < RD16_RPG; ++j) {
-      const int n = min(nb + 16 * j, N - 1);
-      const int8_t* row = codes + (int64_t)n * K;
-      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
-      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
+      const unsigned n = (unsigned)min(nb + 16 * j, N - 1);
+      off0[j] = n * (unsigned)K + (unsigned)(in0 ? k0 : 0);
+      off1[j] = n * (unsigned)K + (unsigned)(in1 ? k0 + 256 : 0);
     }
-    if (in0) {
-      float4 v[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
-#pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
+    for (int j = 0; j < RD16_RPG; ++j) {
+      c0[j] = *reinterpret_cast<const i32x4*>(codes + off0[j]);
+      c1[j] = *reinterpret_cast<const i32x4*>(codes + off1[j]);
     }
-    if (in1) {
-      float4 v[4];
+    float4 v0[4], v1[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
+    for (int w = 0; w < 4; ++w) {
+      v0[w] = *reinterpret_cast<const float4*>(vec + (in0 ? k0 : 0) + 4 * w);
+      v1[w] = *reinterpret_cast<const float4*>(vec + (in1 ? k0 + 256 : 0) + 4 * w);
+    }
 #pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
+    for (int j = 0; j < RD16_RPG; ++j) {
+      float t = 0.f;                                         // (the same association as ever: 0 + chunk 0, then + chunk 1)
+      fma16(t, k0, c0[j], v0);
+      const float a = in0 ? t : 0.f;
+      t = a;
+      fma16(t, k0 + 256, c1[j], v1);
+      asm volatile("" :: "v"(off0[j]), "v"(off1[j]));       // (the offsets outlive the loads' results: no destination may alias them)
+      acc[j] = in1 ? t : a;
     }
   } else {
 #pragma unroll
@@ -122,7 +135,7 @@ extern "C" int ofq_codes_transpose_f16(const int8_t* codes, void* out_bf16, int6
 extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, int64_t rows, int64_t cols,
                              ofq_stream_t stream) {
   if (!codes || !vec || !out || rows <= 0 || cols <= 0) return OFQ_EINVAL;
-  if ((cols & 15) == 0 && al16(codes) && al16(vec))
+  if ((cols & 15) == 0 && al16(codes) && al16(vec) && rows * cols < (1ll << 32))        // (32-bit row offsets)
     hipLaunchKernelGGL(rowdot_i8_v16_kernel, dim3((unsigned)ceil_div(rows, 16 * RD16_RPG)), dim3(256), 0, (hipStream_t)stream, codes, vec,
                        out, (int)rows, (int)cols);
   else
@@ -130,6 +143,17 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
                        (int)rows, (int)cols);
   OFQ_LAUNCH_CHECK();
   return 0;
+}
+
+// Rows of the workgroup tile of the linear layers' int8 kernels (forward and recompute backward): 64 (four 32 x 64 waves, more
+// and smaller workgroups in flight) or 128 (four 64 x 64 waves).  Test hook: OFQ_I8_TILE_ROWS=64|128 forces one (read at every
+// launch, so that a test can compare the two forms bit for bit at one shape).
+static int i8_lin_tile_rows(int64_t M, int64_t N, int64_t K) {
+  const char* e = getenv("OFQ_I8_TILE_ROWS");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 64 || forced == 128) return forced;
+  (void)M; (void)N; (void)K;
+  return 128;
 }
 
 static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
@@ -145,11 +169,14 @@ static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const flo
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
-  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  const int rows = i8_lin_tile_rows(M, N, K);
+  a.tiles_m = (int)ceil_div(M, rows); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
   a.qout = qout; a.ldq = ldq; a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4;
   a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu; a.qrowmul = q_rowmul;
   a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
-  hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  if (rows == 64) hipLaunchKernelGGL((qgemm_i8_lin_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((qgemm_i8_lin_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

@@ -527,7 +527,7 @@ class AllWqkFn(torch.autograd.Function):
     The backward runs once, when the last block's gradient has arrived, i.e. at the end of the model's backward."""
 
     @staticmethod
-    def forward(ctx, H, *ws):
+    def forward(ctx, H, want_gbuf, *ws):
         L = len(ws) // 2
         Wq = torch.stack(ws[0::2])                                    # (L, H*d, C)
         Wk = torch.stack(ws[1::2])
@@ -541,14 +541,18 @@ class AllWqkFn(torch.autograd.Function):
         ctx.H = H
         ctx.set_materialize_grads(False)
         # one buffer for the L gradients that come back: the dW GEMMs of the W_qk layers write their slices of it directly
-        # (all_wqk hands the slices out as `_ofq_grad_out`), and the backward below reads it without a 42 MB torch.stack
-        ctx.gbuf = torch.empty((L, H * C, C), dtype=torch.float32, device=Wq.device)
-        _WQK_GBUF[0] = ctx.gbuf
-        return tuple(out.unbind(0))
+        # (all_wqk hands the slices out as `_ofq_grad_out`), and the backward below reads it without a 42 MB torch.stack.
+        # Only when a backward pass can follow (want_gbuf: decided by the caller, grad mode is off inside a Function's forward);
+        # it travels back as a non-differentiable extra output, not through a module global
+        ctx.gbuf = torch.empty((L, H * C, C), dtype=torch.float32, device=Wq.device) if want_gbuf else None
+        extra = ctx.gbuf if ctx.gbuf is not None else out.new_empty(0)
+        ctx.mark_non_differentiable(extra)
+        return tuple(out.unbind(0)) + (extra,)
 
     @staticmethod
     def backward(ctx, *gs):
         flush_dw()                         # the W_qk gradients of the last blocks may still be queued
+        gs = gs[:-1]                       # (the last output is the gradient buffer itself)
         Wq, Wk = ctx.saved_tensors
         H = ctx.H
         L, _, C = Wq.shape
@@ -564,13 +568,12 @@ class AllWqkFn(torch.autograd.Function):
                  tile_hint=64 if d <= 64 else 0)
         ops.gemm(Wq, g, dWk, d, C, C, C, C, C, nb0=L * H, sA=(d * C, 0), sB=(C * C, 0), sC=(d * C, 0),
                  tile_hint=64 if d <= 64 else 0)
-        grads = [None]
+        grads = [None, None]
         for l in range(L):
             grads += [dWq[l], dWk[l]]
         return tuple(grads)
 
 
-_WQK_GBUF = [None]                 # AllWqkFn.forward -> all_wqk: the gradient buffer of the products just formed
 BULK_WQK = os.environ.get("OFQ_NO_BULK_WQK", "0") != "1"
 STEP_CACHE_ACTIVE = False          # set by engine.train_step around the forward (see engine.refresh_weight_codes)
 
@@ -588,11 +591,12 @@ def all_wqk(attns):
     ws = []
     for a in attns:
         ws += [a.q.weight, a.k.weight]
-    outs = AllWqkFn.apply(a0.num_heads, *ws)
-    gbuf, _WQK_GBUF[0] = _WQK_GBUF[0], None
+    want_gbuf = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
+    outs = AllWqkFn.apply(a0.num_heads, want_gbuf, *ws)
+    outs, gbuf = outs[:-1], (outs[-1] if want_gbuf else None)
     for l, (a, w) in enumerate(zip(attns, outs)):
         w._ofq_flushes = True              # AllWqkFn.backward flushes the dW queue before it reads this tensor's gradient
-        if gbuf is not None and torch.is_grad_enabled():
+        if gbuf is not None:
             w._ofq_grad_out = gbuf[l]      # where this block's W_qk gradient is to be written (CodesLinearFn.backward)
         a._wqk_pre = w
     if STEP_CACHE_ACTIVE:

@@ -55,10 +55,14 @@ def lsq_bounds(bits, unsigned):
 # ----------------------------------------------------------------------------------------------
 
 
-def statsq(W, bits):
-    """Returns (W_hat with STE gradient, integer levels L, scale s[rows,1]).  statsq.py:138-148."""
+def statsq(W, bits, s=None):
+    """Returns (W_hat with STE gradient, integer levels L, scale s[rows,1]).  statsq.py:138-148.
+    s: test hook, see cga_freeze_idx."""
     assert W.dim() == 2
-    s = (2 * torch.mean(W.abs(), dim=1, keepdim=True)).detach()          # :138, :142
+    if s is None:
+        s = (2 * torch.mean(W.abs(), dim=1, keepdim=True)).detach()      # :138, :142
+    else:
+        s = s.detach().reshape(-1, 1).to(W.dtype)
     v = W / s                                                            # :144
     c = torch.clamp(v, min=-(2.0 / 2), max=(2.0 / 2) - 1e-6)             # :145  clip_val = 2.0 (:126-128)
     n = float(2 ** (bits - 1))                                           # :146
@@ -502,10 +506,15 @@ def kd_loss_soft_and_hard(cls_out, dist_out, hard_target, soft_target):
 # ----------------------------------------------------------------------------------------------
 
 
-def cga_freeze_idx(W, bits, boundary_range=0.005):
-    """freeze_outside_boundary_weight_idx (cga.py:450-469): 1.0 where the weight is frozen."""
+def cga_freeze_idx(W, bits, boundary_range=0.005, s=None):
+    """freeze_outside_boundary_weight_idx (cga.py:450-469): 1.0 where the weight is frozen.
+    s: test hook -- the per-row scale to use instead of 2 * mean|W| (tests inject the device's scale, which is the correctly
+    rounded row mean where torch-CPU's cascade sum may be one ulp off, to state the mask's bit-exactness GIVEN the scale)."""
     W = W.detach()
-    s = 2 * torch.mean(W.abs(), dim=1, keepdim=True)                     # :462
+    if s is None:
+        s = 2 * torch.mean(W.abs(), dim=1, keepdim=True)                 # :462
+    else:
+        s = s.detach().reshape(-1, 1).to(W.dtype)
     c = torch.clamp(W / s, min=-1.0, max=1.0 - 1e-6)                     # :456
     n = float(2 ** (bits - 1))
     b4 = c * n - 0.5                                                     # :458
