@@ -16,6 +16,16 @@
  *    no device memory owned by the library (workspaces, flags and tables are the caller's)
  *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative OFQ_E* code
  *  - workspaces are caller-provided; the *_ws_bytes() functions are pure host arithmetic
+ *
+ * Entries that are NOT on the default training step (parity-tested, kept for the configurations / comparisons named):
+ *    ofq_qattn_dqkx_lsq_bwd     the fused qkx backward: bit-identical to the pair the step runs, 278 vs 257 us (round 5)
+ *    ofq_qgemm_bf16s_nt_lsq     dX GEMM + LSQ backward in one kernel: slower than the pair (OFQ_LSQ_BWD_FUSE=1, three-plane mode)
+ *    ofq_qattn_scores_i8, ofq_qattn_dp_bf16s, ofq_softmax_lsq_fwd / _bwd
+ *                               the unfused forms of the two fused attention kernels: what those are tested against, and the path
+ *                               of token counts the fused kernels do not take (N > 256)
+ *    ofq_gemm_bf16x3x3_nt       the KD teacher's nine- / six-product GEMM (teacher gemm="bf16x9" / "bf16x6"; the default is f16x4)
+ *    ofq_cga_mask_grad_save, ofq_cga_restore
+ *                               the reference's three-kernel CGA sequence for optimisers other than ofq_amd.optim.FusedAdamW
  */
 #ifndef OFQ_HIP_H
 #define OFQ_HIP_H

@@ -49,6 +49,10 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
            v[w].z * (float)(signed char)((word >> 16) & 0xff) + v[w].w * (float)(word >> 24);
     }
   };
+#ifndef RD16_VARIANT
+#define RD16_VARIANT 0      // experiments (tools/gpu/r06_variants.sh): 1 = without the keep-alive, 2 = round 5's form + a keep-alive, 3 = round 5's form
+#endif
+#if RD16_VARIANT <= 1
   if (K <= 512) {
     // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
     // for the four rows of the group.  Row offsets are 32-bit (rows x K < 2^31, host check) on the uniform base pointer, the
@@ -85,9 +89,70 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
       const float a = in0 ? t : 0.f;
       t = a;
       fma16(t, k0 + 256, c1[j], v1);
+#if RD16_VARIANT != 1
       asm volatile("" :: "v"(off0[j]), "v"(off1[j]));       // (the offsets outlive the loads' results: no destination may alias them)
+#endif
       acc[j] = in1 ? t : a;
     }
+#elif RD16_VARIANT == 2
+  if (K <= 512) {
+    // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
+    // for the four rows of the group
+    const bool in0 = k0 < K, in1 = k0 + 256 < K;
+    i32x4 c0[RD16_RPG], c1[RD16_RPG];
+    const int8_t* rowp[RD16_RPG];
+#pragma unroll
+    for (int j = 0; j < RD16_RPG; ++j) {
+      const int n = min(nb + 16 * j, N - 1);
+      const int8_t* row = codes + (int64_t)n * K;
+      rowp[j] = row;
+      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
+      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
+    }
+    if (in0) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
+    }
+    if (in1) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
+    }
+#pragma unroll
+    for (int j = 0; j < RD16_RPG; ++j) asm volatile("" :: "v"(rowp[j]));
+#else
+  if (K <= 512) {
+    // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
+    // for the four rows of the group
+    const bool in0 = k0 < K, in1 = k0 + 256 < K;
+    i32x4 c0[RD16_RPG], c1[RD16_RPG];
+#pragma unroll
+    for (int j = 0; j < RD16_RPG; ++j) {
+      const int n = min(nb + 16 * j, N - 1);
+      const int8_t* row = codes + (int64_t)n * K;
+      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
+      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
+    }
+    if (in0) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
+    }
+    if (in1) {
+      float4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
+#pragma unroll
+      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
+    }
+#endif
   } else {
 #pragma unroll
     for (int j = 0; j < RD16_RPG; ++j) {
@@ -145,17 +210,6 @@ extern "C" int ofq_rowdot_i8(const int8_t* codes, const float* vec, float* out, 
   return 0;
 }
 
-// Rows of the workgroup tile of the linear layers' int8 kernels (forward and recompute backward): 64 (four 32 x 64 waves, more
-// and smaller workgroups in flight) or 128 (four 64 x 64 waves).  Test hook: OFQ_I8_TILE_ROWS=64|128 forces one (read at every
-// launch, so that a test can compare the two forms bit for bit at one shape).
-static int i8_lin_tile_rows(int64_t M, int64_t N, int64_t K) {
-  const char* e = getenv("OFQ_I8_TILE_ROWS");
-  const int forced = e ? atoi(e) : 0;
-  if (forced == 64 || forced == 128) return forced;
-  (void)M; (void)N; (void)K;
-  return 128;
-}
-
 static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const float* bias, const float* col_scale,
                            float col_mult, const float* r, const float* lsq_s, int64_t S, float gscale, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int8_t* qout, int64_t ldq, const float* q_s,
@@ -169,14 +223,11 @@ static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const flo
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
-  const int rows = i8_lin_tile_rows(M, N, K);
-  a.tiles_m = (int)ceil_div(M, rows); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
   a.qout = qout; a.ldq = ldq; a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4;
   a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu; a.qrowmul = q_rowmul;
   a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
-  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-  if (rows == 64) hipLaunchKernelGGL((qgemm_i8_lin_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((qgemm_i8_lin_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }

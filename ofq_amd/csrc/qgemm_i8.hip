@@ -16,22 +16,20 @@ __device__ __forceinline__ void lds_barrier() {
 // offset), LDS addresses as immediates, the level through ofq_lsq_level_rcp.  This epilogue is VALU-bound, so
 // instructions per element are what counts.  row_a: [3][128] floats in LDS (effective input step, the by-product's
 // per-row step and its reciprocal), ctile: [128][128] bytes in LDS.
-// MI = 32-row blocks per wave: 2 = 128 x 128 workgroup tile, 1 = 64 x 128 (qgemm_i8_lin_kernel).
-template <int MI>
-__device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const i32x16 (&acc)[MI][2], float* Cb, const float* row_a,
+__device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const i32x16 (&acc)[2][2], float* Cb, const float* row_a,
                                                       signed char* ctile, const float (&csn)[2], const float (&rn)[2],
                                                       const float (&bz)[2], const float (&qb)[2], const float (&qsc)[2], int m0,
                                                       int n0, int wm, int wn, int l31, int lh) {
-  constexpr int BM = 64 * MI, BN = 128, WROWS = 32 * MI;
+  constexpr int BM = 128, BN = 128;
     const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
     const float* row_c = row_a + 2 * BM;
     float qrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) qrc[j] = (p.qout && p.qcolmode) ? __fdiv_rn(1.f, qsc[j]) : 1.f;
     const unsigned lane_off4 = 4u * ((unsigned)(4 * lh) * (unsigned)p.ldc + (unsigned)(n0 + wn_s * 64 + l31));
-    float* Cb_t = Cb + (int64_t)(m0 + wm_s * WROWS) * p.ldc;
-    signed char* ct = ctile + (wm_s * WROWS + 4 * lh) * BN + wn_s * 64 + l31;
-    const float* ra_t = row_a + wm_s * WROWS + 4 * lh;
+    float* Cb_t = Cb + (int64_t)(m0 + wm_s * 64) * p.ldc;
+    signed char* ct = ctile + (wm_s * 64 + 4 * lh) * BN + wn_s * 64 + l31;
+    const float* ra_t = row_a + wm_s * 64 + 4 * lh;
     const float qlo = p.qlo, qhi = p.qhi;
     const float half_m_tol = 0.5f - ofq_lsq_level_tol(qlo, qhi);
     auto tile = [&](auto QMODE_, auto QGELU_, auto STORE_) {
@@ -39,7 +37,7 @@ __device__ __forceinline__ void i8_epi0_interior_tile(const QGemmArgs& p, const 
       constexpr bool QGELU = decltype(QGELU_)::value;
       constexpr bool STORE_Y = decltype(STORE_)::value;       // false: only the by-product codes leave the kernel
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int eg = 0; eg < 4; ++eg) {                      // 4 rows x 2 columns per lane share one exactness check
           // QGELU: the level is decided on ofq_gelu_fast (common.h); its error bound, in level units, widens the
@@ -256,133 +254,10 @@ __device__ __forceinline__ void i8_mainloop(const QGemmArgs& p, const unsigned c
   i8_mainloop_g<T, T, 2, T, T>(p, A, B, m0, n0, smem, acc);
 }
 
-// ---- the linear layers' forward: y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n] (+ the consumer quantiser's codes)
-// MI = 2: 128 x 128 workgroup tile (2 x 2 waves of 64 x 64), three waves per SIMD.
-// MI = 1 (round 6): 64 x 128 tile, the four waves own 32 x 64 each -- half the accumulators and epilogue registers per wave, so
-// four (five) workgroups per CU instead of three, and twice as many, finer tiles.  Why it pays (profiles/r06_pmc_i8_*.txt,
-// tools/probe/pk_rate_probe.hip): ONE wave issues a VALU instruction every ~2.3 ns whatever its ILP, two or more waves of a
-// SIMD together one per ~1.15 ns -- and these launches spend their time in 1000-instruction quantiser epilogues while the
-// co-resident waves sit in their k-loops' barriers and load round trips (SQ_ACTIVE_INST_ANY ~60 % of the SIMD's time at 1.9
-// resident waves): what the kernel lacks is waves in flight, not issue slots.  The N = 384 launches (594 tiles of 128 rows on
-// 768 slots: every CU waits for its third tile while 40 % of them hold two) become 1188 tiles.
-template <int MI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? I8_WPE : 4, MI == 2 ? I8_WPE : 4)))
-void qgemm_i8_lin_kernel(QGemmArgs p) {
-  constexpr int BM = 64 * MI, BN = 128, WROWS = 32 * MI;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
-  static_assert(2 * (BM + BN) * QI8_LD >= 2048 + BM * BN, "row terms + code tile overlay the staging buffers");
-  I8_T(0);
-  int tm, tn, gby;
-  qgemm_tile_id(p, tm, tn, gby);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const unsigned char* A = (const unsigned char*)p.A;
-  const unsigned char* B = (const unsigned char*)p.B;
-  // Epilogue parameters (per-row steps / offsets, per-column scales) are requested before the k-loop: a workgroup lives
-  // for one tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
-  // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
-  // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
-  float pre_ra, pre_rb = 0.f, pre_c[2][5];
-  {
-    const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
-    pre_ra = p.s[m % p.S];
-    const float* qsp = (p.qout && !p.qcolmode) ? p.qs + ((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS : p.s;
-    pre_rb = *qsp;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nc = min(n0 + wn * 64 + j * 32 + l31, p.N - 1);
-      pre_c[j][0] = p.cs[nc];
-      pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
-      pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
-      pre_c[j][3] = ((p.qout && p.qb4) ? p.qb4 : p.cs)[nc];
-      pre_c[j][4] = ((p.qout && p.qcolmode) ? p.qs : p.cs)[nc];
-    }
-  }
-
-  i32x16 acc[MI][2];
-  i8_mainloop_g<MI, 2, 2, MI, 2>(p, A, B, m0, n0, smem, acc);
-  I8_T(2);
-  float* Cb = p.C;
-  int ncol[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) ncol[j] = n0 + wn * 64 + j * 32 + l31;
-  // per-row epilogue terms of the tile rows go through LDS once (the k-loop's last barrier has released smem):
-  // row_a = effective LSQ step of the row, row_b / row_c = the consumer's per-row step and its reciprocal; every lane then
-  // reads them as broadcasts instead of issuing dependent global loads + integer modulos
-  float* row_a = reinterpret_cast<float*>(&smem[0][0]);
-  float* row_b = row_a + BM;
-  if (tid < BM) {
-    row_a[tid] = ofq_lsq_eff_scale(pre_ra, p.gscale);
-    if (p.qout && !p.qcolmode) {
-      const float rbv = ofq_lsq_eff_scale(pre_rb, p.qgscale);
-      row_b[tid] = rbv;
-      row_a[2 * BM + tid] = __fdiv_rn(1.f, rbv);                 // row_c: reciprocal steps for the fast level path
-    }
-  }
-  __syncthreads();
-  I8_T(3);
-  float csn[2], rn[2], bz[2], qb[2], qsc[2];
-  signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [BM][128] codes, behind row_a / row_b / row_c
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    csn[j] = pre_c[j][0] * p.alpha;
-    rn[j] = p.r ? pre_c[j][1] : 0.f;
-    bz[j] = p.bias ? pre_c[j][2] : 0.f;
-    qb[j] = (p.qout && p.qb4) ? pre_c[j][3] : 0.f;
-    qsc[j] = (p.qout && p.qcolmode) ? ofq_lsq_eff_scale(pre_c[j][4], p.qgscale) : 1.f;
-  }
-  // Interior tiles (every tile of the DeiT-S shapes at MI = 2; all but the last row tile at MI = 1) take a straight-line
-  // epilogue specialised on the by-product mode: no per-element bounds / mode branches, row pointers from scalar
-  // arithmetic (the lane adds one 32-bit offset), LDS addresses as immediates, the level through ofq_lsq_level_rcp.
-  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && 4 * (4 * p.ldc + p.N) < (int64_t)0x7fffffff;
-  if (interior) {
-    i8_epi0_interior_tile<MI>(p, acc, Cb, row_a, ctile, csn, rn, bz, qb, qsc, m0, n0, wm, wn, l31, lh);
-  } else {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m >= p.M) continue;
-        const float ae = row_a[m - m0];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (ncol[j] < p.N) {
-            const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
-            if (p.C) Cb[(int64_t)m * p.ldc + ncol[j]] = yv;
-            if (p.qout) {
-              const float xe = p.qgelu ? ofq_gelu(yv) : yv;
-              float q, v;
-              ofq_lsq_quant(__fadd_rn(xe, qb[j]), p.qcolmode ? qsc[j] : row_b[m - m0], p.qlo, p.qhi, q, v);
-              ctile[(m - m0) * BN + (ncol[j] - n0)] = (signed char)(int)q;
-            }
-          }
-      }
-  }
-  I8_T(4);
-  if (p.qout) {       // the code tile goes out in 16-byte pieces of a row (256 / BM threads per row) instead of single bytes
-    __syncthreads();
-    constexpr int TPR = 256 / BM, BYTES = BN / TPR;
-    const int row = tid / TPR, c0 = (tid % TPR) * BYTES;
-    if (m0 + row < p.M) {
-#pragma unroll
-      for (int q4 = 0; q4 < BYTES / 16; ++q4) {
-        const int n = n0 + c0 + 16 * q4;
-        if (n < p.N)       // N % 16 == 0 (host check)
-          *reinterpret_cast<i32x4*>(p.qout + (int64_t)(m0 + row) * p.ldq + n) =
-              *reinterpret_cast<const i32x4*>(ctile + row * BN + c0 + 16 * q4);
-      }
-    }
-  }
-  I8_T(5);
-}
-
-// EPI 1: QKR attention scores   2: P*V      (the linear layers: qgemm_i8_lin_kernel above)
+// EPI 0: linear layer   1: QKR attention scores   2: P*V
 template <int EPI, int T = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_WPE))) void qgemm_i8_nt_kernel(QGemmArgs p) {
-  static_assert(EPI == 1 || EPI == 2, "the linear layers run qgemm_i8_lin_kernel");
+  static_assert(T == 2 || EPI != 0, "the linear-layer epilogue is written for 128 x 128 tiles");
   // T = 3 ("tall"): 256 x 64 tile, the four waves stacked (each 64 x 64) -- P.V, whose output has one head's 64 channels:
   // a 128 x 128 tile there leaves two of the four waves without columns and takes two workgroups per (batch, head)
   constexpr bool TALL = T == 3;
@@ -404,12 +279,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
   // for one 128x128 tile only, and every dependent round trip to memory after the loop (row terms -> barrier -> column
   // terms) is paid in full ~14 times per CU.  All loads are unconditional on clamped indices (a load under a condition
   // ends in a register copy that waits for it); optional vectors fall back to a valid address and are ignored later.
-  float pre_ra, pre_rb = 0.f;
+  float pre_ra, pre_rb = 0.f, pre_c[TT][5];
   {
     const int m = min(m0 + (tid & (BM - 1)), p.M - 1);
     pre_ra = p.s[m % p.S];
+    if (EPI == 0) {
+      const float* qsp = (p.qout && !p.qcolmode) ? p.qs + ((int64_t)m * p.qrowmul + n0 / p.qcoldiv) % p.qS : p.s;
+      pre_rb = *qsp;
+    }
     if (EPI == 1) pre_rb = p.u[((int64_t)b0 * p.M + m) * p.nb1 + b1];
     if (EPI == 2) pre_rb = p.rp[((int64_t)b0 * p.nb1 + b1) * p.M + m];
+    if (EPI == 0) {
+#pragma unroll
+      for (int j = 0; j < TT; ++j) {
+        const int nc = min(n0 + wn * 32 * TT + j * 32 + l31, p.N - 1);
+        pre_c[j][0] = p.cs[nc];
+        pre_c[j][1] = (p.r ? p.r : p.cs)[nc];
+        pre_c[j][2] = (p.bias ? p.bias : p.cs)[nc];
+        pre_c[j][3] = ((p.qout && p.qb4) ? p.qb4 : p.cs)[nc];
+        pre_c[j][4] = ((p.qout && p.qcolmode) ? p.qs : p.cs)[nc];
+      }
+    }
   }
 
   i32x16 acc[TT][TT];
@@ -427,11 +317,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I8_WPE, I8_
   float* row_b = row_a + BM;
   if (tid < BM) {
     row_a[tid] = ofq_lsq_eff_scale(pre_ra, p.gscale);
-    row_b[tid] = pre_rb;
+    if (EPI == 0 && p.qout && !p.qcolmode) {
+      const float rbv = ofq_lsq_eff_scale(pre_rb, p.qgscale);
+      row_b[tid] = rbv;
+      row_a[2 * BM + tid] = __fdiv_rn(1.f, rbv);                 // row_c: reciprocal steps for the fast level path
+    }
+    if (EPI == 1 || EPI == 2) row_b[tid] = pre_rb;
   }
   __syncthreads();
   I8_T(3);
-  if constexpr (EPI == 1) {
+  if constexpr (EPI == 0) {
+    // y = cs[n] * (a_eff[m % S] * I + r[n]) + bias[n]
+    float csn[2], rn[2], bz[2], qb[2], qsc[2];
+    signed char* ctile = reinterpret_cast<signed char*>(&smem[0][0]) + 2048;      // [128][128] codes, behind row_a / row_b
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      csn[j] = pre_c[j][0] * p.alpha;
+      rn[j] = p.r ? pre_c[j][1] : 0.f;
+      bz[j] = p.bias ? pre_c[j][2] : 0.f;
+      qb[j] = (p.qout && p.qb4) ? pre_c[j][3] : 0.f;
+      qsc[j] = (p.qout && p.qcolmode) ? ofq_lsq_eff_scale(pre_c[j][4], p.qgscale) : 1.f;
+    }
+    // Interior tiles (every tile of the DeiT-S shapes) take a straight-line epilogue specialised on the by-product mode:
+    // no per-element bounds / mode branches, row pointers from scalar arithmetic (the lane adds one 32-bit offset),
+    // LDS addresses as immediates, and the level through ofq_lsq_level_rcp.  This epilogue is VALU-bound (the qkx
+    // GEMM spent ~70 of its 119 us in it), so instructions per element are what counts.
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && 4 * (4 * p.ldc + p.N) < (int64_t)0x7fffffff;
+    if (interior) {
+      i8_epi0_interior_tile(p, acc, Cb, row_a, ctile, csn, rn, bz, qb, qsc, m0, n0, wm, wn, l31, lh);
+    } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const float ae = row_a[m - m0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (ncol[j] < p.N) {
+            const float yv = __fadd_rn(__fmul_rn(csn[j], __fadd_rn(__fmul_rn(ae, (float)acc[i][j][e]), rn[j])), bz[j]);
+            if (p.C) Cb[(int64_t)m * p.ldc + ncol[j]] = yv;
+            if (p.qout) {
+              const float xe = p.qgelu ? ofq_gelu(yv) : yv;
+              float q, v;
+              ofq_lsq_quant(__fadd_rn(xe, qb[j]), p.qcolmode ? qsc[j] : row_b[m - m0], p.qlo, p.qhi, q, v);
+              ctile[(m - m0) * BN + (ncol[j] - n0)] = (signed char)(int)q;
+            }
+          }
+      }
+    }
+    I8_T(4);
+    if (p.qout) {       // the code tile goes out in 64-byte row pieces (two threads per row) instead of single bytes
+      __syncthreads();
+      const int row = tid >> 1, c0 = (tid & 1) * 64;
+      if (m0 + row < p.M) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int n = n0 + c0 + 16 * q4;
+          if (n < p.N)       // N % 16 == 0 (host check)
+            *reinterpret_cast<i32x4*>(p.qout + (int64_t)(m0 + row) * p.ldq + n) =
+                *reinterpret_cast<const i32x4*>(ctile + row * BN + c0 + 16 * q4);
+        }
+      }
+    }
+    I8_T(5);
+  } else if constexpr (EPI == 1) {
     // S[n,m] = ax[n] * (aq[m,h] * I + u[b,n,h]) + aq[m,h] * tq[b,m,h] + z[h]      (x_hat . qkx_hat^T, attention.py:210)
     float aq[TT], tqa[TT];
     const float zz = p.z[b1];

@@ -23,16 +23,10 @@
 // the recompute (the x codes) is the B operand of that product.  A 128-row tile of the flat (image, token) rows holds rows
 // of at most two images (N >= 128): every row reads its own image's dS panel, the code operand is staged once per image and
 // a 32-row block that straddles the boundary multiplies twice with the other image's rows zeroed.
-// MI (round 6) = 32-row blocks per wave: 2 = 128 x 128 workgroup tile, two waves per SIMD (256 registers: 64 accumulators, two
-// halves of 32 incoming gradients, 32 row partials); 1 = 64 x 128 tile, the four waves own 32 x 64 each -- 32 accumulators, ONE
-// set of 32 gradients, 16 row partials: three waves per SIMD and twice as many workgroups.  The launch is neither VALU- nor
-// HBM-bound at two waves (profiles/r06_pmc_i8_*.txt: 48 M VALU per launch = 57 us of issue at the two-wave rate, 580 MB = 3.6 TB/s,
-// 160 us): a lone wave issues at half the rate of two (tools/probe/pk_rate_probe.hip) and the partner is in its k-loop or waiting
-// for its gradient loads most of the time.
-template <int QMODE, bool GELU, bool DQKX = false, int MI = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2 : 3, MI == 2 ? 2 : 3))) void qgemm_i8_lsqbwd_kernel(QGemmArgs p) {
-  constexpr int BM = 64 * MI, BN = 128, WROWS = 32 * MI;
-  static_assert(!DQKX || (QMODE == 1 && !GELU && MI == 2), "the fused attention form is the per-row quantiser without a GELU, on 128-row tiles");
+template <int QMODE, bool GELU, bool DQKX = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qgemm_i8_lsqbwd_kernel(QGemmArgs p) {
+  constexpr int BM = 128, BN = 128;
+  static_assert(!DQKX || (QMODE == 1 && !GELU), "the fused attention form is the per-row quantiser without a GELU");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * QI8_LD];
   int tm, tn, gby;
   qgemm_tile_id(p, tm, tn, gby);
@@ -65,11 +59,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
   const float* G = p.lx;
   const int ncl[2] = {min(ncol[0], p.N - 1), min(ncol[1], p.N - 1)};
   const bool cok[2] = {ncol[0] < p.N, ncol[1] < p.N};
-  float g0[16][2], g1[MI == 2 ? 16 : 1][2];
+  float g0[16][2], g1[16][2];
   auto gload = [&](float (&g)[16][2], int i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int m = min(m0 + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, p.M - 1);
+      const int m = min(m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, p.M - 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) g[e][j] = G[(int64_t)m * p.ldlx + ncl[j]];
     }
@@ -272,9 +266,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
   } else {
     gload(g0, 0);
   }
-  i32x16 acc[MI][2];
-  i8_mainloop_g<MI, 2, 2, MI, 2>(p, A, B, m0, n0, smem, acc);
-  if constexpr (!DQKX && MI == 2) gload(g1, 1);
+  i32x16 acc[2][2];
+  i8_mainloop<2>(p, A, B, m0, n0, smem, acc);
+  if constexpr (!DQKX) gload(g1, 1);
 
   float* row_a = reinterpret_cast<float*>(&smem[0][0]);       // [128] effective input step of the row
   float* row_b = row_a + BM;                                  // [128] effective step of the consumer quantiser (row mode)
@@ -301,9 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
   const float tol = ofq_lsq_level_tol(lo, hi);
   const float half_m_tol = 0.5f - tol;
   float cb4[2] = {0.f, 0.f}, cba[2] = {0.f, 0.f}, cds[2] = {0.f, 0.f};
-  float rds[16 * MI];
+  float rds[32];
 #pragma unroll
-  for (int k = 0; k < 16 * MI; ++k) rds[k] = 0.f;
+  for (int k = 0; k < 32; ++k) rds[k] = 0.f;
   auto half = [&](const float (&g)[16][2], auto I_) {
     constexpr int i = decltype(I_)::value;
 #pragma unroll
@@ -315,7 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
 #pragma unroll
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
-        const int mr = wm * WROWS + i * 32 + ee + 8 * eg + 4 * lh;
+        const int mr = wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
         const bool mok = (m0 + mr) < p.M;
         const float ae = row_a[mr];
         const float alr = row_b[mr], rar = row_c[mr];
@@ -337,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
 #pragma unroll
       for (int ee = 0; ee < 4; ++ee) {
         const int e = eg * 4 + ee;
-        const int m = m0 + wm * WROWS + i * 32 + ee + 8 * eg + 4 * lh;
+        const int m = m0 + wm * 64 + i * 32 + ee + 8 * eg + 4 * lh;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           cb4[j] += dq[ee][j];
@@ -350,18 +344,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
     }
   };
   half(g0, std::integral_constant<int, 0>());
-  if constexpr (MI == 2) half(g1, std::integral_constant<int, 1>());
+  half(g1, std::integral_constant<int, 1>());
   if (p.amax_out) ofq_amax_publish(p.amax_out, dymax);       // max |dy| of the written elements (two-plane GEMMs downstream)
   // ---- row partials (row mode): sum over the 32 lanes that hold the columns of one row; transpose-reduce, 31 exchanges:
   // after the step with mask w a lane keeps the half of its slots selected by its bit w, so lane l31 ends with slot l31
-  // (MI = 1: 16 slots on 32 lanes -- a plain butterfly over lane bit 4 first, lanes l and l ^ 16 then hold the same sums)
   if (QMODE == 1) {
-    if constexpr (MI == 1) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) rds[k] += __shfl_xor(rds[k], 16, 64);
-    }
-#pragma unroll
-    for (int w = 8 * MI; w >= 1; w >>= 1) {
+    for (int w = 16; w >= 1; w >>= 1) {
       const bool up = (l31 & w) != 0;
 #pragma unroll
       for (int k = 0; k < w; ++k) {
@@ -370,9 +359,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
         rds[k] = keep + __shfl_xor(send, w, 64);
       }
     }
-    const int e = l31 & 15, i = MI == 2 ? (l31 >> 4) : 0;
-    const int m = m0 + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    if (m < p.M && (MI == 2 || l31 < 16)) p.lrow[(int64_t)m * (2 * p.tiles_n) + 2 * tn + wn] = rds[0];
+    const int e = l31 & 15, i = l31 >> 4;
+    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    if (m < p.M) p.lrow[(int64_t)m * (2 * p.tiles_n) + 2 * tn + wn] = rds[0];
   }
   // ---- column partials: lane pair (lh) -> wave pair (wm) through LDS -> lcol[tm][acc][n]
   constexpr int NACC = QMODE == 2 ? 3 : 2;
@@ -396,8 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 2 ? 2
   }
 }
 
-static void i8_lsqbwd_ws(int64_t M, int64_t N, int colmode, size_t* rowf, size_t* colf, int tile_rows = 64) {
-  const int64_t tiles_m = ceil_div(M, tile_rows), tiles_n = ceil_div(N, 128);
+static void i8_lsqbwd_ws(int64_t M, int64_t N, int colmode, size_t* rowf, size_t* colf) {
+  const int64_t tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
   *rowf = colmode ? 0 : (size_t)M * 2 * tiles_n;
   *colf = (size_t)tiles_m * (colmode ? 3 : 2) * N;
 }
@@ -424,14 +413,13 @@ static int i8_lsq_bwd_launch(const int8_t* A, const int8_t* B, const float* bias
     return OFQ_EINVAL;
   const int64_t T = q_colmode ? 1 : q_S / q_rowmul;          // quantiser rows per batch element (tokens)
   if (!q_colmode && (T * q_rowmul != q_S || M % T)) return OFQ_EINVAL;
-  const int rows = dS ? 128 : i8_lin_tile_rows(M, N, K);
   size_t rf, cf;
-  i8_lsqbwd_ws(M, N, q_colmode, &rf, &cf, rows);
+  i8_lsqbwd_ws(M, N, q_colmode, &rf, &cf);
   if (ws_bytes < (rf + cf) * sizeof(float)) return OFQ_ENOWS;
   QGemmArgs a = {};
   a.A = A; a.B = B; a.C = dy; a.bias = bias; a.cs = col_scale; a.r = r; a.s = lsq_s;
   a.lda = lda; a.ldb = ldb; a.ldc = ldd; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.S = (int)S;
-  a.tiles_m = (int)ceil_div(M, rows); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
+  a.tiles_m = (int)ceil_div(M, 128); a.tiles_n = (int)ceil_div(N, 128); a.gscale = gscale; a.alpha = col_mult; a.nb1 = 1;
   a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4; a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu;
   a.qrowmul = q_rowmul; a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
   a.lx = gy; a.ldlx = ldg; a.lrow = (float*)ws; a.lcol = (float*)ws + rf; a.amax_out = (unsigned*)amax_out;
@@ -440,8 +428,7 @@ static int i8_lsq_bwd_launch(const int8_t* A, const int8_t* B, const float* bias
   auto launch = [&](auto QM, auto GE) {
     constexpr int qm = decltype(QM)::value;
     constexpr bool ge = decltype(GE)::value;
-    if (rows == 64) hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, false, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge, false, 2>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((qgemm_i8_lsqbwd_kernel<qm, ge>), grid, block, 0, st, a);
   };
   if (dS) {
     // x codes [B Ntok][K] (lda == row stride), steps per token (S == Ntok), qkx columns (head, channel): N == H K, the quantiser's

@@ -711,12 +711,11 @@ def _two_rank_worker(rank, world, port, errq):
 
         # (2) five steps: eager DataParallel against captured compute + eager collectives, and rank against rank
         res = {}
-        for mode in ("eager", "eager", "split", "segmented"):
-            # ("eager" twice: two processes time-sharing one GPU over gloo are not perfectly reproducible -- about one
-            # five-step run in twenty ends with parameters that differ in the last bits, with every kernel switch of this round
-            # off as well (tools/two_rank_determinism.py) -- so the graph modes are held to EITHER eager run)
-            if mode == "eager" and "eager" in res:
-                res["eager2"] = res["eager"]
+        for mode in ("eager", "split", "segmented"):
+            # (round 5 held the graph modes to EITHER of two eager runs and retried once: about one five-step run in twenty
+            # ended with other last bits.  Round 6 traced that to ONE routine -- the row-dot of the attention prep launch returned
+            # a wrong tq for 1-4 of 2376 rows about once in 400 calls whenever another process shared the GPU, two ranks or two
+            # unrelated processes alike (tools/two_rank_trace.py) -- and fixed it: strict equality, one eager run.)
             model = copy.deepcopy(base).train()
             dp = parallel.DataParallel(model, bucket_mb=1.0)
             opt = engine.make_optimizer(model, lr=_lr_at(0), weight_decay=0.05)
@@ -741,32 +740,31 @@ def _two_rank_worker(rank, world, port, errq):
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             assert torch.equal(lo, hi), "replicas diverged in mode " + mode
             dp.release()
-        def same(x, y):
-            return x[0] == y[0] and all(torch.equal(a, b_) for a, b_ in zip(x[1], y[1]))
-        ok = torch.tensor([float(all(same(res["eager"], res[m]) or same(res["eager2"], res[m]) for m in ("split", "segmented")))])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok) == 0.0:
-            # one more attempt at the graph modes before calling it a failure (see above); both ranks decide together
-            for mode in ("split", "segmented"):
-                model = copy.deepcopy(base).train()
-                dp = parallel.DataParallel(model, bucket_mb=1.0)
-                opt = engine.make_optimizer(model, lr=_lr_at(0), weight_decay=0.05)
-                gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, warmup=2, mode=mode)
-                losses = []
-                for i in range(5):
-                    for g in opt.param_groups:
-                        g["lr"] = _lr_at(i)
-                    losses.append(float(gs(*batches[i % 2]).detach()))
-                torch.cuda.synchronize()
-                res[mode] = (losses, [p.detach().clone() for p in model.parameters()])
-                dp.release()
         for mode in ("split", "segmented"):
-            assert same(res["eager"], res[mode]) or same(res["eager2"], res[mode]), (mode, res["eager"][0], res["eager2"][0], res[mode][0])
+            assert res["eager"][0] == res[mode][0], (mode, res["eager"][0], res[mode][0])
+            assert all(torch.equal(a, b_) for a, b_ in zip(res["eager"][1], res[mode][1])), mode
         dist.barrier()
         dist.destroy_process_group()
     except BaseException:  # noqa: BLE001
         errq.put("rank %d:\n%s" % (rank, traceback.format_exc()))
         raise
+
+
+def test_two_processes_sharing_the_gpu_repeat_their_steps_bit_for_bit():
+    """Two INDEPENDENT processes on one GPU, each repeating the same five eager training steps 150 times from the same state
+    (tools/two_rank_trace.py, MODE=solo): every repetition must leave the trace of the first -- losses, every gradient, every
+    parameter after every step.  Round 5's form of the attention prep's row-dot failed this in 2-5 % of the repetitions (about
+    one wrong launch in 400), which is what made the two-rank test below irreproducible; 150 repetitions of each process are
+    ~1500 launches of that routine per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MODE="solo", REPS="150", CFGS="nodp", PROCS="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_rank_trace.py")], cwd=root, env=env, capture_output=True, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in out.splitlines() if " cfg " in l]
+    assert len(lines) == 2 and all("REPRODUCIBLE" in l for l in lines), out[-3000:]
 
 
 def test_two_ranks_on_one_gpu_over_gloo_run_the_data_parallel_step():

@@ -178,7 +178,7 @@ def test_cga_masks_and_frozen_weights_at_full_size(model_type):
         s_dev = ops.statsq_fwd(before[k], bits)[1].cpu()
         assert torch.equal(frz, O.cga_freeze_idx(before[k].cpu(), bits, br, s=s_dev)), k
         # (2) against the oracle's OWN scale (torch-CPU's cascade-summed mean, which may be one ulp away from the correctly
-        # rounded one): a disagreement is allowed only where that ulp decides -- the two scales of the row differ, by one ulp,
+        # rounded one): a disagreement is allowed only where that ulp decides -- the two scales of the row differ, by an ulp or two,
         # and the element's level coordinate b4 = clamp(W / s) * n - 0.5 lies within a few ulp of an edge of a +-boundaryRange
         # band under either scale (measured: 1 element of Swin-T's 27.5 M, none of DeiT-S's 21.2 M)
         diff = frz != want[k]
@@ -187,14 +187,14 @@ def test_cga_masks_and_frozen_weights_at_full_size(model_type):
             s_cpu = 2 * W.abs().mean(dim=1)
             rows = diff.any(dim=1)
             ulp = torch.ldexp(torch.ones_like(s_cpu), torch.frexp(s_cpu)[1] - 24)
-            assert bool(((s_dev - s_cpu).abs()[rows] > 0).all()) and bool(((s_dev - s_cpu).abs()[rows] <= ulp[rows]).all()), k
+            assert bool(((s_dev - s_cpu).abs()[rows] > 0).all()) and bool(((s_dev - s_cpu).abs()[rows] <= 4 * ulp[rows]).all()), k
             n = float(2 ** (bits - 1))
             for sc in (s_cpu, s_dev):
                 b4 = torch.clamp(W / sc[:, None], -1.0, 1.0 - 1e-6) * n - 0.5
                 frac = (b4 - torch.floor(b4))[diff]                 # distance of the level coordinate from the integer below
                 edge = torch.minimum((frac - (0.5 - br)).abs(), (frac - (0.5 + br)).abs())
                 edge = torch.minimum(edge, torch.minimum((frac - (1.5 - br)).abs(), (frac + (0.5 - br)).abs()))
-                tol = 4 * 2.0 ** -23 * (b4[diff].abs() + 1.0)
+                tol = 8 * 2.0 ** -23 * (b4[diff].abs() + 1.0)
                 assert bool((edge <= tol).all()), (k, float(edge.max()))
             assert int(diff.sum()) <= 2, (k, int(diff.sum()))
         f = (frz != 0).cuda()
