@@ -10,13 +10,18 @@ batches (randn images, random labels, random teacher logits), random-init weight
 forward + KDLossSoftandHard + backward (+ bucketed RCCL all-reduce for N > 1) + AdamW step; the device side of the step
 is captured once in a hipGraph (engine.GraphedTrainStep) and replayed -- every kernel of every timed step runs.
 
+`dtype` / `config.grad_planes` say which arithmetic the backward code GEMMs ran on (default: the gradient operand as two fp16 planes of
+the power-of-two-scaled tensor; OFQ_GRAD_PLANES=3: three bf16 planes, the exact fp32 product); the default line also
+carries `exact_fp32_backward` (the same 20 steps with OFQ_GRAD_PLANES=3) and `recipe_step` (the fp32 KD teacher's forward inside the
+step), each measured by a child process after the headline's timed region.
+
 Prints ONE JSON line on rank 0, with two extra objects:
   roofline      — the dominant matrix-core kernel class by time (at 128 images: qgemm_bf16s_nt_wide_kernel, the dX GEMM of
-                  the linear layers on 3 bf16 planes): algorithmic 2*M*N*K per launch / HIP-event time per launch, both
+                  the linear layers): algorithmic 2*M*N*K per launch / HIP-event time per launch, both
                   measured live over a second pass of the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak
                   (`frac`); every algorithmic FMA of the split kernels is three bf16 MFMA FMAs, so the matrix pipe is busy
                   3x that fraction (`mfma_pipe_frac`); `mfma_util_pmc` / `traffic` come from the committed rocprofv3 PMC
-                  passes of the same kernel sources (profiles/r04_traffic.json)
+                  passes of the same kernel sources (profiles/r06_traffic.json)
   cpu_baseline  — oracle/ofq_oracle.py (eager torch-CPU restatement of the reference path) timed on this box's
                   host cores on a bounded sample (DeiT-S W2A2 QKR, batch 8, a few steps), rank 0 at N = 1 only
 """
@@ -37,7 +42,7 @@ PEAKS = {"gemm_f32": 157.3,        # Peak FP32 (matrix)
          "qgemm_i8": 5000.0,       # I8 runs at 2x the bf16 rate (2xK); measured ceiling in the guide: 3944-4404 TOPS
          "qattn_scores_softmax": 5000.0,   # (fused int8 GEMM + softmax kernels have their own timer classes: they are VALU-bound)
          "qattn_dp_softmax_bwd": 2500.0}   # (fused dP GEMM + softmax backward: VALU / HBM-bound)
-PROFILE_JSON = "r05_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
+PROFILE_JSON = "r06_traffic.json"  # profiles/: per-kernel HBM bytes and MfmaUtil of the committed PMC passes (tools/make_traffic.py)
 
 
 def parse():

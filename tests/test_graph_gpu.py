@@ -658,6 +658,8 @@ def test_bench_line_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "images/s" and d["higher_is_better"] is True and "workload" in d["config"]
+    # the precision trade of the backward GEMMs is part of the record: the mode in `config`, spelled out in `dtype`
+    assert d["config"]["grad_planes"] in (2, 3) and d["dtype"].startswith("f32 (backward GEMM gradient operands as %d " % d["config"]["grad_planes"])
     assert abs(d["value"] - 16 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
     roof = d["roofline"]
     # (which class dominates depends on the batch: at 128 images the dW GEMM, at 16 any of the GEMM classes)

@@ -41,15 +41,16 @@ for ev in prof.events():
     if any(ch.kernels for ch in ev.cpu_children if ch.name.startswith("aten::")):
         continue
     frame = ""
-    for fr in (ev.stack or []):
+    st = list(ev.stack or [])
+    for fr in st:
         if "ofq_amd" in fr or "bench.py" in fr:
             frame = fr
             break
-    if not frame and ev.stack:
-        frame = ev.stack[0]
+    if not frame:                                  # (backward ops: the autograd node's name is the best there is)
+        frame = next((fr for fr in st if "Backward" in fr or "autograd" in fr), st[0] if st else "")
     frame = frame.replace(ROOT + "/", "")
     shapes = str(ev.input_shapes)[:70]
-    key = (ev.name, shapes, frame[:90])
+    key = (ev.name, shapes, frame[-110:])
     rows[key] += 1
     dur[key] += sum(k.duration for k in ev.kernels)
 tot = 0
