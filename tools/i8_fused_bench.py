@@ -44,6 +44,9 @@ qa, qw, s, cs, bias, r = operands(C, C)
 fv = {"s": torch.rand(C, device="cuda") * 0.5 + 0.5, "S": C, "gscale": 0.01, "b4": torch.randn(C, device="cuda") * 0.1,
       "lo": -2, "hi": 1, "gelu": False, "rowmul": 1, "coldiv": C, "colmode": 1}
 bench("i8 v y+codes        N=%d K=%d" % (C, C), lambda: ops.qgemm_i8_nt(qa, qw, bias, cs, 0.25, r, s, T, 0.01, fuse=fv), 2.0 * M * C * C)
-# fc2 / proj: plain
+# proj: plain, K = C
+qa, qw, s, cs, bias, r = operands(C, C)
+bench("i8 proj y only      N=%d K=%d" % (C, C), lambda: ops.qgemm_i8_nt(qa, qw, bias, cs, 0.25, r, s, T, 0.01), 2.0 * M * C * C)
+# fc2: plain, K = 4 C
 qa, qw, s, cs, bias, r = operands(C, 4 * C)
 bench("i8 fc2 y only       N=%d K=%d" % (C, 4 * C), lambda: ops.qgemm_i8_nt(qa, qw, bias, cs, 0.25, r, s, T, 0.01), 2.0 * M * 4 * C * C)
