@@ -13,7 +13,6 @@ extern "C" const char* ofq_source_hash(void) { return "OFQ_SOURCE_HASH=" OFQ_SOU
 #include "gemm_f32.hip"
 #include "qgemm_args.h"
 #include "qgemm_i8.hip"
-#include "qgemm_i8_l384.hip"
 #include "qgemm_planes.hip"
 #include "qgemm_tn.hip"
 #include "qgemm_nn.hip"

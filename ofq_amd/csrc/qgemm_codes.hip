@@ -227,8 +227,7 @@ static int qgemm_i8_linear(const int8_t* A, const int8_t* B, float* C, const flo
   a.qout = qout; a.ldq = ldq; a.qs = q_s; a.qS = (int)q_S; a.qgscale = q_gscale; a.qb4 = q_b4;
   a.qlo = (float)q_lo; a.qhi = (float)q_hi; a.qgelu = q_gelu; a.qrowmul = q_rowmul;
   a.qcoldiv = (int)(q_coldiv > (1ll << 30) ? (1ll << 30) : q_coldiv); a.qcolmode = q_colmode;
-  if (i8_l384_ok(a)) i8_l384_launch(a, (hipStream_t)stream);      // fc2-shaped layers: one 128 x 384 tile per workgroup, LDS-DMA ring
-  else hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((qgemm_i8_nt_kernel<0>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, (hipStream_t)stream, a);
   OFQ_LAUNCH_CHECK();
   return 0;
 }
