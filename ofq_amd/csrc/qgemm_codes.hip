@@ -49,19 +49,19 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
            v[w].z * (float)(signed char)((word >> 16) & 0xff) + v[w].w * (float)(word >> 24);
     }
   };
-#ifndef RD16_VARIANT
-#define RD16_VARIANT 0      // experiments (tools/gpu/r06_variants.sh): 1 = without the keep-alive, 2 = round 5's form + a keep-alive, 3 = round 5's form
-#endif
-#if RD16_VARIANT <= 1
   if (K <= 512) {
     // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
-    // for the four rows of the group.  Row offsets are 32-bit (rows x K < 2^31, host check) on the uniform base pointer, the
-    // loads unconditional on clamped offsets, and every offset register stays LIVE until its data has been consumed (the empty
-    // asm statements below): round 6 traced the one non-reproducible result of a training step on a shared GPU to this
-    // routine -- tq of rows (row % 64) in {35, 39, 43, 47}, i.e. lanes 48..63 of the THIRD row load, the one whose destination
-    // registers the compiler had laid over the load's own 64-bit address pair (global_load_dwordx4 v[2:5], v[2:3], off) --
-    // wrong in 1-4 of 2376 rows about once in 400 calls, with the inputs in memory verified before and after the launch
-    // (tools/two_rank_trace.py DUMP_OP=qattn_prep).
+    // for the four rows of the group.  Row offsets are 32-bit (rows x K < 2^32, host check) on the uniform base pointer, the
+    // loads unconditional on clamped offsets, every offset register live until its data has been consumed (the empty asm
+    // statements below).  WHY this form: round 6 traced the one non-reproducible result of a training step on a SHARED GPU to
+    // round 5's form of this routine (loads on 64-bit row pointers under `if (k0 < K)`): tq of rows (row % 64) in {35, 39, 43, 47}
+    // -- lanes 48..63 of the THIRD row load, `global_load_dwordx4 v[2:5], v[2:3], off` in that build -- wrong in 1-4 of 2376 rows
+    // about once in 400 calls, with the inputs in memory verified before and after the launch, and only while another process
+    // had work on the GPU (tools/two_rank_trace.py DUMP_OP=qattn_prep).  Round 5's form, that form with its row
+    // pointers kept live (another register allocation of the same loads), and this form without the keep-alive were compared under
+    // -DRD16_VARIANT=3 / 2 / 1 in commit a29d053 (tools/gpu/r06_variants.sh, profiles/r06_shared_gpu_rowdot_variants.txt): 32
+    // differing repetitions of 1398 for round 5's form, 0 of 1398 for each of the others.  The mechanism inside the failing build
+    // is NOT established (its waits are the right ones; the aliased destination is still there in the passing keep-alive build).
     const bool in0 = k0 < K, in1 = k0 + 256 < K;
     i32x4 c0[RD16_RPG], c1[RD16_RPG];
     unsigned off0[RD16_RPG], off1[RD16_RPG];
@@ -89,70 +89,9 @@ __device__ __forceinline__ void rowdot_i8_v16_body(int bx, const int8_t* __restr
       const float a = in0 ? t : 0.f;
       t = a;
       fma16(t, k0 + 256, c1[j], v1);
-#if RD16_VARIANT != 1
-      asm volatile("" :: "v"(off0[j]), "v"(off1[j]));       // (the offsets outlive the loads' results: no destination may alias them)
-#endif
+      asm volatile("" :: "v"(off0[j]), "v"(off1[j]));       // (the offsets outlive the loads' results)
       acc[j] = in1 ? t : a;
     }
-#elif RD16_VARIANT == 2
-  if (K <= 512) {
-    // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
-    // for the four rows of the group
-    const bool in0 = k0 < K, in1 = k0 + 256 < K;
-    i32x4 c0[RD16_RPG], c1[RD16_RPG];
-    const int8_t* rowp[RD16_RPG];
-#pragma unroll
-    for (int j = 0; j < RD16_RPG; ++j) {
-      const int n = min(nb + 16 * j, N - 1);
-      const int8_t* row = codes + (int64_t)n * K;
-      rowp[j] = row;
-      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
-      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
-    }
-    if (in0) {
-      float4 v[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
-#pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
-    }
-    if (in1) {
-      float4 v[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
-#pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
-    }
-#pragma unroll
-    for (int j = 0; j < RD16_RPG; ++j) asm volatile("" :: "v"(rowp[j]));
-#else
-  if (K <= 512) {
-    // K = 384 (the attention prep): all rows' chunks are requested before the arithmetic, the vector chunk is read once
-    // for the four rows of the group
-    const bool in0 = k0 < K, in1 = k0 + 256 < K;
-    i32x4 c0[RD16_RPG], c1[RD16_RPG];
-#pragma unroll
-    for (int j = 0; j < RD16_RPG; ++j) {
-      const int n = min(nb + 16 * j, N - 1);
-      const int8_t* row = codes + (int64_t)n * K;
-      c0[j] = *reinterpret_cast<const i32x4*>(row + (in0 ? k0 : 0));
-      c1[j] = *reinterpret_cast<const i32x4*>(row + (in1 ? k0 + 256 : 0));
-    }
-    if (in0) {
-      float4 v[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 4 * w);
-#pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0, c0[j], v);
-    }
-    if (in1) {
-      float4 v[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) v[w] = *reinterpret_cast<const float4*>(vec + k0 + 256 + 4 * w);
-#pragma unroll
-      for (int j = 0; j < RD16_RPG; ++j) fma16(acc[j], k0 + 256, c1[j], v);
-    }
-#endif
   } else {
 #pragma unroll
     for (int j = 0; j < RD16_RPG; ++j) {
