@@ -32,7 +32,7 @@ for pat in ("*.py", "gpu/*.sh", "probe/*.hip", "probe/*.py"):
 head = """# tools/ index
 
 Micro-benchmarks, profiling helpers and hardware probes behind the numbers in `DESIGN.md`.  None of this is imported by the
-product (`ofq_amd/`) or by the tests; every script runs on the GPU box from the repository root (`gpurun -- 'python tools/x.py'`).
+product (`ofq_amd/`); one test (`tests/test_graph_gpu.py`) runs `tools/two_rank_trace.py` as a subprocess; every script runs on the GPU box from the repository root (`gpurun -- 'python tools/x.py'`).
 The `OFQ_*` environment switches some of them set select between kernels that give the same results (A/B switches, test hooks).
 (This file: `python tools/make_index.py`.)
 
