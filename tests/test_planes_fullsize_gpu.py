@@ -17,7 +17,7 @@ arithmetic.  Asserted per parameter tensor, planes 2 vs planes 3 (measured value
 
     relative l2                              <= 1e-5     (measured 3e-7 .. 1.8e-6 on DeiT-S / DeiT-T, <= 5.2e-6 on Swin-T)
     max |difference| / max |gradient|        <= 1e-5     (measured <= 2.2e-6)
-    step-size gradients d(s) of the LSQ quantisers: 3e-5 / 3e-5 (measured <= 1.4e-5): sum_i g_i (q_i - v_i) over 10^4 .. 10^6 terms
+    step-size gradients d(s) of the LSQ quantisers: 3e-5 / 3e-5 (measured <= 1.4e-5 / 1.8e-5): sum_i g_i (q_i - v_i) over 10^4 .. 10^6 terms
         of either sign, an ill-conditioned sum in ANY fp32 evaluation (the fp32 oracle is 5e-3 from its own fp64
         run on two of them)
     attn.move_qkx_aft.bias (QKR) / attn.move_k_aft.bias (plain attention): compared on the scale of the sibling move_qkx_b4.bias /
