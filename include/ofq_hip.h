@@ -276,7 +276,7 @@ int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const fl
  *            optimiser step / gradient all-reduce (train.py:927-933), so a caller may collect the ones of a whole
  *            transformer block (Block.forward deit_vision_transformer.py:154-164: v, W_qk, proj, fc1, fc2) and run them
  *            here: each workgroup then owns a long token range, and the split-K partials shrink fivefold.
- *            Every job: N >= 256, N % 16 == 0, S >= 32; all jobs of one tile class (N % 384 == 0 for all or none);
+ *            Every job: N >= 256, N % 16 == 0, any S >= 1 (round 6: step vectors shorter than a 32-token k-tile too); all jobs of one tile class (N % 384 == 0 for all or none);
  *            njobs <= 8; `split` (>= 1) is common, about 256 / (sum of ceil(M/128) * ceil(N/384) over the jobs). */
 typedef struct ofq_tn_job {
   const float* dY; const int8_t* codes; float* dW; const float* lsq_s; float* db; const float* baft;
@@ -429,6 +429,17 @@ int ofq_adamw_hyper_pack(float* host8, float lr, double beta1, double beta2, flo
                          double bias_correction1, double bias_correction2);
 int ofq_adamw_multi_dev(const void* tensors, int64_t n_tensors, const float* hyper_dev, ofq_stream_t stream);
 int ofq_store_f32(float* dst_dev, const float* host_vals, int n, ofq_stream_t stream);
+/*  Step guard (round 6).  ofq_step_guard ORs up to 32 device words -- the error words of the stream-K workspaces (byte offset
+ *  16384 of a workspace of ofq_qgemm_bf16s_nt_sk), the flag elements a data-parallel wrapper appends to its gradient buckets
+ *  (averaged over the ranks by the bucket's own all-reduce, so every rank reads the same value) -- compared as bits without a
+ *  float's sign bit; if any is set: loss[0] <- NaN, guard_u32[0] <- 1, flag_f32[0] <- 1.0, else guard_u32[0] <- 0,
+ *  flag_f32[0] <- 0.0 (each output optional; one thread, no host sync, capturable).  The _g forms of the AdamW step take such
+ *  a word: while it is non-zero the launch leaves p, m and v untouched, so a step whose gradients are invalid on ANY rank
+ *  updates nothing on EVERY rank (the reference has no counterpart: torch's GEMMs cannot time out). */
+int ofq_step_guard(const void* const* words, int n_words, float* loss, void* guard_u32, float* flag_f32, ofq_stream_t stream);
+int ofq_adamw_multi_g(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps, float weight_decay,
+                      double bias_correction1, double bias_correction2, const void* guard, ofq_stream_t stream);
+int ofq_adamw_multi_dev_g(const void* tensors, int64_t n_tensors, const float* hyper_dev, const void* guard, ofq_stream_t stream);
 
 /* ---- K16  CGA: freeze_outside_boundary_weight_idx cga.py:450-469 and the step hooks cga.py:962-964,
  *  :994-997.  frozen[r][c] in {0,1}; range_ws: 2 ints of scratch (global min / max level). */

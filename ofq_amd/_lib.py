@@ -108,6 +108,9 @@ SIGNATURES = {
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_adamw_hyper_pack": (i32, [vp, f32, f64, f64, f32, f32, f64, f64]),
     "ofq_adamw_multi_dev": (i32, [vp, i64, vp, vp]),
+    "ofq_adamw_multi_g": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp, vp]),
+    "ofq_adamw_multi_dev_g": (i32, [vp, i64, vp, vp, vp]),
+    "ofq_step_guard": (i32, [vp, i32, vp, vp, vp, vp]),
     "ofq_store_f32": (i32, [vp, vp, i32, vp]),
     "ofq_cga_freeze_mask": (i32, [vp, i64, i64, i32, f32, vp, vp, vp]),
     "ofq_cga_tensor_entry_bytes": (i64, []),

@@ -26,8 +26,13 @@ struct AdamWPack {
 // in a hipGraph must not carry the per-step lr and bias corrections in its arguments)
 struct AdamWHyper { float lr, omb1, b2, omb2, eps, wd, bc1, sqrt_bc2; };
 
+// guard: a device word (NULL: none) that, when non-zero, makes the launch leave p, m and v untouched -- the step guard of
+// ofq_step_guard (a stream-K hand-off timed out somewhere in this step, on this or on another rank: the gradients are invalid).
+// The word is compared as bits without a float's sign bit, so an int 1, a float 0.25 (an averaged flag) and a NaN all count.
 template <bool DEV>
-__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, AdamWHyper hv, const AdamWHyper* __restrict__ hd) {
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamWPack pk, AdamWHyper hv, const AdamWHyper* __restrict__ hd,
+                                                          const unsigned* __restrict__ guard) {
+  if (guard != nullptr && (__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffffu) != 0u) return;
   const AdamWHyper h = DEV ? *hd : hv;
   const float lr = h.lr, omb1 = h.omb1, b2 = h.b2, omb2 = h.omb2, eps = h.eps, wd = h.wd, bc1 = h.bc1, sqrt_bc2 = h.sqrt_bc2;
   int ti = 0;
@@ -103,7 +108,9 @@ extern "C" int ofq_store_f32(float* dst_dev, const float* host_vals, int n, ofq_
   return 0;
 }
 
-static int adamw_launch(const void* tensors, int64_t n_tensors, const AdamWHyper& hv, const AdamWHyper* hd, hipStream_t stream) {
+static int adamw_launch(const void* tensors, int64_t n_tensors, const AdamWHyper& hv, const AdamWHyper* hd, const void* guard,
+                        hipStream_t stream) {
+  const unsigned* gd = (const unsigned*)guard;
   const AdamWTensor* ts = (const AdamWTensor*)tensors;
   for (int64_t base = 0; base < n_tensors; base += ADAMW_PACK) {
     AdamWPack pk = {};
@@ -118,8 +125,8 @@ static int adamw_launch(const void* tensors, int64_t n_tensors, const AdamWHyper
     }
     pk.first_chunk[pk.n] = (int32_t)chunks;
     if (chunks == 0) continue;
-    if (hd) hipLaunchKernelGGL(adamw_multi_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd);
-    else hipLaunchKernelGGL(adamw_multi_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd);
+    if (hd) hipLaunchKernelGGL(adamw_multi_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd, gd);
+    else hipLaunchKernelGGL(adamw_multi_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, stream, pk, hv, hd, gd);
     OFQ_LAUNCH_CHECK();
   }
   return 0;
@@ -131,11 +138,52 @@ extern "C" int ofq_adamw_multi(const void* tensors, int64_t n_tensors, float lr,
   if (!tensors || n_tensors <= 0 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
   AdamWHyper h;
   ofq_adamw_hyper_pack((float*)&h, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2);
-  return adamw_launch(tensors, n_tensors, h, nullptr, (hipStream_t)stream);
+  return adamw_launch(tensors, n_tensors, h, nullptr, nullptr, (hipStream_t)stream);
+}
+// the same with a step guard (see adamw_multi_kernel): guard = a 4-byte device word or NULL
+extern "C" int ofq_adamw_multi_g(const void* tensors, int64_t n_tensors, float lr, double beta1, double beta2, float eps,
+                                 float weight_decay, double bias_correction1, double bias_correction2, const void* guard,
+                                 ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || bias_correction1 <= 0.0 || bias_correction2 <= 0.0) return OFQ_EINVAL;
+  AdamWHyper h;
+  ofq_adamw_hyper_pack((float*)&h, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2);
+  return adamw_launch(tensors, n_tensors, h, nullptr, guard, (hipStream_t)stream);
 }
 
 // the same step with the eight scalars read from DEVICE memory (hyper_dev: 8 floats in ofq_adamw_hyper_pack's order)
 extern "C" int ofq_adamw_multi_dev(const void* tensors, int64_t n_tensors, const float* hyper_dev, ofq_stream_t stream) {
   if (!tensors || n_tensors <= 0 || !hyper_dev) return OFQ_EINVAL;
-  return adamw_launch(tensors, n_tensors, AdamWHyper{}, (const AdamWHyper*)hyper_dev, (hipStream_t)stream);
+  return adamw_launch(tensors, n_tensors, AdamWHyper{}, (const AdamWHyper*)hyper_dev, nullptr, (hipStream_t)stream);
+}
+extern "C" int ofq_adamw_multi_dev_g(const void* tensors, int64_t n_tensors, const float* hyper_dev, const void* guard,
+                                     ofq_stream_t stream) {
+  if (!tensors || n_tensors <= 0 || !hyper_dev) return OFQ_EINVAL;
+  return adamw_launch(tensors, n_tensors, AdamWHyper{}, (const AdamWHyper*)hyper_dev, guard, (hipStream_t)stream);
+}
+
+// The step guard.  words[0..n): device words that are non-zero when something made this step's gradients invalid -- the error
+// words of the stream-K workspaces (ofq_qgemm_bf16s_nt_sk), the flag elements the data-parallel wrapper appends to its gradient
+// buckets (every rank's flag, averaged by the bucket's all-reduce: the same value on every rank).  If any is set (bits without
+// the sign bit non-zero): loss[0] <- NaN, guard_u32[0] <- 1, flag_f32[0] <- 1.0; otherwise guard_u32[0] <- 0, flag_f32[0] <- 0.0
+// and the loss stays.  Every output is optional.  One thread, no host sync, capturable.
+struct StepGuardArgs { const unsigned* w[32]; int n; };
+__global__ void step_guard_kernel(StepGuardArgs a, float* __restrict__ loss, unsigned* __restrict__ guard, float* __restrict__ flag) {
+  unsigned any = 0u;
+  for (int i = 0; i < a.n; ++i) any |= __hip_atomic_load(a.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffffu;
+  if (any != 0u && loss != nullptr) loss[0] = __builtin_nanf("");
+  if (guard != nullptr) guard[0] = any != 0u ? 1u : 0u;
+  if (flag != nullptr) flag[0] = any != 0u ? 1.f : 0.f;
+}
+extern "C" int ofq_step_guard(const void* const* words, int n_words, float* loss, void* guard_u32, float* flag_f32,
+                              ofq_stream_t stream) {
+  if (n_words < 0 || n_words > 32 || (n_words > 0 && !words)) return OFQ_EINVAL;
+  StepGuardArgs a = {};
+  a.n = n_words;
+  for (int i = 0; i < n_words; ++i) {
+    if (!words[i] || ((uintptr_t)words[i] & 3)) return OFQ_EINVAL;
+    a.w[i] = (const unsigned*)words[i];
+  }
+  hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, loss, (unsigned*)guard_u32, flag_f32);
+  OFQ_LAUNCH_CHECK();
+  return 0;
 }

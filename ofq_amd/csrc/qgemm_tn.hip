@@ -553,6 +553,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
   int kmod[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) kmod[i] = (t_begin * QTN_BK + a_k + 16 * i) % p.S;
+  const int kstep = QTN_BK % p.S;        // any S >= 1: kmod < S and kstep < S, so one conditional subtraction per k-step suffices
 #ifdef TNW_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = clock64();
@@ -574,8 +575,8 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
       rok[sl][i] = a_ok && k < p.Ktok && live;
       ra[sl][i] = *reinterpret_cast<const f32x4v*>(Ap + (unsigned)(kc * ldA));
       rs[sl][i] = p.s[kmod[i]];
-      kmod[i] += QTN_BK;                                   // gload runs on consecutive k-steps: k mod S incrementally
-      kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;               // S >= QTN_BK (host check)
+      kmod[i] += kstep;                                    // gload runs on consecutive k-steps: k mod S incrementally
+      kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;
     }
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -819,7 +820,7 @@ __device__ __forceinline__ void tn_wide_body(const QTnArgs& p, const int lid, co
         offA[i] += advA;
         ra[sl][i] = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(Ap) + min(offA[i], maxA));
         rs[sl][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.s) + 4u * (unsigned)kmod[i]);
-        kmod[i] += QTN_BK;
+        kmod[i] += kstep;
         kmod[i] -= (kmod[i] >= p.S) ? p.S : 0;
       } else {
         constexpr int j = P - 2 * NPA - NPB * NJ - 2;
@@ -1572,7 +1573,7 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   if (compute_db && !db) return OFQ_EINVAL;
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (N > 128 && (N & 7) == 0 && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {
+  if (N > 128 && (N & 7) == 0 && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {
     // wide tile: one dY split feeds three (two when N is not a multiple of 384) 128-column blocks
     if (N % 384 == 0) {
       a.tiles_n = (int)(N / 384);
@@ -1600,7 +1601,8 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
 }
 
 static bool tn_wide_ok(int64_t Ktok, int64_t N, int64_t S, int64_t lda, int64_t ldb) {
-  return N > 128 && (N & 7) == 0 && S >= QTN_BK && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31);
+  (void)S;                         // (any step-vector length: Swin's 4-D MLP quantisers have S = 7 / 14 / 28)
+  return N > 128 && (N & 7) == 0 && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31);
 }
 
 extern "C" size_t ofq_qgemm_bf16s_tn_group_ws_bytes(const ofq_tn_job* jobs, int njobs, int split) {

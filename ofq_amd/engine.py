@@ -215,7 +215,7 @@ def invalidate_weight_codes(model):
 def _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga):
     """Everything of one step that touches the device (train.py:893-933); GraphedTrainStep captures exactly this."""
     loss = _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp)
-    _step_update(optimizer, dp, cga)
+    _step_update(optimizer, dp, cga, loss=loss)
     return loss
 
 
@@ -254,10 +254,19 @@ def _step_compute(model, optimizer, images, target, soft_target, loss_fn, dp):
     return loss
 
 
-def _step_update(optimizer, dp, cga):
-    """finish the gradient all-reduce, [CGA mask], AdamW, [CGA restore] (train.py:927-933, cga.py:953-1013)."""
+def _step_update(optimizer, dp, cga, loss=None, guard_dp=None):
+    """finish the gradient all-reduce, the step guard, [CGA mask], AdamW, [CGA restore] (train.py:927-933, cga.py:953-1013).
+
+    The step guard (ops.step_guard; the reference has no counterpart -- torch's GEMMs cannot time out): between the collectives
+    and the optimiser one tiny launch looks at this rank's stream-K error words and at the flag elements of the gradient buckets
+    (guard_dp: the wrapper whose collectives the caller has issued itself; every bucket carries the flags of ALL ranks once it is
+    reduced).  If any is set the loss of this step becomes NaN on EVERY rank and the AdamW launches that follow update nothing on
+    EVERY rank; ops.nt_sk_poll then raises on every rank at the same step boundary."""
     if dp is not None:
         dp.finish_gradient_sync()
+    if loss is not None and loss.is_cuda:
+        gdp = dp if dp is not None else guard_dp
+        ops.step_guard(loss.device, loss=loss.detach(), extra_words=gdp.flag_word_ptrs() if gdp is not None else ())
     if cga is not None:
         cga.before_step(optimizer)
     optimizer.step()
@@ -269,7 +278,9 @@ def train_step(model, optimizer, images, target, soft_target, loss_fn=None, dp=N
     """One QAT step: student forward, KD loss, backward (+ bucketed all-reduce), [CGA mask], AdamW, [CGA restore]."""
     loss_fn = loss_fn or KDLossSoftandHard()
     if images.is_cuda:
-        ops.nt_sk_poll(images.device)           # raises when an earlier step's stream-K hand-off timed out (no host sync)
+        # raises when an earlier step's stream-K hand-off timed out (one rank: no host sync; several ranks: waits for the copy the
+        # previous call queued -- a step behind the device at most -- so that every rank raises at the same step)
+        ops.nt_sk_poll(images.device, wait=dp is not None and dp.sync and dp.world > 1)
     if dp is not None:
         dp.sync_buffers()                       # DDP's per-forward buffer broadcast (train.py:727, broadcast_buffers=True)
     return _step_body(model, optimizer, images, target, soft_target, loss_fn, dp, cga)
@@ -376,7 +387,7 @@ class GraphedTrainStep:
                     self.dp.finish_gradient_sync()         # packs what the hooks have not packed; starts nothing
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, stream=self.stream, pool=g.pool(), capture_error_mode=mode):
-                    _step_update(self.optimizer, None, self.cga)
+                    _step_update(self.optimizer, None, self.cga, loss=self.loss, guard_dp=self.dp)
             finally:
                 self.dp.pack_only = False
             self.graph_b = gb
@@ -446,7 +457,7 @@ class GraphedTrainStep:
                     raise
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, stream=self.stream, pool=pool[0], capture_error_mode=capture_mode):
-                _step_update(self.optimizer, None, self.cga)
+                _step_update(self.optimizer, None, self.cga, loss=self.loss, guard_dp=self.dp)
         finally:
             torch.autograd.set_multithreading_enabled(prev_mt)
             dp.pack_only, dp.on_packed = False, None
@@ -462,7 +473,7 @@ class GraphedTrainStep:
                 loss = train_step(self.model, self.optimizer, images, target, soft_target, self.loss_fn, self.dp, self.cga)
             cur.wait_stream(self.stream)
             return loss
-        ops.nt_sk_poll(images.device)
+        ops.nt_sk_poll(images.device, wait=self.dp is not None and self.dp.sync and self.dp.world > 1)
         if self.dp is not None:
             self.dp.sync_buffers()
         # the signedness latch of a still-unsigned image quantiser: decide on the host, as the eager forward would

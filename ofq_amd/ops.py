@@ -665,29 +665,79 @@ def nt_sk_poison(loss):
         _chk(lib().ofq_qgemm_bf16s_nt_sk_check(buf.data_ptr(), loss.data_ptr(), _stream()), "ofq_qgemm_bf16s_nt_sk_check")
 
 
+_guard_words = {}
+
+
+def step_guard_word(device):
+    """The device's step-guard word (int32, 0 = the step is good): written by step_guard() once per step, read by the AdamW launches
+    of FusedAdamW (a non-zero word makes them leave p, m, v untouched) and by nt_sk_poll on the host.  Allocated by the first EAGER
+    step (never inside a capture: engine's warm-up steps come first)."""
+    w = _guard_words.get(device.index)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ofq_amd: the step-guard word must exist before a stream capture (run an eager step first)")
+        w = _guard_words[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def step_guard_ptr(device):
+    """Address of the guard word for the AdamW launches: 0 (no guard) while no step of engine has created it."""
+    w = _guard_words.get(device.index)
+    return 0 if w is None else w.data_ptr()
+
+
+def sk_error_word_ptrs(device):
+    """Addresses of the error words of the device's stream-K workspaces (int32 word 4096 of each flag area)."""
+    return [buf.data_ptr() + 4 * 4096 for (idx, _st), buf in _sk_ws.items() if idx == device.index]
+
+
+def step_guard(device, loss=None, extra_words=(), flag_out=None, set_guard=True):
+    """One tiny launch (no host sync, capturable): OR the stream-K error words of the device and `extra_words` (device addresses:
+    the flag elements of the data-parallel buckets, the same on every rank once reduced); if any is set, loss <- NaN, the guard word
+    <- 1 (AdamW then updates nothing) and flag_out[0] <- 1.0; else guard word <- 0, flag_out[0] <- 0.0.  engine calls it between
+    the gradient collectives and the optimiser (set_guard) and DataParallel when it packs a bucket (flag_out = the bucket's flag)."""
+    words = list(sk_error_word_ptrs(device)) + [int(w) for w in extra_words]
+    if len(words) > 32:
+        words = words[:len(sk_error_word_ptrs(device))] + words[-(32 - len(sk_error_word_ptrs(device))):]     # the LATEST buckets' flags
+    arr = (_lib.vp * max(1, len(words)))(*words)
+    g = step_guard_word(device) if set_guard else None
+    _chk(lib().ofq_step_guard(arr, len(words), _p(loss), _p(g), _p(flag_out), _stream()), "ofq_step_guard")
+
+
 _sk_poll = {}
 
 
-def nt_sk_poll(device):
+def nt_sk_poll(device, wait=False):
     """Host side of the same check without a synchronisation: every call queues an asynchronous copy of the error words to
     pinned memory behind the work enqueued so far and looks at the copy queued by the PREVIOUS call if it has arrived.
     Raises once an error word is seen (after re-zeroing the flag areas, so that training can be resumed from a checkpoint
     without restarting the process); engine.train_step / GraphedTrainStep call it once per step."""
-    bufs = [buf for (idx, _st), buf in _sk_ws.items() if idx == device.index]
+    bufs = [buf[:32768].view(torch.int32)[4096:4097] for (idx, _st), buf in _sk_ws.items() if idx == device.index]
+    g = _guard_words.get(device.index)
+    if g is not None:
+        # the guard word: with several ranks it carries EVERY rank's error (reduced with the buckets) and is the ONLY word looked
+        # at -- this rank's own error words are ahead of it by up to a step, and a rank that raised on them alone would leave its
+        # peers waiting in a collective
+        bufs = [g] if wait else bufs + [g]
+    elif wait:
+        bufs = []                 # (before the first step of a several-rank run: nothing symmetric to look at yet)
     st = _sk_poll.get(device.index)
+    if st is not None and wait:
+        st[1].synchronize()       # several ranks: all of them must look at the SAME step's word, so that they raise together
     if st is not None and st[1].query():
         bad = bool(st[0][:st[2]].any())
         _sk_poll.pop(device.index)
         st = None
         if bad:
             nt_sk_reset(device)
-            raise RuntimeError("ofq_amd: a stream-K hand-off timed out in an earlier step (a workgroup of ofq_qgemm_bf16s_nt_sk "
-                               "waited ~0.6 s for a partial tile): the gradients since then are invalid; the flag areas have been "
-                               "re-zeroed -- restore the last checkpoint")
+            raise RuntimeError("ofq_amd: a stream-K hand-off timed out in an earlier step, on this rank or on another (a workgroup "
+                               "of ofq_qgemm_bf16s_nt_sk waited ~0.6 s for a partial tile): the gradients since then are invalid "
+                               "and the optimiser has skipped those steps on every rank; the flag areas have been re-zeroed -- "
+                               "restore the last checkpoint")
     if st is None and bufs:
         host = torch.empty(len(bufs), dtype=torch.int32).pin_memory()
         for i, buf in enumerate(bufs):
-            host[i:i + 1].copy_(buf[:32768].view(torch.int32)[4096:4097], non_blocking=True)
+            host[i:i + 1].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         _sk_poll[device.index] = (host, ev, len(bufs))
@@ -699,6 +749,9 @@ def nt_sk_reset(device):
     for (idx, _st), buf in _sk_ws.items():
         if idx == device.index:
             _chk(lib().ofq_qgemm_bf16s_nt_sk_reset(buf.data_ptr(), _stream()), "ofq_qgemm_bf16s_nt_sk_reset")
+    g = _guard_words.get(device.index)
+    if g is not None:
+        g.zero_()
 
 
 def nt_sk_inject_fault(device, wg):
@@ -859,7 +912,7 @@ def tn_tiles(M, N):
 
 def tn_groupable(Ktok, M, N, S, lda, ldb):
     """May this dW problem join a grouped launch (ofq_qgemm_bf16s_tn_group)?"""
-    return (N >= 256 and N % 16 == 0 and M % 4 == 0 and S >= 32 and lda % 4 == 0 and ldb % 16 == 0
+    return (N >= 256 and N % 16 == 0 and M % 4 == 0 and S >= 1 and lda % 4 == 0 and ldb % 16 == 0
             and Ktok * lda < (1 << 31) and Ktok * ldb < (1 << 31))
 
 

@@ -146,19 +146,22 @@ class FusedAdamW(torch.optim.Optimizer):
                 continue
             for t0, ps in self._classes(plist).items():
                 tens = self._table(ps)
+                # the device's step-guard word (engine's step writes it between the collectives and this call; None before the
+                # first such step): while it is non-zero the launch updates nothing -- see ops.step_guard
+                guard = ops.step_guard_ptr(ps[0].device) or None
                 if capturing:
                     i = len(self._graph_classes)
                     if i >= self.MAX_GRAPH_CLASSES:
                         raise RuntimeError("FusedAdamW: more than %d (group, step) classes in one captured step" % i)
                     hyper = self._hyper_pool[8 * i:8 * i + 8]
                     self._graph_classes.append(_GraphClass(group, ps, hyper))
-                    ops._chk(lib.ofq_adamw_multi_dev(tens.ctypes.data, len(ps), hyper.data_ptr(), ops._stream()),
-                             "ofq_adamw_multi_dev")
+                    ops._chk(lib.ofq_adamw_multi_dev_g(tens.ctypes.data, len(ps), hyper.data_ptr(), guard, ops._stream()),
+                             "ofq_adamw_multi_dev_g")
                     continue
                 t = t0 + 1
                 self._set_step(ps, t)
                 b1, b2 = group["betas"]
-                ops._chk(lib.ofq_adamw_multi(tens.ctypes.data, len(ps), float(group["lr"]), float(b1), float(b2),
-                                             float(group["eps"]), float(group["weight_decay"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
-                                             ops._stream()), "ofq_adamw_multi")
+                ops._chk(lib.ofq_adamw_multi_g(tens.ctypes.data, len(ps), float(group["lr"]), float(b1), float(b2),
+                                               float(group["eps"]), float(group["weight_decay"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
+                                               guard, ops._stream()), "ofq_adamw_multi_g")
         return loss

@@ -60,7 +60,7 @@ def grad_slot(param):
 
 
 class GradBucket:
-    __slots__ = ("flat", "params", "pending", "work", "views")
+    __slots__ = ("flat", "params", "pending", "work", "views", "flag")
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
@@ -194,8 +194,12 @@ class DataParallel(torch.nn.Module):
         self._bucket_of = {}
         for grp in groups:
             n = sum(p.numel() for p in grp)
-            flat = torch.zeros(n, dtype=grp[0].dtype, device=grp[0].device)
+            # one element more than the gradients: the bucket's step flag (this rank's stream-K error state when the bucket was
+            # packed; the all-reduce averages it with the gradients, so afterwards every rank holds the same non-zero value when
+            # ANY rank's step went wrong -- engine's step guard reads it, no extra collective)
+            flat = torch.zeros(n + 1, dtype=grp[0].dtype, device=grp[0].device)
             b = GradBucket(flat, grp)
+            b.flag = flat[n:n + 1]
             off = 0
             b.views = []
             for p in grp:
@@ -243,6 +247,11 @@ class DataParallel(torch.nn.Module):
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(b.views, b.params):
             p.grad = v
+        if b.flat.is_cuda:
+            ops = sys.modules.get(__package__ + ".ops")
+            if ops is not None:                       # flag <- 1.0 if a stream-K hand-off of this rank has timed out so far, else 0.0
+                ops.step_guard(b.flat.device, flag_out=b.flag, set_guard=False)
+                ops.LAUNCHES[0] -= 1                  # (not "work since the last cut" for engine's segmented capture)
         if self.pack_only:
             b.work = "packed"
             if self.on_packed is not None:
@@ -435,6 +444,10 @@ class DataParallel(torch.nn.Module):
             self.release()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
+
+    def flag_word_ptrs(self):
+        """Device addresses of the buckets' step flags (see _build_buckets), for ops.step_guard."""
+        return [b.flag.data_ptr() for b in self.buckets if b.flat.is_cuda]
 
     def gradient_bytes(self):
         return sum(b.flat.numel() * 4 for b in self.buckets)

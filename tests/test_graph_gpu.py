@@ -752,6 +752,117 @@ def _two_rank_worker(rank, world, port, errq):
         raise
 
 
+def _two_rank_fault_worker(rank, world, port, errq):
+    """A stream-K hand-off times out on rank 1 ONLY (fault injection): both ranks must see it in the same step -- NaN loss, no
+    parameter, moment or step changed by that step's optimiser on either rank -- and both must raise at the same later call."""
+    import traceback
+    try:
+        import numpy as np
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from ofq_amd import engine, ops, parallel
+        from ofq_amd.quantization.utils import KDLossSoftandHard
+        base = _tiny(seed=0)
+        batches = [_batch(seed=40 + 2 * i + rank) for i in range(2)]
+        engine.setup_alpha(base, batches[0][0])
+        loss_fn = KDLossSoftandHard()
+        dev = torch.device("cuda", 0)
+        rs = np.random.RandomState(3)
+        dy = torch.from_numpy(rs.randn(640, 256).astype(np.float32)).cuda()
+        ks = torch.from_numpy((0.01 + rs.rand(256) * 0.09).astype(np.float32)).cuda()
+        wT = ops.codes_transpose_bf16(torch.from_numpy((2 * rs.randint(-8, 8, (256, 384)) + 1).astype(np.int8)).cuda())
+        scratch = torch.empty((640, 384), device="cuda")
+        for mode in ("eager", "segmented"):
+            model = copy.deepcopy(base).train()
+            dp = parallel.DataParallel(model, bucket_mb=1.0)
+            opt = engine.make_optimizer(model, lr=1e-3, weight_decay=0.05)
+            gs = engine.GraphedTrainStep(model, opt, loss_fn, dp=dp, warmup=2, mode=mode) if mode != "eager" else None
+            stream = gs.stream if gs is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):                # the workspace (and its error word) of the stream the steps run on
+                ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], scratch, wgs=3)
+            torch.cuda.synchronize()
+            step = (lambda b: gs(*b)) if gs is not None else (lambda b: engine.train_step(model, opt, *b, loss_fn, dp=dp))
+            for i in range(4):
+                assert torch.isfinite(step(batches[i % 2]))
+            torch.cuda.synchronize()
+            before = [p.detach().clone() for p in model.parameters()]
+            moments = [opt.state[p]["exp_avg"].clone() for p in model.parameters() if p in opt.state]
+            if rank == 1:
+                with torch.cuda.stream(stream):
+                    ops.nt_sk_inject_fault(dev, 1)
+                    ops.qgemm_bf16s_nt_sk([(dy, wT, ks, 0.25)], scratch, wgs=3)
+                    ops.nt_sk_inject_fault(dev, -1)
+                torch.cuda.synchronize()
+                assert ops.nt_sk_error(dev) != 0
+            else:
+                assert ops.nt_sk_error(dev) == 0
+            raised_at = -1
+            for i in range(4):
+                try:
+                    loss = step(batches[i % 2])
+                    torch.cuda.synchronize()
+                    assert torch.isnan(loss), (mode, rank, i, float(loss))       # on BOTH ranks, from the very step of the fault on
+                except RuntimeError as e:
+                    assert "stream-K hand-off timed out" in str(e), str(e)
+                    raised_at = i
+                    break
+            assert raised_at == 2, (mode, rank, raised_at)                     # fault in step 0, seen by the poll of call 2 on both ranks
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters())), (mode, rank)
+            assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(moments, [q for q in model.parameters() if q in opt.state]))
+            assert ops.nt_sk_error(dev) == 0                                   # re-zeroed by the poll that raised
+            assert torch.isfinite(step(batches[0]))                            # and training can go on (from a checkpoint, in real life)
+            torch.cuda.synchronize()
+            flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+            lo, hi = flat.clone(), flat.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), "replicas diverged after the fault in mode " + mode
+            dp.release()
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:  # noqa: BLE001
+        errq.put("rank %d:\n%s" % (rank, traceback.format_exc()))
+        raise
+
+
+def _spawn_two(worker, timeout=600):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    errq = ctx.SimpleQueue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, errq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    msgs = []
+    while not errq.empty():
+        msgs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            msgs.append("a rank was still running after %d s" % timeout)
+    assert not msgs, "\n".join(msgs)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_a_stream_k_timeout_on_one_rank_stops_the_optimiser_on_every_rank():
+    """the error word used to reach the faulty rank's loss only, graph B applied the corrupt (reduced) gradients on every
+    rank, and the faulty rank alone raised a step or two later while its peers blocked in their next collective.  Now every gradient
+    bucket carries one flag element (this rank's error state when the bucket was packed; averaged by the bucket's own all-reduce),
+    ofq_step_guard ORs the flags between the collectives and the optimiser -- loss <- NaN, AdamW launches update nothing -- and the
+    host poll raises on all ranks at the same call (tests: eager step and the segmented graph, two ranks sharing the GPU over gloo)."""
+    _spawn_two(_two_rank_fault_worker)
+
+
 def test_two_processes_sharing_the_gpu_repeat_their_steps_bit_for_bit():
     """Two INDEPENDENT processes on one GPU, each repeating the same five eager training steps 150 times from the same state
     (tools/two_rank_trace.py, MODE=solo): every repetition must leave the trace of the first -- losses, every gradient, every

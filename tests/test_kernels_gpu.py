@@ -572,9 +572,12 @@ def test_engine_step_surfaces_a_stream_k_timeout(ops):
     ops.nt_sk_inject_fault(dev, 1)
     ops.qgemm_bf16s_nt_sk([(dy, ops.codes_transpose_bf16(wcodes), ks, 0.25)], out, wgs=3)
     ops.nt_sk_inject_fault(dev, -1)
+    before = [p.detach().clone() for p in model.parameters()]
     l1 = engine.train_step(model, opt, img, tgt, soft)
     torch.cuda.synchronize()
     assert torch.isnan(l1)
+    # round 6: the step guard (ofq_step_guard) sits between the backward pass and the optimiser -- nothing was updated
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
     with pytest.raises(RuntimeError, match="stream-K hand-off timed out"):
         engine.train_step(model, opt, img, tgt, soft)
         torch.cuda.synchronize()
@@ -582,6 +585,86 @@ def test_engine_step_surfaces_a_stream_k_timeout(ops):
     torch.cuda.synchronize()
     assert ops.nt_sk_error(dev) == 0
     assert torch.isfinite(engine.train_step(model, opt, img, tgt, soft))
+
+
+def test_step_guard_words_and_the_guarded_adamw_launch(ops):
+    """ofq_step_guard: OR of device words compared as bits without a float's sign bit (an int 1, a float 0.25 from an averaged
+    bucket flag, -0.0 = clean, NaN = set); outputs loss / guard word / flag.  ofq_adamw_multi_g / _dev_g: a non-zero guard word
+    makes the launch leave p, m, v untouched; a zero word gives the bits of the unguarded launch."""
+    from ofq_amd import _lib
+    from ofq_amd.optim import FusedAdamW
+    dev = torch.device("cuda", 0)
+    words = torch.zeros(4, dtype=torch.int32, device=dev)
+    fw = words.view(torch.float32)
+    guard = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    flag = torch.full((1,), 7.0, device=dev)
+
+    def run(n=4, with_loss=True):
+        loss = torch.ones(1, device=dev)
+        arr = (_lib.vp * 4)(*[words.data_ptr() + 4 * i for i in range(4)])
+        ops._chk(ops.lib().ofq_step_guard(arr, n, loss.data_ptr() if with_loss else None, guard.data_ptr(), flag.data_ptr(), ops._stream()), "g")
+        torch.cuda.synchronize()
+        return float(loss), int(guard), float(flag)
+    assert run() == (1.0, 0, 0.0)
+    fw[1] = -0.0
+    assert run() == (1.0, 0, 0.0)                       # the sign bit alone is not a flag
+    words[2] = 1
+    l, g, f = run()
+    assert l != l and g == 1 and f == 1.0
+    assert run(n=2) == (1.0, 0, 0.0)                    # only the first n words count
+    words[2] = 0
+    fw[0] = 0.25
+    l, g, f = run(with_loss=False)
+    assert l == 1.0 and g == 1 and f == 1.0             # (no loss pointer: the other outputs still written)
+    fw[0] = float("nan")
+    assert run()[1] == 1
+    fw[0] = 0.0
+    assert run() == (1.0, 0, 0.0)
+    assert ops.lib().ofq_step_guard(None, 33, None, None, None, ops._stream()) != 0
+
+    torch.manual_seed(0)
+    ps = [torch.randn(1000, device=dev), torch.randn(37, 5, device=dev)]
+    gs = [torch.randn_like(p) for p in ps]
+
+    def adam(guard_val, captured):
+        qs = [torch.nn.Parameter(p.clone()) for p in ps]
+        opt = FusedAdamW(qs, lr=1e-2, weight_decay=0.1)
+        for q, g_ in zip(qs, gs):
+            q.grad = g_.clone()
+        opt.step()                                      # creates the state (unguarded: no engine step has made the word yet, or it is 0)
+        w = ops.step_guard_word(dev)
+        w.fill_(guard_val)
+        try:
+            if captured:
+                opt.begin_capture(dev)
+                gph = torch.cuda.CUDAGraph()
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.graph(gph, stream=st):
+                    opt.step()
+                opt.advance_for_replay()
+                gph.replay()
+            else:
+                opt.step()
+            torch.cuda.synchronize()
+        finally:
+            w.zero_()
+        return [q.detach().clone() for q in qs] + [opt.state[q]["exp_avg"].clone() for q in qs] + [opt.state[q]["exp_avg_sq"].clone() for q in qs]
+    ops.step_guard_word(dev).zero_()
+    for captured in (False, True):
+        one = adam(0, captured)
+        base = adam(0, False)
+        assert all(torch.equal(a, b) for a, b in zip(one, base))
+        held = adam(1, captured)
+        qs = [torch.nn.Parameter(p.clone()) for p in ps]
+        opt = FusedAdamW(qs, lr=1e-2, weight_decay=0.1)
+        for q, g_ in zip(qs, gs):
+            q.grad = g_.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        first = [q.detach().clone() for q in qs] + [opt.state[q]["exp_avg"].clone() for q in qs] + [opt.state[q]["exp_avg_sq"].clone() for q in qs]
+        assert all(torch.equal(a, b) for a, b in zip(held, first)), captured      # the guarded second step changed nothing
+        assert not all(torch.equal(a, b) for a, b in zip(one, first))
 
 
 @pytest.mark.parametrize("colmode", [0, 1])

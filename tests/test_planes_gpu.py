@@ -130,6 +130,35 @@ def test_two_plane_dw_gemm_matches_three_planes_and_fp64(ops, shape):
     assert rel_err(res[2].cpu(), res[3].cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("S", [1, 7, 14, 28, 31, 32, 33, 49])
+def test_wide_dw_gemm_with_a_step_vector_shorter_than_a_k_tile(ops, S):
+    """Swin's 4-D MLP quantisers carry S = 7 / 14 / 28 token steps (one per row of the feature map); until round 6 such a layer's dW
+    ran on the narrow three-plane kernel whatever its width (the wide kernels' incremental `k mod S` assumed S >= 32).  Wide
+    shapes with short step vectors: against fp64 in both plane forms, single == grouped bit for bit, and every split."""
+    rs = np.random.RandomState(S)
+    import ofq_oracle as O
+    for Ktok, Mo, Nc in ((1568, 384, 1536), (1568 + 40, 1536, 384), (784, 192, 768), (1000, 768, 192 + 64)):
+        dy = (T(det_normalish((Ktok, Mo), 91 + S, 1.0)) * T(det_uniform((Ktok, 1), 92, 1e-3, 10.0))).cuda()
+        codes = torch.from_numpy(rs.randint(-4, 4, (Ktok, Nc)).astype(np.int8)).cuda()
+        s = T(det_uniform((S,), 93 + S, 0.1, 1.0)).cuda()
+        baft = T(det_uniform((Nc,), 94, -0.05, 0.05)).cuda()
+        ae = O.lsq_effective_scale(s.cpu(), 0.01)[torch.arange(Ktok) % S].double().cuda()
+        db = dy.double().sum(0)
+        ref = (dy.double() * ae[:, None]).t() @ codes.double() + db[:, None] * baft.double()[None, :]
+        den = ((dy.double() * ae[:, None]).abs().t() @ codes.double().abs()) + 1e-30
+        assert ops.tn_groupable(Ktok, Mo, Nc, S, dy.stride(0), codes.stride(0))
+        for planes in (2, 3):
+            for split in (1, 3, None):
+                dW, dbg = ops.qgemm_bf16s_tn(dy, codes, s, S, 0.01, None, baft, split=split, compute_db=True, planes=planes)
+                assert float(((dW.double() - ref).abs() / den).max()) < 1e-6, (planes, split, Ktok)
+                assert rel_err(dbg.cpu(), db.float().cpu()) < 1e-5
+            dW, dbg = ops.qgemm_bf16s_tn(dy, codes, s, S, 0.01, None, baft, split=3, compute_db=True, planes=planes)
+            job = {"dy2d": dy, "xcodes2d": codes, "lsq_s": s, "S": S, "gscale": 0.01, "baft": baft,
+                   "dW": torch.full((Mo, Nc), float("nan"), device="cuda"), "db": torch.full((Mo,), float("nan"), device="cuda")}
+            ops.qgemm_bf16s_tn_group([job], split=3, planes=planes)
+            assert torch.equal(job["dW"], dW) and torch.equal(job["db"], dbg), planes
+
+
 def test_two_plane_attention_backward_matches_three_planes(ops):
     """dqkx (streaming, stacked heads) and dxq (128 x 384 tiles) at the DeiT-S geometry: two planes vs three and vs fp64; the pad
     columns of dS hold NaN on purpose (never read: the maximum word covers the real columns only)."""
