@@ -276,7 +276,7 @@ int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* dW, const fl
  *            optimiser step / gradient all-reduce (train.py:927-933), so a caller may collect the ones of a whole
  *            transformer block (Block.forward deit_vision_transformer.py:154-164: v, W_qk, proj, fc1, fc2) and run them
  *            here: each workgroup then owns a long token range, and the split-K partials shrink fivefold.
- *            Every job: N >= 256, N % 16 == 0, any S >= 1 (round 6: step vectors shorter than a 32-token k-tile too); all jobs of one tile class (N % 384 == 0 for all or none);
+ *            Every job: N > 128, N % 16 == 0, any S >= 1 (round 6: N < 256 and step vectors shorter than a 32-token k-tile too); all jobs of one tile class (N % 384 == 0 for all or none);
  *            njobs <= 8; `split` (>= 1) is common, about 256 / (sum of ceil(M/128) * ceil(N/384) over the jobs). */
 typedef struct ofq_tn_job {
   const float* dY; const int8_t* codes; float* dW; const float* lsq_s; float* db; const float* baft;

@@ -1441,21 +1441,21 @@ __device__ __forceinline__ void tn_reduce4_body(const int bx, const float* __res
                                                 const float* __restrict__ csum, float* __restrict__ db,
                                                 const float* __restrict__ baft, int M, int N, int split) {
   __shared__ float4 red[3][64];
-  __shared__ float dbs[2];
+  __shared__ float dbs[3];
   const int tx = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int N4 = N >> 2;
   const int64_t MN = (int64_t)M * N;
   const int g0 = bx * 64;
   const int total = M * N4;
-  const int o_first = g0 / N4, o_last = min(g0 + 63, total - 1) / N4;      // N4 >= 64: at most two rows per block
-  if (part < 2) {
-    const int o = part == 0 ? o_first : o_last;
+  const int o_first = g0 / N4, o_last = min(g0 + 63, total - 1) / N4;      // N4 >= 32 (N >= 128): at most three rows per block
+  if (part < 3) {
+    const int o = min(o_first + part, o_last);
     float v = 0.f;
     if (csum) {
       for (int s = tx; s < split; s += 64) v += csum[(int64_t)s * M + o];
       v = ofq_wave_sum(v);
       const int gfirst = o * N4;                                             // the block holding chunk (o, 0) publishes db[o]
-      if (tx == 0 && gfirst >= g0 && gfirst < g0 + 64 && (part == 0 || o_last != o_first)) db[o] = v;
+      if (tx == 0 && gfirst >= g0 && gfirst < g0 + 64 && o_first + part <= o_last) db[o] = v;
     } else if (db) {
       v = db[o];
     }
@@ -1490,7 +1490,7 @@ __device__ __forceinline__ void tn_reduce4_body(const int bx, const float* __res
     t.z = (t.z + r1.z) + (r2.z + r3.z);
     t.w = (t.w + r1.w) + (r2.w + r3.w);
     if (baft && (db || csum)) {
-      const float dbo = dbs[o == o_first ? 0 : 1];
+      const float dbo = dbs[o - o_first];
       const float4 bf = *reinterpret_cast<const float4*>(baft + 4 * c4);
       t.x += dbo * bf.x; t.y += dbo * bf.y; t.z += dbo * bf.z; t.w += dbo * bf.w;
     }
@@ -1573,7 +1573,8 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
   if (compute_db && !db) return OFQ_EINVAL;
   a.csum = compute_db ? (float*)ws + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (N > 128 && (N & 7) == 0 && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31)) {
+  static const bool narrow_small_s = getenv("OFQ_TN_NARROW_SMALL_S") != nullptr;      // A/B hook: round 5's routing of S < 32
+  if (N > 128 && (N & 7) == 0 && Ktok * lda < (1ll << 31) && Ktok * ldb < (1ll << 31) && !(narrow_small_s && S < QTN_BK)) {
     // wide tile: one dY split feeds three (two when N is not a multiple of 384) 128-column blocks
     if (N % 384 == 0) {
       a.tiles_n = (int)(N / 384);
@@ -1590,7 +1591,7 @@ extern "C" int ofq_qgemm_bf16s_tn(const float* dY, const int8_t* codes, float* d
     hipLaunchKernelGGL(qgemm_bf16s_tn_kernel<false>, dim3((unsigned)(a.tiles_m * a.tiles_n * split)), dim3(256), 0, st, a);
   }
   OFQ_LAUNCH_CHECK();
-  if ((N & 3) == 0 && N >= 256)
+  if ((N & 3) == 0 && N >= 128)
     hipLaunchKernelGGL(qgemm_tn_reduce4_kernel, dim3((unsigned)ceil_div(M * (N / 4), 64)), dim3(256), 0, st, (const float*)ws, dW,
                        compute_db ? (const float*)a.csum : (const float*)nullptr, db, baft, (int)M, (int)N, split);
   else
@@ -1628,7 +1629,7 @@ extern "C" int ofq_qgemm_bf16s_tn_group(const ofq_tn_job* jobs, int njobs, int s
     if (!q.dY || !q.codes || !q.dW || !q.lsq_s || q.Ktok <= 0 || q.M <= 0 || q.N <= 0 || q.S <= 0) return OFQ_EINVAL;
     if ((q.M & 3) || (q.N & 15) || (q.lda & 3) || (q.ldb & 15) || !al16(q.dY) || !al16(q.codes) || q.Ktok >= (1ll << 30))
       return OFQ_EINVAL;
-    if (!tn_wide_ok(q.Ktok, q.N, q.S, q.lda, q.ldb) || (q.N % 384 == 0) != three || q.N < 256) return OFQ_EINVAL;
+    if (!tn_wide_ok(q.Ktok, q.N, q.S, q.lda, q.ldb) || (q.N % 384 == 0) != three) return OFQ_EINVAL;      // (N > 128: the reduce's bound)
     if (q.compute_db && !q.db) return OFQ_EINVAL;
     QTnArgs& a = g.job[j];
     a.A = q.dY; a.B = q.codes; a.ws = wsf; a.s = q.lsq_s; a.lda = q.lda; a.ldb = q.ldb;

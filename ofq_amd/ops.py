@@ -903,6 +903,11 @@ def qgemm_bf16s_tn(dy2d, xcodes2d, lsq_s, S, gscale, db, baft, split=None, compu
 
 
 TN_GROUP_MAX = 8
+# Which dW problems join a grouped launch.  The entry takes any N > 128 and any S >= 1 (round 6); measured on one box
+# (profiles/r06_dw_routing_ab.txt): grouping the N = 192 layers of DeiT-T / Swin's stage 2 changes nothing (17.27 -> 17.27 ms,
+# 42.07 -> 42.16), so the rule for N stays round 5's; S < 32 (Swin's 4-D MLP quantisers) joins.  Environment: A/B hooks.
+TN_GROUP_MIN_N = int(os.environ.get("OFQ_TN_GROUP_MIN_N", "256"))
+TN_GROUP_MIN_S = int(os.environ.get("OFQ_TN_GROUP_MIN_S", "1"))
 
 
 def tn_tiles(M, N):
@@ -912,7 +917,7 @@ def tn_tiles(M, N):
 
 def tn_groupable(Ktok, M, N, S, lda, ldb):
     """May this dW problem join a grouped launch (ofq_qgemm_bf16s_tn_group)?"""
-    return (N >= 256 and N % 16 == 0 and M % 4 == 0 and S >= 1 and lda % 4 == 0 and ldb % 16 == 0
+    return (N >= TN_GROUP_MIN_N and N % 16 == 0 and M % 4 == 0 and S >= TN_GROUP_MIN_S and lda % 4 == 0 and ldb % 16 == 0
             and Ktok * lda < (1 << 31) and Ktok * ldb < (1 << 31))
 
 

@@ -763,13 +763,15 @@ def test_qgemm_bf16_split_weight_grad_tn(ops, shape):
     assert rel_err(dW.cpu(), dW2.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("cls", [3, 2, 128])
+@pytest.mark.parametrize("cls", [3, 2, 128, 192])
 def test_qgemm_tn_group_equals_single_launches(ops, cls):
     """ofq_qgemm_bf16s_tn_group (the deferred weight gradients of a block in one launch) == one ofq_qgemm_bf16s_tn call
     per job with the same split, bit for bit (same partials, same reduction order), dW and db; different token counts,
     step-vector lengths and leading dimensions per job, with and without the offset term."""
     shapes = ([(792, 384, 384), (792, 1536, 384), (594, 384, 1536), (1188, 2304, 384), (396, 128, 768)] if cls == 3 else
               [(792, 576, 192 + 64), (640, 192, 768 + 256), (500, 72, 272)])
+    if cls == 192:      # round 6: N in (128, 256) -- DeiT-T's q / k / v / proj / fc1 (N = 192) join grouped launches; the reduce then
+        shapes = [(792, 192, 192), (792, 768, 192), (500, 192, 144), (1188, 576, 192), (396, 192, 192 + 48)]     # walks three rows a block
     if cls == 128:      # one DeiT-S block of the headline step: 128 x 197 tokens, the five layers the engine queues together
         shapes = [(25216, 384, 1536), (25216, 1536, 384), (25216, 384, 384), (25216, 384, 384), (25216, 2304, 384)]
     rs = np.random.RandomState(6)

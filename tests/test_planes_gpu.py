@@ -146,7 +146,7 @@ def test_wide_dw_gemm_with_a_step_vector_shorter_than_a_k_tile(ops, S):
         db = dy.double().sum(0)
         ref = (dy.double() * ae[:, None]).t() @ codes.double() + db[:, None] * baft.double()[None, :]
         den = ((dy.double() * ae[:, None]).abs().t() @ codes.double().abs()) + 1e-30
-        assert ops.tn_groupable(Ktok, Mo, Nc, S, dy.stride(0), codes.stride(0))
+        assert ops.tn_groupable(Ktok, Mo, Nc, S, dy.stride(0), codes.stride(0)) == (Nc >= ops.TN_GROUP_MIN_N)
         for planes in (2, 3):
             for split in (1, 3, None):
                 dW, dbg = ops.qgemm_bf16s_tn(dy, codes, s, S, 0.01, None, baft, split=split, compute_db=True, planes=planes)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 6, on frozen kernel sources: evidence.sh (kernel stats, PMC passes, traffic JSON, bench lines), the whole GPU suite with -s (the
+# planes-at-size tables), and the shared-GPU repeat traces (two independent processes x 300, two ranks x 200)
 set -u
 O=gpurun_out/r06_final2; mkdir -p $O
 export TMPDIR=/tmp

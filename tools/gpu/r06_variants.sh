@@ -1,7 +1,8 @@
 #!/bin/bash
 # Which property of the attention prep's row-dot makes it fail on a shared GPU?  Variant libraries built with -DRD16_VARIANT=v
 # (csrc/qgemm_codes.hip): 3 = round 5's form (control), 2 = round 5's form + row pointers kept live, 1 = round 6's form without the
-# keep-alive, default library = round 6's form as shipped.
+# keep-alive, default library = round 6's form as shipped.  The RD16_VARIANT switch exists in commit a29d053 only (HEAD keeps the
+# shipped form): build the variant libraries from that commit's csrc into tools/probe/bin/ before running this.
 set -u
 O=gpurun_out/r06_variants; mkdir -p $O
 export TMPDIR=/tmp
