@@ -765,12 +765,16 @@ class QKVSplitLsqFn(torch.autograd.Function):
         B, N, C = ctx.shape
         dqkv = torch.empty_like(qkv2)
         db4s, res = [], []
-        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):
+        am = ops.amax_out(dqkv.device)       # ONE maximum word for the three column slices: the qkv projection's backward GEMMs
+        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):     # read dqkv whole
             dy = dy.contiguous()
-            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:])
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
             db4s.append(db4)
             res.append((ds, dbaft))
-        return (dqkv.view(B, N, 3 * C), torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+        out = dqkv.view(B, N, 3 * C)
+        if am is not None:
+            ops.tag_amax(out, am)
+        return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
 
@@ -802,12 +806,16 @@ class QKVSplitLsqCodesFn(torch.autograd.Function):
         B, N, C = ctx.shape
         dqkv = torch.empty_like(qkv2)
         db4s, res = [], []
-        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):
+        am = ops.amax_out(dqkv.device)       # ONE maximum word for the three column slices: the qkv projection's backward GEMMs
+        for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):     # read dqkv whole
             dy = dy.contiguous()
-            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:])
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
             db4s.append(db4)
             res.append((ds, dbaft))
-        return (dqkv.view(B, N, 3 * C), torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+        out = dqkv.view(B, N, 3 * C)
+        if am is not None:
+            ops.tag_amax(out, am)
+        return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
 

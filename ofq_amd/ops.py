@@ -262,7 +262,9 @@ def lsq_fwd(x, s, b4, baft, g, y=None, want_codes=False, need_values=True):
     return y, codes
 
 
-def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
+def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True, amax_word=None):
+    """amax_word: raise THIS maximum word instead of a fresh one (the kernels raise it with an atomic max, so several launches that
+    write column slices of one tensor can share the word of the whole tensor; the caller tags the tensor itself)."""
     _dev(gy, "grad")
     dev = x.device
     if dx is None:
@@ -273,11 +275,11 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True):
     dbaft = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
     nbytes = lib().ofq_lsq_bwd_ws_bytes(g.outer, g.S, g.inner, g.bias_len, g.mode)
     ws = workspace(nbytes, dev)
-    am = amax_out(dev)
+    am = amax_word if amax_word is not None else amax_out(dev)
     _chk(lib().ofq_lsq_bwd(gy.data_ptr(), x.data_ptr(), s.data_ptr(), _p(b4), dx.data_ptr(), ds.data_ptr(), _p(db4),
                            _p(dbaft), g.outer, g.S, g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale,
                            g.prologue, ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_lsq_bwd")
-    if am is not None:
+    if am is not None and amax_word is None:
         tag_amax(dx, am)
     return dx, ds, db4, dbaft
 

@@ -217,6 +217,16 @@ def test_absmax_kernel_and_producer_by_products(ops):
     geom = ops.LsqGeom(4, 198, C, C, 0, -2, 1, 4 * C)
     dxl, _, _, _ = ops.lsq_bwd(dy, xx, s, torch.zeros(C, device="cuda"), geom)
     assert _word(ops.amax_of(dxl)) == float(dxl.abs().max())
+    # three launches writing column slices of ONE tensor share its word (plain attention: dq | dk | dv -> the qkv projection)
+    wide = torch.full((R, 3 * C), float("nan"), device="cuda")
+    am = ops.amax_out(wide.device)
+    if am is not None:
+        x3 = torch.randn(R, 3 * C, device="cuda", generator=g)
+        for i, scale in enumerate((1e-3, 7.0, 1e-5)):
+            ops.lsq_bwd(dy * scale, x3[:, i * C:], s, torch.zeros(C, device="cuda"),
+                        ops.LsqGeom(4, 198, C, C, 0, -2, 1, 4 * C, ldx=3 * C, ldy=C), dx=wide[:, i * C:], amax_word=am)
+        assert not bool(torch.isnan(wide).any())
+        assert _word(am) == float(wide.abs().max()) and ops.amax_of(wide[:, C:]) is None     # (the slices are not tagged)
     # softmax-LSQ backward (in place) and the fused dP + softmax backward
     B, H, N, d, Np = 2, 3, 198, 64, 208
     prob = torch.softmax(torch.randn(B, H, N, Np, device="cuda", generator=g), -1)

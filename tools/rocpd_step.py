@@ -10,7 +10,7 @@ import sys
 
 OWN = ("absmax_", "adamw_", "assemble_tokens", "attn_f32", "cga_", "codes_transpose", "colsum_", "gelu_fwd", "gemm_bf16x3x3", "gemm_f32",
        "gemm_splitk", "input_pipeline", "kd_loss", "layernorm_", "lsq_", "nt_sk_", "permute_tokens", "qattn_", "qgemm_", "rowdot_",
-       "softmax_lsq", "split_f32", "statsq_", "store_f32", "strided_sum")      # every __global__ of ofq_amd/csrc
+       "softmax_lsq", "split_f32", "statsq_", "step_guard", "store_f32", "strided_sum")      # every __global__ of ofq_amd/csrc
 
 
 def family(name):
