@@ -1192,7 +1192,7 @@ def norm_quant(norm, spec, x, res=None):
     Returns (x [+ res], (x_hat carrier, codes, geom)) or None when the fused kernel does not apply."""
     qz = spec["quant"]
     C = x.shape[-1]
-    if not (isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and
+    if not (isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and
             len(norm.normalized_shape) == 1 and C % 4 == 0 and C <= 2048 and qz.initialized_alpha and qz.s is not None):
         return None
     geom = qz._geom(tuple(x.shape), spec["b4"].numel(), 0, None, None)

@@ -6,15 +6,23 @@ The window attention is the DeiT attention core run on (B*num_windows, 49, C) wi
 arithmetic — relative-position bias and the shifted-window mask added to the scaled scores before the softmax
 (:201-221) — is one additive tensor handed to the fused softmax+LSQ kernel (`addend` of ofq_softmax_lsq_fwd).
 Pad / roll / window partition and their inverses are data movement on the host (torch views and copies)."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .qbias import LearnableBias
 from .qlinear import QLinear, LSQ_input
+from . import qlinear as _ql
 from .attention import _qlinear_kwargs, plain_attention_core, qkr_attention_core
 from ..quantizer.lsq import LsqQuantizer, LsqQuantizer4v
 from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkreparam_cga
 from ...swin import ShiftedWindowAttention, WindowGeometry, MLP as swin_MLP, relative_position_index
+
+
+# round 6: the Swin MLP takes the fusions the DeiT MLP has had since round 2 (norm2 + fc1's input quantiser in one kernel each way,
+# GELU + fc2's input quantiser in fc1's GEMM epilogue); OFQ_NO_SWIN_MLP_FUSE=1 is the A/B switch
+SWIN_MLP_FUSE = os.environ.get("OFQ_NO_SWIN_MLP_FUSE") is None
 
 
 class QMLP_swin(torch.nn.Module):
@@ -41,8 +49,19 @@ class QMLP_swin(torch.nn.Module):
             and self.drop1.p == 0
         self.fc2._prologue = 1 if self._fuse_gelu else 0
 
-    def forward(self, x):
-        x = self.fc1(x)
+    def fused_input_quant(self, in_shape):
+        """fc1's input quantiser for a producer that can apply it itself (LayerNorm + LSQ in one kernel: SwinTransformerBlock
+        .forward_fused); the 4-D geometry is the kernels' [outer = B * Hf][S = Wf][inner = C] view like any other."""
+        return self.fc1.fused_input_quant(in_shape) if SWIN_MLP_FUSE else None
+
+    def forward(self, x, pre_quant=None):
+        if SWIN_MLP_FUSE and _ql.FUSE_NEXT_CODES and _ql.FUSE_NEXT_CODES_MLP and self._fuse_gelu and self.fc1.code_path():
+            # as QMLP.forward (qlinear.py): fc1's GEMM epilogue applies GELU + fc2's offset and LSQ and emits fc2's input codes,
+            # so the fp32 activation is written once (for the backward) and never re-read by a quantiser launch
+            spec = self.fc2.input_fuse_spec(tuple(x.shape[:-1]) + (self.fc1.out_features,))
+            h = self.fc1(x, fuse_next=spec, pre_quant=pre_quant)
+            return self.drop2(self.fc2(h, pre_codes=None if spec is None else spec.get("codes_out"), fused=spec))
+        x = self.fc1(x, pre_quant=pre_quant)
         if not self._fuse_gelu:
             x = self.drop1(self.act(x))
         return self.drop2(self.fc2(x))

@@ -3,6 +3,7 @@ SwinTransformerBlock :255, SwinTransformer :330, swin_t :512) with the same modu
 (`features.0.0` = 4x4 patch conv, `features.{1,3,5,7}.{i}.{norm1,attn,norm2,mlp}`, `features.{2,4,6}.{reduction,norm}`),
 so the reference's `qmodules` name lists and checkpoints carry over.  torchvision is not a dependency: `MLP` and
 `Permute` are the few lines needed from it.  Blocks pass `(features, attn_info)` tuples like the reference."""
+import os
 from functools import partial
 from typing import List
 
@@ -36,6 +37,7 @@ class Permute(nn.Module):
 
 
 _MERGE_PERM = {}
+_SWIN_FUSE = os.environ.get("OFQ_NO_SWIN_MLP_FUSE") is None      # A/B switch of round 6's LayerNorm + quantiser fusions in Swin
 
 
 class PatchMerging(nn.Module):
@@ -69,6 +71,13 @@ class PatchMerging(nn.Module):
         else:
             fx = F.pad(fx, (0, 0, 0, W % 2, 0, H % 2))
             fx = self._gather4(fx)
+        # norm -> the reduction's input quantiser in one kernel each way when the reduction is a QLinear that offers it
+        red = self.reduction
+        spec = red.fused_input_quant(tuple(fx.shape)) if _SWIN_FUSE and hasattr(red, "fused_input_quant") else None
+        fused = F_ofq.norm_quant(self.norm, spec, fx) if spec is not None else None
+        if fused is not None:
+            _, pre = fused
+            return red(pre[0], pre_quant=pre), info
         return self.reduction(F_ofq.layer_norm(self.norm, fx)), info
 
 
@@ -307,6 +316,12 @@ class SwinTransformerBlock(nn.Module):
         else:
             xin, n1 = F_ofq.add_layer_norm(self.norm1, x, pending)
         y, info = self.attn(n1)
+        # norm2 -> the input quantiser of its only consumer (the MLP's fc1) in one kernel when the MLP offers it (QMLP_swin)
+        spec = self.mlp.fused_input_quant(tuple(xin.shape)) if _SWIN_FUSE and hasattr(self.mlp, "fused_input_quant") else None
+        fused = F_ofq.norm_quant(self.norm2, spec, xin, y) if spec is not None else None
+        if fused is not None:
+            x, pre = fused
+            return x, info, self.mlp(pre[0], pre_quant=pre)
         x, n2 = F_ofq.add_layer_norm(self.norm2, xin, y)
         return x, info, self.mlp(n2)
 
