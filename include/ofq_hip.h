@@ -411,6 +411,22 @@ int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, co
                           const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale, const float* b4,
                           int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds, float* dbaft,
                           int64_t rows, int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
+/*  Round 6: the same pair with token permutations folded in -- Swin's LayerNorm -> shifted-window partition -> input quantiser
+ *  (swin_attention_and_mlp.py:312-323, swin.py:103-131) and the window reverse in front of the residual add (swin.py:160-170),
+ *  which the reference runs as roll / view / permute copies.  The R rows are images of perm_n tokens (R % perm_n == 0,
+ *  perm_n % S == 0).  q_perm[t]: the row, inside its image, of token t's QUANTISED form -- its codes, the gradient gq of the
+ *  quantised values, the step index (row % S) and the step-gradient partial all live there (window-major order); res_perm[t]:
+ *  the row of token t in the forward's `res` operand and in the backward's dres_out (a second copy of dx's rows: the gradient of
+ *  `res` in its producer's order).  Either permutation may be NULL (identity); x, xsum, mean, rstd, dres, dx: token order. */
+int ofq_layernorm_lsq_fwd_perm(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* xsum,
+                               float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S, float gscale,
+                               const float* b4, int lo, int hi, int64_t rows, int64_t cols, int64_t ldx, float eps,
+                               const int* q_perm, const int* res_perm, int64_t perm_n, ofq_stream_t stream);
+int ofq_layernorm_lsq_bwd_perm(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale, const float* b4,
+                               int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds, float* dbaft,
+                               int64_t rows, int64_t cols, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes, void* amax_out,
+                               const int* q_perm, const int* res_perm, int64_t perm_n, float* dres_out, ofq_stream_t stream);
 
 /* ---- AdamW over many tensors in one launch (train.py:662, :933: timm create_optimizer_v2 -> torch.optim.AdamW), with
  *  the CGA freeze folded in (cga.py:962-964, :994-997): where frozen[i] != 0 the gradient is masked before the moment

@@ -104,6 +104,10 @@ SIGNATURES = {
     "ofq_layernorm_lsq_bwd_ws_bytes": (sz, [i64, i64]),
     "ofq_layernorm_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64,
                                     i64, i64, vp, sz, vp, vp]),
+    "ofq_layernorm_lsq_fwd_perm": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, i64, i64, i64, f32,
+                                         vp, vp, i64, vp]),
+    "ofq_layernorm_lsq_bwd_perm": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64,
+                                         i64, i64, vp, sz, vp, vp, vp, i64, vp, vp]),
     "ofq_adamw_tensor_entry_bytes": (i64, []),
     "ofq_adamw_multi": (i32, [vp, i64, f32, f64, f64, f32, f32, f64, f64, vp]),
     "ofq_adamw_hyper_pack": (i32, [vp, f32, f64, f64, f32, f32, f64, f64]),

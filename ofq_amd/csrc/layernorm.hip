@@ -28,7 +28,20 @@ struct LnArgs {
   const float* qs; const float* qb4; int8_t* qcodes; float* rowpart;
   int64_t qS;
   float qgscale, qlo, qhi;
+  // token permutations (Swin's shifted-window partition / reverse folded into this pass; the rows come in images of permN):
+  //   qperm[t]: where the QUANTISED row of token t lives inside its image -- codes, their gradient dy, the step index and the
+  //             step-gradient partial all use row b * permN + qperm[t] (the window-major order the attention works in);
+  //   rperm[t]: where token t's row of `res` lives (forward), and where its row of dx is written a second time (dx2, backward:
+  //             the gradient of `res`, for a producer that works in that order).  NULL: the identity.
+  const int* qperm; const int* rperm; float* dx2;
+  int permN;
 };
+
+__device__ __forceinline__ int64_t ln_perm_row(int64_t r, const int* perm, int n) {
+  if (perm == nullptr) return r;
+  const int64_t t = r % n;
+  return r - t + perm[t];
+}
 
 template <int TXW>
 __device__ __forceinline__ float ln_row_sum(float v) {
@@ -78,14 +91,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   float4 xn[J], sn[J];          // x (and res / dy) of the next row
   float4 dn[J];
   auto issue = [&](int64_t rr) {
+    const int64_t rres = (!BWD && a.res) ? ln_perm_row(rr, a.rperm, a.permN) : rr;
+    const int64_t rqd = (BWD && Q) ? ln_perm_row(rr, a.qperm, a.permN) : rr;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       if (cok[j]) {
         const int64_t col = (tx + (int64_t)j * TXW) * 4;
         xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + col);
-        if (!BWD && a.res) sn[j] = *reinterpret_cast<const float4*>(a.res + rr * a.ldx + col);
+        if (!BWD && a.res) sn[j] = *reinterpret_cast<const float4*>(a.res + rres * a.ldx + col);
         if (BWD) {
-          sn[j] = *reinterpret_cast<const float4*>(a.dy + rr * a.ldy + col);
+          sn[j] = *reinterpret_cast<const float4*>(a.dy + rqd * a.ldy + col);
           if (a.dres) dn[j] = *reinterpret_cast<const float4*>(a.dres + rr * a.ldx + col);
         }
       }
@@ -127,8 +142,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       const float var = ln_row_sum<TXW>(s2) * invC;
       rs = 1.0f / sqrtf(var + a.eps);
       float q_al = 1.f, q_ra = 1.f;
+      const int64_t rq = Q ? ln_perm_row(r, a.qperm, a.permN) : r;
       if (Q) {
-        q_al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+        q_al = ofq_lsq_eff_scale(a.qs[rq % a.qS], a.qgscale);
         q_ra = ofq_div(1.0f, q_al);                       // correctly rounded reciprocal of the row's step
       }
 #pragma unroll
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
             q2 = ofq_lsq_level_exact(xe[2], q_al, a.qlo, a.qhi);
             q3 = ofq_lsq_level_exact(xe[3], q_al, a.qlo, a.qhi);
           }
-          *reinterpret_cast<char4*>(a.qcodes + r * a.C + col) =
+          *reinterpret_cast<char4*>(a.qcodes + rq * a.C + col) =
               make_char4((signed char)(int)q0, (signed char)(int)q1, (signed char)(int)q2, (signed char)(int)q3);
         }
       }
@@ -171,7 +187,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       float4 xh[J], g[J];
       float sa = 0.f, sb = 0.f;
       if (Q) {       // sv holds the gradient of the quantised tensor: turn it into the gradient of n = LN(xs)
-        const float al = ofq_lsq_eff_scale(a.qs[r % a.qS], a.qgscale);
+        const int64_t rq = ln_perm_row(r, a.qperm, a.permN);
+        const float al = ofq_lsq_eff_scale(a.qs[rq % a.qS], a.qgscale);
         const float ral = ofq_div(1.0f, al);
         float rds = 0.f;
 #pragma unroll
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           sv[j] = make_float4(dq[0], dq[1], dq[2], dq[3]);
         }
         rds = ln_row_sum<TXW>(rds);
-        if (tx == 0) a.rowpart[r] = rds;
+        if (tx == 0) a.rowpart[rq] = rds;
       }
 #pragma unroll
       for (int j = 0; j < J; ++j) {
@@ -223,6 +240,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         o.w = rs * (g[j].w - ma - xh[j].w * mb);
         if (a.dres) { o.x += dv[j].x; o.y += dv[j].y; o.z += dv[j].z; o.w += dv[j].w; }
         *reinterpret_cast<float4*>(a.dx + r * a.ldx + col) = o;
+        if (a.dx2) *reinterpret_cast<float4*>(a.dx2 + ln_perm_row(r, a.rperm, a.permN) * a.ldx + col) = o;
         dxmax = ofq_absmax4(dxmax, o.x, o.y, o.z, o.w);
       }
     }
@@ -344,12 +362,14 @@ extern "C" int ofq_layernorm_bwd(const float* dy, const float* x, const float* m
 
 // ---- LayerNorm fused with the per-token LSQ that consumes its output (Block.norm1 -> attention input quantiser,
 // Block.norm2 -> fc1's input quantiser: deit_vision_transformer.py:154-164 + qlinear.py:66-68 / attention.py:177)
-extern "C" int ofq_layernorm_lsq_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                                     float* xsum, float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S,
-                                     float gscale, const float* b4, int lo, int hi, int64_t R, int64_t C, int64_t ldx,
-                                     float eps, ofq_stream_t stream) {
+static int ln_lsq_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                      float* xsum, float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S,
+                      float gscale, const float* b4, int lo, int hi, int64_t R, int64_t C, int64_t ldx,
+                      float eps, const int* q_perm, const int* res_perm, int64_t perm_n, ofq_stream_t stream) {
   if (!x || !mean || !rstd || !codes || !lsq_s || S <= 0 || (res && !xsum)) return OFQ_EINVAL;
   if (ldx < C || (ldx & 3)) return OFQ_EINVAL;
+  if ((q_perm || res_perm) && (perm_n <= 0 || perm_n >= (1ll << 31) || R % perm_n)) return OFQ_EINVAL;
+  if (q_perm && perm_n % S) return OFQ_EINVAL;             // the step index is (row within the image) % S
   LnGeom g;
   int rc = ln_geom(R, C, &g);
   if (rc) return rc;
@@ -357,7 +377,27 @@ extern "C" int ofq_layernorm_lsq_fwd(const float* x, const float* res, const flo
   a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.xs = xsum; a.mean = mean; a.rstd = rstd;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = C; a.TX = g.TX; a.TY = 256 / g.TX; a.eps = eps;
   a.qs = lsq_s; a.qS = S; a.qgscale = gscale; a.qb4 = b4; a.qlo = (float)lo; a.qhi = (float)hi; a.qcodes = codes;
+  a.qperm = q_perm; a.rperm = res ? res_perm : nullptr; a.permN = (int)perm_n;
   return ln_launch<false, true>(g, a, (hipStream_t)stream);
+}
+extern "C" int ofq_layernorm_lsq_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                     float* xsum, float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S,
+                                     float gscale, const float* b4, int lo, int hi, int64_t R, int64_t C, int64_t ldx,
+                                     float eps, ofq_stream_t stream) {
+  return ln_lsq_fwd(x, res, gamma, beta, y, xsum, mean, rstd, codes, lsq_s, S, gscale, b4, lo, hi, R, C, ldx, eps, nullptr, nullptr,
+                    0, stream);
+}
+// The same with token permutations folded in (Swin: LayerNorm -> shifted-window partition -> input quantiser, and the window
+// reverse in front of the residual add, swin_attention_and_mlp.py:312-323 / swin.py:160-170).  The R rows are images of perm_n
+// tokens; q_perm[t] = row (within its image) of token t's codes, the step being lsq_s[that row % S]; res_perm[t] = row of token
+// t in `res`; either may be NULL (identity).  xsum / mean / rstd stay in token order.
+extern "C" int ofq_layernorm_lsq_fwd_perm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                          float* xsum, float* mean, float* rstd, int8_t* codes, const float* lsq_s, int64_t S,
+                                          float gscale, const float* b4, int lo, int hi, int64_t R, int64_t C, int64_t ldx,
+                                          float eps, const int* q_perm, const int* res_perm, int64_t perm_n, ofq_stream_t stream) {
+  if (y && q_perm) return OFQ_EINVAL;         // (the un-quantised LayerNorm output is written in token order only)
+  return ln_lsq_fwd(x, res, gamma, beta, y, xsum, mean, rstd, codes, lsq_s, S, gscale, b4, lo, hi, R, C, ldx, eps, q_perm, res_perm,
+                    perm_n, stream);
 }
 
 extern "C" size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t R, int64_t C) {
@@ -366,13 +406,16 @@ extern "C" size_t ofq_layernorm_lsq_bwd_ws_bytes(int64_t R, int64_t C) {
   return ((size_t)g.gx * 3 * C + (size_t)R) * sizeof(float);
 }
 
-extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                     const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
-                                     const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds,
-                                     float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
-                                     void* amax_out, ofq_stream_t stream) {
+static int ln_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
+                      const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds,
+                      float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
+                      void* amax_out, const int* q_perm, const int* res_perm, int64_t perm_n, float* dres_out,
+                      ofq_stream_t stream) {
   if (!gq || !x || !mean || !rstd || !dx || !ws || !lsq_s || S <= 0 || R % S) return OFQ_EINVAL;
   if (ldx < C || ldg < C || (ldx & 3) || (ldg & 3)) return OFQ_EINVAL;
+  if ((q_perm || res_perm) && (perm_n <= 0 || perm_n >= (1ll << 31) || R % perm_n)) return OFQ_EINVAL;
+  if (q_perm && perm_n % S) return OFQ_EINVAL;             // the step index is (row within the image) % S
   LnGeom g;
   int rc = ln_geom(R, C, &g);
   if (rc) return rc;
@@ -382,6 +425,7 @@ extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const floa
   a.colpart = (float*)ws; a.rowpart = (float*)ws + (size_t)g.gx * 3 * C; a.amax = (unsigned*)amax_out;
   a.R = R; a.C = C; a.ldx = ldx; a.ldy = ldg; a.TX = g.TX; a.TY = 256 / g.TX;
   a.qs = lsq_s; a.qS = S; a.qgscale = gscale; a.qb4 = b4; a.qlo = (float)lo; a.qhi = (float)hi;
+  a.qperm = q_perm; a.rperm = res_perm; a.dx2 = dres_out; a.permN = (int)perm_n;
   hipStream_t st = (hipStream_t)stream;
   rc = ln_launch<true, true>(g, a, st);
   if (rc) return rc;
@@ -400,4 +444,25 @@ extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const floa
     OFQ_LAUNCH_CHECK();
   }
   return 0;
+}
+extern "C" int ofq_layernorm_lsq_bwd(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
+                                     const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4, float* ds,
+                                     float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws, size_t ws_bytes,
+                                     void* amax_out, ofq_stream_t stream) {
+  return ln_lsq_bwd(gq, x, mean, rstd, gamma, beta, dres, lsq_s, S, gscale, b4, lo, hi, dx, dgamma, dbeta, db4, ds, dbaft, R, C, ldx,
+                    ldg, ws, ws_bytes, amax_out, nullptr, nullptr, 0, nullptr, stream);
+}
+// Backward of ofq_layernorm_lsq_fwd_perm: gq (and the step-gradient partials) are read / indexed at row q_perm[t] of their image;
+// dres_out (optional, with res_perm): the rows of dx once more, token t at row res_perm[t] -- the gradient of the forward's
+// permuted `res` operand, in the order its producer works in.  dx itself, dres, mean, rstd, x: token order.
+extern "C" int ofq_layernorm_lsq_bwd_perm(const float* gq, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, const float* dres, const float* lsq_s, int64_t S, float gscale,
+                                          const float* b4, int lo, int hi, float* dx, float* dgamma, float* dbeta, float* db4,
+                                          float* ds, float* dbaft, int64_t R, int64_t C, int64_t ldx, int64_t ldg, void* ws,
+                                          size_t ws_bytes, void* amax_out, const int* q_perm, const int* res_perm, int64_t perm_n,
+                                          float* dres_out, ofq_stream_t stream) {
+  if (dres_out && !res_perm) return OFQ_EINVAL;
+  return ln_lsq_bwd(gq, x, mean, rstd, gamma, beta, dres, lsq_s, S, gscale, b4, lo, hi, dx, dgamma, dbeta, db4, ds, dbaft, R, C, ldx,
+                    ldg, ws, ws_bytes, amax_out, q_perm, dres_out ? res_perm : nullptr, perm_n, dres_out, stream);
 }

@@ -771,9 +771,9 @@ class QKVSplitLsqFn(torch.autograd.Function):
             _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
             db4s.append(db4)
             res.append((ds, dbaft))
-        out = dqkv.view(B, N, 3 * C)
         if am is not None:
-            ops.tag_amax(out, am)
+            ops.tag_amax(dqkv, am)           # (on the BASE: a consumer's reshape is a view of dqkv, and amax_of looks at t and t._base)
+        out = dqkv.view(B, N, 3 * C)
         return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
@@ -812,9 +812,9 @@ class QKVSplitLsqCodesFn(torch.autograd.Function):
             _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
             db4s.append(db4)
             res.append((ds, dbaft))
-        out = dqkv.view(B, N, 3 * C)
         if am is not None:
-            ops.tag_amax(out, am)
+            ops.tag_amax(dqkv, am)           # (on the BASE: a consumer's reshape is a view of dqkv, and amax_of looks at t and t._base)
+        out = dqkv.view(B, N, 3 * C)
         return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
@@ -1155,50 +1155,74 @@ class NormQuantFn(torch.autograd.Function):
     from (xs, mean, rstd) and runs the quantiser's backward in front of the LayerNorm backward."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, eps, s, b4, baft, geom):
+    def forward(ctx, x, res, weight, bias, eps, s, b4, baft, geom, q_perm=None, res_perm=None, qshape=None):
+        """q_perm / res_perm / qshape (round 6, Swin): the quantised form leaves in the token order q_perm describes (shape qshape:
+        windows x window tokens x C), and `res` arrives in the order res_perm describes (its own shape) -- the shifted-window
+        partition and reverse ride in this pass; x and the first output (x + res) stay in x's order."""
         shp = x.shape
         C = shp[-1]
         x2d = x.reshape(-1, C).contiguous()
         r2d = None if res is None else res.reshape(-1, C).contiguous()
-        codes, xs, mean, rstd = ops.layernorm_lsq_fwd(x2d, weight, bias, eps, s, b4, geom, res2d=r2d)
+        if res is None:
+            res_perm = None
+        codes, xs, mean, rstd = ops.layernorm_lsq_fwd(x2d, weight, bias, eps, s, b4, geom, res2d=r2d, q_perm=q_perm, res_perm=res_perm)
         xin = xs if xs is not None else x2d
-        ctx.save_for_backward(xin, mean, rstd, weight, bias, s, b4)
+        ctx.save_for_backward(xin, mean, rstd, weight, bias, s, b4, q_perm, res_perm)
         ctx.geom, ctx.shape, ctx.has_res = geom, shp, res is not None
+        ctx.res_shape = None if res is None else res.shape
         ctx.sum_leaves = (weight, bias, s, b4, baft)
         ctx.mark_non_differentiable(codes)
         ctx.set_materialize_grads(False)
         first = xs.view(shp) if xs is not None else ops.placeholder(shp, x.device)
-        return first, ops.placeholder(shp, x.device), codes
+        return first, ops.placeholder(tuple(qshape) if qshape is not None else shp, x.device), codes
 
     @staticmethod
     def backward(ctx, dxs, dxq, _gc):
-        xin, mean, rstd, weight, bias, s, b4 = ctx.saved_tensors
+        xin, mean, rstd, weight, bias, s, b4, q_perm, res_perm = ctx.saved_tensors
         shp = ctx.shape
         C = shp[-1]
         if not ctx.has_res:
             dxs = None
         if dxq is None:
-            return dxs, dxs, None, None, None, None, None, None, None
+            if dxs is not None and res_perm is not None:
+                raise RuntimeError("ofq_amd NormQuantFn: a permuted residual operand needs the quantised output's gradient")
+            return dxs, dxs, None, None, None, None, None, None, None, None, None, None
         gq = dxq.reshape(-1, C).contiguous()
         dres = None if dxs is None else dxs.reshape(-1, C).contiguous()
         with sum_scope(*ctx.sum_leaves):
-            dx, dg, db, db4, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
+            if q_perm is None and res_perm is None:
+                dx, dg, db, db4, ds, dba = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom, dres2d=dres)
+                dx2 = dx
+            else:
+                dx, dg, db, db4, ds, dba, dx2 = ops.layernorm_lsq_bwd(gq, xin, mean, rstd, weight, bias, s, b4, ctx.geom,
+                                                                      dres2d=dres, q_perm=q_perm,
+                                                                      res_perm=res_perm if ctx.has_res else None)
+                if dx2 is None:
+                    dx2 = dx
         dx = dx.view(shp)
-        return (dx, dx if ctx.has_res else None, dg, (db if bias is not None else None), None, ds, db4, dba, None)
+        dres_out = None
+        if ctx.has_res:
+            dres_out = dx if dx2 is dx or dx2.data_ptr() == dx.data_ptr() else dx2.view(ctx.res_shape)
+        return (dx, dres_out, dg, (db if bias is not None else None), None, ds, db4, dba, None, None, None, None)
 
 
-def norm_quant(norm, spec, x, res=None):
+def norm_quant(norm, spec, x, res=None, q_perm=None, res_perm=None, qshape=None):
     """spec: {"quant": LsqQuantizer, "b4": Parameter, "baft": Parameter} of the only consumer of norm(x [+ res]).
-    Returns (x [+ res], (x_hat carrier, codes, geom)) or None when the fused kernel does not apply."""
+    Returns (x [+ res], (x_hat carrier, codes, geom)) or None when the fused kernel does not apply.
+    q_perm / qshape: the consumer sees the tokens of every image permuted (token t at row q_perm[t]) in the shape qshape, and its
+    quantiser's geometry is qshape's; res_perm: `res` is given in such an order (NormQuantFn)."""
     qz = spec["quant"]
     C = x.shape[-1]
     if not (isinstance(norm, torch.nn.LayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.dim() in (3, 4) and
             len(norm.normalized_shape) == 1 and C % 4 == 0 and C <= 2048 and qz.initialized_alpha and qz.s is not None):
         return None
-    geom = qz._geom(tuple(x.shape), spec["b4"].numel(), 0, None, None)
+    geom = qz._geom(tuple(qshape) if qshape is not None else tuple(x.shape), spec["b4"].numel(), 0, None, None)
     if geom.mode != 0 or geom.bias_len != geom.inner or geom.lo < -128 or geom.hi > 127:
         return None
-    xs, xq, codes = NormQuantFn.apply(x, res, norm.weight, norm.bias, norm.eps, qz.s, spec["b4"], spec["baft"], geom)
+    if q_perm is not None and q_perm.numel() % geom.S:
+        return None
+    xs, xq, codes = NormQuantFn.apply(x, res, norm.weight, norm.bias, norm.eps, qz.s, spec["b4"], spec["baft"], geom,
+                                      q_perm, res_perm, qshape)
     return (xs if res is not None else x), (xq, codes, geom)
 
 

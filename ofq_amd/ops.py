@@ -1221,8 +1221,10 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres2d=None, want_affine_grads=T
     return dx, dg, db
 
 
-def layernorm_lsq_fwd(x2d, gamma, beta, eps, s, b4, g, res2d=None):
-    """codes = LSQ(LN(x [+ res]) + b4) without materialising the LayerNorm output; returns (codes, xsum|None, mean, rstd)."""
+def layernorm_lsq_fwd(x2d, gamma, beta, eps, s, b4, g, res2d=None, q_perm=None, res_perm=None):
+    """codes = LSQ(LN(x [+ res]) + b4) without materialising the LayerNorm output; returns (codes, xsum|None, mean, rstd).
+    q_perm / res_perm (int32, one image's tokens): ofq_layernorm_lsq_fwd_perm -- token t's codes go to row q_perm[t] of its image
+    (the quantiser's step is indexed there), token t's `res` row is read from row res_perm[t]."""
     _dev(x2d, "x")
     rows, cols = x2d.shape
     dev = x2d.device
@@ -1230,14 +1232,23 @@ def layernorm_lsq_fwd(x2d, gamma, beta, eps, s, b4, g, res2d=None):
     mean = torch.empty(rows, dtype=torch.float32, device=dev)
     rstd = torch.empty(rows, dtype=torch.float32, device=dev)
     codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+    if q_perm is not None or res_perm is not None:
+        n = (q_perm if q_perm is not None else res_perm).numel()
+        _chk(lib().ofq_layernorm_lsq_fwd_perm(x2d.data_ptr(), _p(res2d), _p(gamma), _p(beta), 0, _p(xsum), mean.data_ptr(),
+                                              rstd.data_ptr(), codes.data_ptr(), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi,
+                                              rows, cols, x2d.stride(0), float(eps), _p(q_perm), _p(res_perm), n, _stream()),
+             "ofq_layernorm_lsq_fwd_perm")
+        return codes, xsum, mean, rstd
     _chk(lib().ofq_layernorm_lsq_fwd(x2d.data_ptr(), _p(res2d), _p(gamma), _p(beta), 0, _p(xsum), mean.data_ptr(),
                                      rstd.data_ptr(), codes.data_ptr(), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, rows,
                                      cols, x2d.stride(0), float(eps), _stream()), "ofq_layernorm_lsq_fwd")
     return codes, xsum, mean, rstd
 
 
-def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None):
-    """returns (dx [+ dres], dgamma, dbeta, db4 (same values as dbeta, its own tensor; None without b4), ds, dbaft)"""
+def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None, q_perm=None, res_perm=None):
+    """returns (dx [+ dres], dgamma, dbeta, db4 (same values as dbeta, its own tensor; None without b4), ds, dbaft)
+    q_perm: gq2d's rows (and the step index) are in the permuted order of layernorm_lsq_fwd(q_perm=...); res_perm: a seventh
+    result, dx's rows once more in the order of the forward's permuted `res` operand (its gradient)."""
     rows, cols = x2d.shape
     dev = x2d.device
     dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
@@ -1248,6 +1259,19 @@ def layernorm_lsq_bwd(gq2d, x2d, mean, rstd, gamma, beta, s, b4, g, dres2d=None)
     ds = torch.empty_like(s)
     ws = workspace(lib().ofq_layernorm_lsq_bwd_ws_bytes(rows, cols), dev)
     am = amax_out(dev)
+    if q_perm is not None or res_perm is not None:
+        n = (q_perm if q_perm is not None else res_perm).numel()
+        dx2 = torch.empty((rows, cols), dtype=torch.float32, device=dev) if res_perm is not None else None
+        _chk(lib().ofq_layernorm_lsq_bwd_perm(gq2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma),
+                                              _p(beta), _p(dres2d), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, dx.data_ptr(),
+                                              _p(dg), db.data_ptr(), _p(db4), ds.data_ptr(), dba.data_ptr(), rows, cols,
+                                              x2d.stride(0), gq2d.stride(0), ws.data_ptr(), ws.numel(), _p(am), _p(q_perm),
+                                              _p(res_perm), n, _p(dx2), _stream()), "ofq_layernorm_lsq_bwd_perm")
+        if am is not None:
+            tag_amax(dx, am)
+            if dx2 is not None:
+                tag_amax(dx2, am)          # (the same rows in another order: the same maximum)
+        return dx, dg, db, db4, ds, dba, dx2
     _chk(lib().ofq_layernorm_lsq_bwd(gq2d.data_ptr(), x2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                      _p(dres2d), s.data_ptr(), g.S, g.gscale, _p(b4), g.lo, g.hi, dx.data_ptr(), _p(dg),
                                      db.data_ptr(), _p(db4), ds.data_ptr(), dba.data_ptr(), rows, cols, x2d.stride(0),

@@ -14,7 +14,7 @@ import torch.nn as nn
 from .qbias import LearnableBias
 from .qlinear import QLinear, LSQ_input
 from . import qlinear as _ql
-from .attention import _qlinear_kwargs, plain_attention_core, qkr_attention_core
+from .attention import _qlinear_kwargs, plain_attention_core, qkr_attention_core, _attn_codes_ok
 from ..quantizer.lsq import LsqQuantizer, LsqQuantizer4v
 from ..quantizer.statsq import StatsQuantizer, StatsQuantizer_specific_4_qkreparam_cga
 from ...swin import ShiftedWindowAttention, WindowGeometry, MLP as swin_MLP, relative_position_index
@@ -23,6 +23,9 @@ from ...swin import ShiftedWindowAttention, WindowGeometry, MLP as swin_MLP, rel
 # round 6: the Swin MLP takes the fusions the DeiT MLP has had since round 2 (norm2 + fc1's input quantiser in one kernel each way,
 # GELU + fc2's input quantiser in fc1's GEMM epilogue); OFQ_NO_SWIN_MLP_FUSE=1 is the A/B switch
 SWIN_MLP_FUSE = os.environ.get("OFQ_NO_SWIN_MLP_FUSE") is None
+# ... and the shifted-window partition / reverse ride in the LayerNorm passes around the attention (norm1 + partition + the attention's
+# input quantiser in one kernel each way; the window-major proj output read by norm2's pass): OFQ_NO_SWIN_ATTN_FUSE=1 switches it off
+SWIN_ATTN_FUSE = os.environ.get("OFQ_NO_SWIN_ATTN_FUSE") is None
 
 
 class QMLP_swin(torch.nn.Module):
@@ -92,6 +95,33 @@ class _SwinQBase(ShiftedWindowAttention):
         out = core(self, xw, (self.dim // self.num_heads) ** -0.5, add)
         return g.reverse(self.proj(out)), None
 
+    # ---- round 6: partition and reverse folded into the LayerNorm passes around the attention (SwinTransformerBlock.forward_fused)
+    def _input_spec(self, win_shape):
+        """The input quantiser of the window attention ({"quant", "b4", "baft"}) for a producer that applies it itself, or None."""
+        return None
+
+    def fused_window_plan(self, x):
+        """(geometry, input-quantiser spec, token permutation) when the LayerNorm in front of this attention can emit the
+        quantiser's codes directly in window-major order (no padding: every 224-px stage), else None.  perm[t] = row of token t
+        of an image after the cyclic shift + window partition (swin.py:103-131)."""
+        if not (SWIN_ATTN_FUSE and x.is_cuda and x.dim() == 4):
+            return None
+        g = WindowGeometry(x, self.window_size, self.shift_size)
+        if g.pad != (0, 0):
+            return None
+        spec = self._input_spec((g.B * g.nW, g.N, g.C))
+        if spec is None:
+            return None
+        return g, spec, g._perm(x.device)[1]
+
+    def window_forward_pre(self, g, pre):
+        """The attention on window-major codes `pre` = (x_hat carrier, codes, geom) -> proj output, STILL window-major
+        ((B*nW, N, C)): the caller's next LayerNorm pass reads it through the same permutation."""
+        self.shift_size = g.ss
+        add = g.addend(self.relative_position_bias_table, self.relative_position_index, self.num_heads)
+        out = self._core(self, pre[0], (self.dim // self.num_heads) ** -0.5, add, pre_quant=pre)
+        return self.proj(out)
+
 
 class QAttention_swin(_SwinQBase):
     """swin_attention_and_mlp.py:65-251."""
@@ -114,6 +144,11 @@ class QAttention_swin(_SwinQBase):
         self.move_k_aft = LearnableBias(C)
         self.move_v_aft = LearnableBias(C)
         self.quan_a_softmax_fn = LsqQuantizer(bit=input_bits, all_positive=True, per_channel=True, learnable=aq_learnable)
+
+    _core = staticmethod(plain_attention_core)
+
+    def _input_spec(self, win_shape):
+        return self.qkv.fused_input_quant(win_shape)
 
     def forward(self, x):
         return self._window_forward(x, plain_attention_core)
@@ -155,6 +190,15 @@ class QAttention_swin_qkreparam(_SwinQBase):
 
     def _make_qk_quant(self, wq_learnable, boundaryRange):
         return StatsQuantizer(num_bits=self.weight_bits, clip_learnable=wq_learnable)
+
+    _core = staticmethod(qkr_attention_core)
+
+    def _input_spec(self, win_shape):
+        _, N, C = win_shape
+        xin = self.quant_x_4_qkv
+        if not (_ql.FUSE_NORM_QUANT and _attn_codes_ok(self, N, C)):
+            return None
+        return {"quant": xin.input_quant_fn, "b4": xin.move_b4.bias, "baft": xin.move_aft.bias}
 
     def forward(self, x):
         return self._window_forward(x, qkr_attention_core)

@@ -311,6 +311,23 @@ class SwinTransformerBlock(nn.Module):
         """forward() with the residual add of the PREVIOUS block's MLP output (`pending`, not yet added to x) folded into
         norm1's pass; this block's own MLP output is returned un-added.  Returns (x after the attention residual, info,
         mlp output)."""
+        plan = self.attn.fused_window_plan(x) if hasattr(self.attn, "fused_window_plan") else None
+        if plan is not None:
+            # norm1 (+ the pending residual) -> cyclic shift + window partition -> the attention's input quantiser in ONE pass:
+            # the codes leave in window-major order, the residual stream stays in token order; the attention's output stays
+            # window-major and norm2's pass reads it through the same permutation (no partition / reverse copies either way)
+            g, spec, perm = plan
+            fused = F_ofq.norm_quant(self.norm1, spec, x, pending, q_perm=perm, qshape=(g.B * g.nW, g.N, g.C))
+            if fused is not None:
+                xin, pre = fused
+                yw = self.attn.window_forward_pre(g, pre)
+                spec2 = self.mlp.fused_input_quant(tuple(xin.shape)) if _SWIN_FUSE and hasattr(self.mlp, "fused_input_quant") else None
+                fused2 = F_ofq.norm_quant(self.norm2, spec2, xin, yw, res_perm=perm) if spec2 is not None else None
+                if fused2 is not None:
+                    x2, pre2 = fused2
+                    return x2, None, self.mlp(pre2[0], pre_quant=pre2)
+                x2, n2 = F_ofq.add_layer_norm(self.norm2, xin, g.reverse(yw))
+                return x2, None, self.mlp(n2)
         if pending is None:
             xin, n1 = x, F_ofq.layer_norm(self.norm1, x)
         else:

@@ -587,6 +587,59 @@ def test_engine_step_surfaces_a_stream_k_timeout(ops):
     assert torch.isfinite(engine.train_step(model, opt, img, tgt, soft))
 
 
+@pytest.mark.parametrize("shift", [0, 3])
+def test_layernorm_lsq_with_token_permutations_equals_the_same_kernel_on_permuted_rows(ops, shift):
+    """ofq_layernorm_lsq_fwd_perm / _bwd_perm (round 6: Swin's shifted-window partition and reverse folded into the LayerNorm passes,
+    swin.py:103-131, :160-170; swin_attention_and_mlp.py:312-323).  The permutation is the real one (7 x 7 windows on a 14 x 14 map,
+    cyclic shift 0 / 3).  Reference = the UN-permuted kernels on explicitly permuted rows: every per-row result (codes, x + res, mean,
+    rstd, dx, the res gradient, the step gradients' row partials) must be the same bits at its new place; the column sums
+    (dgamma, dbeta, d offsets) add the same rows in another order: 1e-5."""
+    from ofq_amd.swin import WindowGeometry
+    B, Hm, Wm, C = 3, 14, 14, 96
+    g = torch.Generator(device="cuda").manual_seed(5 + shift)
+    x = torch.randn(B, Hm, Wm, C, device="cuda", generator=g)
+    geo = WindowGeometry(x, [7, 7], [shift, shift])
+    idx, inv = geo._perm(x.device)
+    N, S = Hm * Wm, 49
+    x2 = x.reshape(B * N, C)
+    res_w = torch.randn(B * N, C, device="cuda", generator=g)                       # window-major
+    gam, bet = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.1
+    s = torch.rand(S, device="cuda", generator=g) * 0.2 + 0.3
+    b4 = torch.randn(C, device="cuda", generator=g) * 0.05
+    geom = ops.LsqGeom(B * N // S, S, C, C, 0, -4, 3, B * N // S * C)
+    to_w = lambda t: t.view(B, N, -1)[:, idx.long()].reshape(B * N, -1)              # token-major rows -> window-major   # noqa: E731
+    to_t = lambda t: t.view(B, N, -1)[:, inv.long()].reshape(B * N, -1)              # window-major rows -> token-major   # noqa: E731
+    # forward
+    cw, xsw, mw, rw = ops.layernorm_lsq_fwd(to_w(x2).contiguous(), gam, bet, 1e-5, s, b4, geom, res2d=res_w)
+    cp, xsp, mp, rp = ops.layernorm_lsq_fwd(x2, gam, bet, 1e-5, s, b4, geom, res2d=res_w, q_perm=inv, res_perm=inv)
+    assert torch.equal(cp, cw)                                                      # codes: window-major in both
+    assert torch.equal(to_w(xsp), xsw) and torch.equal(to_w(mp.view(-1, 1)), mw.view(-1, 1)) and torch.equal(to_w(rp.view(-1, 1)), rw.view(-1, 1))
+    assert len(torch.unique(cp)) >= 6
+    # only the quantised side permuted (norm1: the pending residual is token-major)
+    res_t = to_t(res_w).contiguous()
+    cq, xsq, _, _ = ops.layernorm_lsq_fwd(x2, gam, bet, 1e-5, s, b4, geom, res2d=res_t, q_perm=inv)
+    assert torch.equal(cq, cw) and torch.equal(xsq, xsp)
+    # backward
+    gq_w = torch.randn(B * N, C, device="cuda", generator=g) * 1e-2                  # gradient of the quantised values: window-major
+    dres_t = torch.randn(B * N, C, device="cuda", generator=g) * 1e-2                # gradient arriving on x + res: token-major
+    ref = ops.layernorm_lsq_bwd(gq_w, xsw, mw, rw, gam, bet, s, b4, geom, dres2d=to_w(dres_t).contiguous())
+    got = ops.layernorm_lsq_bwd(gq_w, xsp, mp, rp, gam, bet, s, b4, geom, dres2d=dres_t, q_perm=inv, res_perm=inv)
+    assert len(got) == 7
+    assert torch.equal(to_w(got[0]), ref[0])                                        # dx: token-major here, window-major there
+    assert torch.equal(got[6], ref[0])                                              # the res gradient: window-major
+    assert torch.equal(got[4], ref[4])                                              # ds: the same row partials at the same places
+    for i in (1, 2, 3, 5):
+        assert rel_err(got[i].cpu(), ref[i].cpu()) < 1e-5, i
+    if ops.GRAD_PLANES == 2:
+        assert ops.amax_of(got[6]) is not None and ops.amax_of(got[6]) is ops.amax_of(got[0])
+    got2 = ops.layernorm_lsq_bwd(gq_w, xsp, mp, rp, gam, bet, s, b4, geom, dres2d=dres_t, q_perm=inv)
+    assert got2[6] is None and torch.equal(got2[0], got[0])
+    # argument checks: the image length must divide the rows and be a multiple of the step vector
+    assert ops.lib().ofq_layernorm_lsq_fwd_perm(x2.data_ptr(), None, None, None, None, None, mp.data_ptr(), rp.data_ptr(), cp.data_ptr(),
+                                                s.data_ptr(), S, 1.0, None, -4, 3, B * N, C, C, 1e-5, inv.data_ptr(), None, N - 1,
+                                                ops._stream()) != 0
+
+
 def test_step_guard_words_and_the_guarded_adamw_launch(ops):
     """ofq_step_guard: OR of device words compared as bits without a float's sign bit (an int 1, a float 0.25 from an averaged
     bucket flag, -0.0 = clean, NaN = set); outputs loss / guard word / flag.  ofq_adamw_multi_g / _dev_g: a non-zero guard word
