@@ -679,7 +679,13 @@ def _addend_grad(dS, addend, alpha):
     """d(addend)[p] = sum over the batch rows that used slab p of dS / alpha   (S' = alpha*S + addend)."""
     B, H, N, Np = dS.shape
     P = addend.shape[0]
-    return dS.reshape(B * H // P, P, N, Np).sum(0) / alpha
+    G = B * H // P
+    if dS.is_cuda and dS.is_contiguous() and dS.dtype == torch.float32 and G > 1:
+        # the library's two-stage column sum, not torch.sum: over 8192 windows (Swin-T's first block) ATen's multi-workgroup
+        # reduction returned different last bits in 1 of ~150 replays of the captured step (tools/swin_relpos_trace.py; on its own
+        # the same call is reproducible: tools/relpos_determinism_probe.py) -- the one gradient of the Swin step that did
+        return ops.colsum(dS.view(G, P * N * Np)).view(P, N, Np) / alpha
+    return dS.reshape(G, P, N, Np).sum(0) / alpha
 
 
 class SoftmaxLsqFn(torch.autograd.Function):

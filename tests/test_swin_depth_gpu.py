@@ -130,6 +130,49 @@ def test_every_block_and_merging_layer_of_swin_t_teacher_forced():
     assert clean >= 6, rows
 
 
+def test_fused_swin_block_equals_the_unfused_block():
+    """Round 6: SwinTransformerBlock.forward_fused folds the cyclic shift + window partition / reverse into the LayerNorm + quantiser
+    passes around the attention (ofq_layernorm_lsq_fwd_perm / _bwd_perm) and gives the MLP and patch merging the LayerNorm + quantiser
+    and GELU-epilogue fusions.  Against the same block's un-fused forward() (permute kernels, separate LayerNorm and quantiser
+    launches -- the path the teacher-forced oracle test above runs) on the same input, real dimensions, shifted and un-shifted,
+    first and later stages, with and without a pending residual: identical integer decisions => the output is the same bits or
+    differs by rounding only (< 1e-6), every gradient agrees to 1e-5 (the column sums add the same rows in another order)."""
+    model, img = _build_swin()
+    model.train()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    feats = model.features
+    cases = [(feats[1][0], (2, 56, 56, 96)), (feats[1][1], (2, 56, 56, 96)), (feats[3][1], (2, 28, 28, 192)), (feats[5][2], (2, 14, 14, 384)),
+             (feats[7][1], (2, 7, 7, 768))]
+    for blk, shp in cases:
+        x = torch.randn(shp, device="cuda", generator=gen)
+        up = torch.randn(shp, device="cuda", generator=gen)
+        for with_pending in (False, True):
+            pend = torch.randn(shp, device="cuda", generator=gen) * 0.1 if with_pending else None
+            res = {}
+            for mode in ("plain", "fused"):
+                blk.zero_grad(set_to_none=True)
+                xi = x.clone().requires_grad_(True)
+                pi = pend.clone().requires_grad_(True) if pend is not None else None
+                if mode == "plain":
+                    y = blk(((xi + pi) if pi is not None else xi, None))[0]
+                else:
+                    assert blk.attn.fused_window_plan(xi) is not None            # the path under test is the one taken
+                    x2, _, m = blk.forward_fused(xi, pi)
+                    y = x2 + m
+                (y * up).sum().backward()
+                res[mode] = (y.detach(), xi.grad.clone(), None if pi is None else pi.grad.clone(),
+                             {n: q.grad.clone() for n, q in blk.named_parameters() if q.grad is not None})
+            a, b = res["plain"], res["fused"]
+            assert _l2(b[0], a[0]) < 1e-6, (shp, with_pending, _l2(b[0], a[0]))
+            assert _l2(b[1], a[1]) < 1e-5 and (a[2] is None or _l2(b[2], a[2]) < 1e-5)
+            assert a[3].keys() == b[3].keys()
+            big = max(float(v.abs().max()) for v in a[3].values())
+            for n in a[3]:
+                if float(a[3][n].abs().max()) < 1e-6 * big:
+                    continue
+                assert _l2(b[3][n], a[3][n]) < 3e-5, (shp, with_pending, n, _l2(b[3][n], a[3][n]))
+
+
 @pytest.mark.parametrize("model_type", ["deit", "swin"])
 def test_cga_masks_and_frozen_weights_at_full_size(model_type):
     """Config C5 at its real size: CGAHooks + FusedAdamW on every quantised weight matrix of DeiT-S W2A2 (qk_reparam_type=1:
