@@ -37,6 +37,7 @@ class Permute(nn.Module):
 
 
 _MERGE_PERM = {}
+_SWIN_WQK = os.environ.get("OFQ_NO_SWIN_WQK") is None                # A/B switch: W_qk of a stage's blocks in one batched launch
 _SWIN_FUSE = os.environ.get("OFQ_NO_SWIN_MLP_FUSE") is None      # A/B switch of round 6's LayerNorm + quantiser fusions in Swin
 
 
@@ -381,13 +382,20 @@ class SwinTransformer(nn.Module):
         for blk in self.features[1:]:
             if isinstance(blk, nn.Sequential):
                 info, pending, cur = None, None, x[0]
-                for b in blk:
-                    if hasattr(b, "forward_fused"):     # residual adds ride in the next block's norm1 (same values)
-                        cur, info, pending = b.forward_fused(cur, pending)
-                    else:
-                        if pending is not None:
-                            cur, pending = cur + pending, None
-                        cur, info = b((cur, None))
+                # the W_qk products (and their StatsQ operands) of a stage's QKR blocks in one batched launch each way, as the
+                # DeiT models have it (functional.all_wqk: the blocks of a stage share one shape); round 6
+                served = F_ofq.all_wqk([b.attn for b in blk if hasattr(b, "attn")]) if _SWIN_WQK and x[0].is_cuda else []
+                try:
+                    for b in blk:
+                        if hasattr(b, "forward_fused"):     # residual adds ride in the next block's norm1 (same values)
+                            cur, info, pending = b.forward_fused(cur, pending)
+                        else:
+                            if pending is not None:
+                                cur, pending = cur + pending, None
+                            cur, info = b((cur, None))
+                finally:
+                    for a_ in served:
+                        a_._wqk_pre = None
                 if pending is not None:
                     cur = cur + pending
                 x = (cur, None)
