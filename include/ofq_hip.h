@@ -261,7 +261,9 @@ size_t ofq_qgemm_bf16s_nt_lsq_ws_bytes(int64_t M, int64_t N);
 int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const float* k_scale, float alpha, const float* x,
                            const float* lsq_s, int64_t S, float gscale, const float* b4, int lo, int hi, int gelu,
                            float* dx, float* ds, float* db4, float* dbaft, int64_t M, int64_t N, int64_t K, int64_t lda,
-                           int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, ofq_stream_t stream);
+                           int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, const void* amax, ofq_stream_t stream);
+/*  (amax, round 6: NULL = B holds bf16 codes and dY is split into three bf16 planes; else the maximum word of dY, B holds fp16
+ *  codes and dY is split into two fp16 planes, as in ofq_qgemm_bf16s_nt.) */
 /*  weight gradient: dW[o,c] = sum_m (dY[m,o] * a_eff[m % S]) * codes[m,c] + db[o]*baft[c]  (= dY^T @ X_hat with
  *            X_hat = a_eff*codes + baft).  dY fp32 [Ktok][M], codes int8 [Ktok][N]; three bf16 pieces of dY*a_eff,
  *            LDS transpose reads, split-K over tokens with a deterministic reduction.  M % 4 == 0, N % 16 == 0.

@@ -68,7 +68,7 @@ SIGNATURES = {
     "ofq_qgemm_bf16s_nt_sk_reset": (i32, [vp, vp]),
     "ofq_qgemm_bf16s_nt_lsq_ws_bytes": (sz, [i64, i64]),
     "ofq_qgemm_bf16s_nt_lsq": (i32, [vp, vp, vp, f32, vp, vp, i64, f32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i64, i64, i64,
-                                     i64, i64, vp, sz, vp]),
+                                     i64, i64, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_tn_ws_bytes": (sz, [i64, i64, i32]),
     "ofq_qgemm_bf16s_tn": (i32, [vp, vp, vp, vp, i64, f32, vp, i32, vp, i64, i64, i64, i64, i64, i32, vp, sz, vp, vp]),
     "ofq_qgemm_bf16s_tn_group_ws_bytes": (sz, [C.POINTER(TnJob), i32, i32]),

@@ -14,7 +14,8 @@ extern "C" size_t ofq_qgemm_bf16s_nt_lsq_ws_bytes(int64_t M, int64_t N) {
 extern "C" int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const float* k_scale, float alpha, const float* x,
                                       const float* lsq_s, int64_t S, float gscale, const float* b4, int lo, int hi, int gelu,
                                       float* dx, float* ds, float* db4, float* dbaft, int64_t M, int64_t N, int64_t K,
-                                      int64_t lda, int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, ofq_stream_t stream) {
+                                      int64_t lda, int64_t ldb, int64_t ldx, void* ws, size_t ws_bytes, const void* amax,
+                                      ofq_stream_t stream) {
   if (!dY || !B_bf16 || !x || !lsq_s || !dx || !ws || M <= 0 || N <= 128 || K <= 0 || S <= 0) return OFQ_EINVAL;
   if ((K & 7) || (lda & 3) || (ldb & 7) || ldx < N || !al16(dY) || !al16(B_bf16) || (k_scale && !al16(k_scale)) ||
       M >= (1ll << 30) || N >= (1ll << 30))
@@ -23,14 +24,17 @@ extern "C" int ofq_qgemm_bf16s_nt_lsq(const float* dY, const void* B_bf16, const
   int64_t tm, tn;
   nt_lsq_tiles(M, N, &tm, &tn);
   QGemmArgs a = {};
-  a.A = dY; a.B = B_bf16; a.C = dx; a.s = k_scale;
+  a.A = dY; a.B = B_bf16; a.C = dx; a.s = k_scale; a.amax = (const unsigned*)amax;      // amax: fp16 codes, two planes of dY
   a.lda = lda; a.ldb = ldb; a.ldc = ldx; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)tm; a.tiles_n = (int)tn; a.alpha = alpha; a.nb1 = 1;
   a.lx = x; a.ldlx = ldx; a.ls = lsq_s; a.lS = (int)S; a.lgscale = gscale; a.lb4 = b4; a.llo = (float)lo; a.lhi = (float)hi;
   a.lgelu = gelu; a.lrow = (float*)ws; a.lcol = (float*)ws + (size_t)M * tn;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(tm * tn));
-  if (N > 256) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, true>), grid, dim3(512), 0, st, a);
+  if (amax) {
+    if (N > 256) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, true, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, true, true>), grid, dim3(512), 0, st, a);
+  } else if (N > 256) hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<3, true>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((qgemm_bf16s_nt_wide_kernel<2, true>), grid, dim3(512), 0, st, a);
   OFQ_LAUNCH_CHECK();
   SumJobs jobs = {};

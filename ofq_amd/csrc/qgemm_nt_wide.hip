@@ -8,7 +8,6 @@
 // back (8 of the 16 B/element of the unfused pair).
 template <int NJ, bool LSQ, bool F16 = false>
 __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
-  static_assert(!(LSQ && F16), "the fused LSQ epilogue exists for the three-plane form only");
   constexpr int BM = 128, BN = 128 * NJ, NS = F16 ? 2 : 3;
   constexpr int PLANE = BM * QBS_LD;
   constexpr int STAGE = NS * PLANE + BN * QBS_LD;
@@ -380,6 +379,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
     float* colred = fsm + 5 * BM;                      // [2][2][BN] offset-gradient partials per row-wave
     if (tid < BM) row_a[tid] = ofq_lsq_eff_scale(p.ls[min(m0 + tid, p.M - 1) % p.lS], p.lgscale);
     __syncthreads();
+    const float alpha_l = p.alpha * inv_sE;             // (F16: back from the launch's power-of-two scale)
     int ncol[NJ];
     bool nok[NJ];
     float b4v[NJ], cb4[NJ], cg[NJ];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512) void qgemm_bf16s_nt_wide_kernel(QGemmArgs p) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const bool ok = mok && nok[j];
-            const float ge = ok ? acc[i][j][e] * p.alpha : 0.f;
+            const float ge = ok ? acc[i][j][e] * alpha_l : 0.f;
             const float xin = xv[ee][j];
             const float xe = p.lgelu ? ofq_gelu(xin) : xin;
             float q, v;

@@ -862,11 +862,12 @@ def qgemm_bf16s_nt_lsq(dy2d, B_bf16, k_scale, alpha, x2d, s, b4, g, want_bias_gr
     db4 = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     dbaft = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
     ws = workspace(lib().ofq_qgemm_bf16s_nt_lsq_ws_bytes(M, N), dev)
+    amax = amax_for(dy2d) if B_bf16.dtype == torch.float16 else None         # fp16 codes: the two-plane form
     with _Timed('qgemm_bf16s_nt_wide_lsq (linear dX + LSQ backward epilogue)', 2.0 * M * N * K):
         _chk(lib().ofq_qgemm_bf16s_nt_lsq(dy2d.data_ptr(), B_bf16.data_ptr(), _p(k_scale), alpha, x2d.data_ptr(), s.data_ptr(),
                                           g.S, g.gscale, _p(b4), g.lo, g.hi, int(g.prologue == 1), dx.data_ptr(), ds.data_ptr(),
                                           _p(db4), _p(dbaft), M, N, K, dy2d.stride(0), B_bf16.stride(0), x2d.stride(0),
-                                          ws.data_ptr(), ws.numel(), _stream()), "ofq_qgemm_bf16s_nt_lsq")
+                                          ws.data_ptr(), ws.numel(), _p(amax), _stream()), "ofq_qgemm_bf16s_nt_lsq")
     return dx, ds, db4, dbaft
 
 

@@ -29,8 +29,9 @@ FUSE_NEXT_CODES_MLP = os.environ.get("OFQ_NO_EPILOGUE_FUSE_MLP") is None
 # The input quantiser's backward can run in the epilogue of the layer's dX GEMM (ofq_qgemm_bf16s_nt_lsq: dX never
 # goes to HBM).  Correct and tested, but OFF by default: measured on MI355X it loses -- the 2-waves-per-SIMD GEMM kernel
 # executes the division-heavy LSQ arithmetic at a fraction of the rate of the 5-waves-per-SIMD elementwise kernel
-# (+75 us per GEMM launch vs 51 us for the separate kernel).  OFQ_LSQ_BWD_FUSE=1 turns it on.
-FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None and ops.GRAD_PLANES == 3     # (its kernel reads bf16 weight codes)
+# (+75 us per GEMM launch vs 51 us for the separate kernel; round 6, two-plane form, both sites of a block: 21.03 -> 22.05 ms per
+# step).  OFQ_LSQ_BWD_FUSE=1 turns it on.
+FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None
 # LayerNorm + the per-token LSQ of its single consumer in one kernel each way (A/B switch: OFQ_NO_NORM_QUANT_FUSE=1)
 FUSE_NORM_QUANT = os.environ.get("OFQ_NO_NORM_QUANT_FUSE") is None
 # A GEMM whose epilogue applies its only consumer's quantiser writes that quantiser's codes and nothing else; the
