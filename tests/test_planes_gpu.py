@@ -203,6 +203,8 @@ def test_absmax_kernel_and_producer_by_products(ops):
     xn = x.clone()
     xn[17, 3] = float("nan")
     assert np.isnan(_word(ops.absmax(xn)))
+    if ops.GRAD_PLANES != 2:
+        pytest.skip("the producers raise a maximum word in two-plane mode only (run under OFQ_GRAD_PLANES=3)")
     # LayerNorm backward (plain)
     R, C = 792, 384
     xx = torch.randn(R, C, device="cuda", generator=g)
