@@ -204,6 +204,7 @@ class VisionTransformer(nn.Module):
         attn_matrixs, feats = [], []
         pending = None
         served = F_ofq.all_wqk([blk.attn for blk in self.blocks])
+        served_plain = F_ofq.all_plain_prep([blk.attn for blk in self.blocks]) if x.is_cuda else []
         try:
             for i, blk in enumerate(self.blocks):
                 x, a, pending, xin = blk.forward_fused(x, pending)  # same values as x, a = blk(x), adds fused into norms
@@ -213,6 +214,8 @@ class VisionTransformer(nn.Module):
         finally:
             for a_ in served:
                 a_._wqk_pre = None
+            for a_ in served_plain:
+                a_._plain_pre = None
         x = x + pending
         feats.append(x)
         # LayerNorm is per token and only the class / distillation tokens are read: norm those rows only

@@ -610,6 +610,31 @@ def all_wqk(attns):
     return attns
 
 
+def all_plain_prep(attns):
+    """The per-head offset operands of the plain attention's scores -- eye_h * bk, eye_h * bq (H rows of length C: the head's
+    channels of the offset vector, zeros elsewhere) and z[h] = bq|h . bk|h (attention.py:96 with the offsets of :77-78 expanded) --
+    for ALL blocks of a model in five small launches instead of four per block; they depend on parameters only.  Each module picks
+    its slices up from `_plain_pre` (ScoresSoftmaxCodesFn / QKScoresCodesFn); returns the modules served."""
+    if not BULK_WQK or len(attns) < 2 or os.environ.get("OFQ_NO_PLAIN_PREP") is not None:      # (A/B switch)
+        return []
+    a0 = attns[0]
+    ok = all(hasattr(a, "move_q_aft") and hasattr(a, "move_k_aft") and not hasattr(a, "qk_quant") and a.num_heads == a0.num_heads
+             and a.move_q_aft.bias.shape == a0.move_q_aft.bias.shape and a.move_q_aft.bias.is_cuda for a in attns)
+    if not ok:
+        return []
+    H = a0.num_heads
+    C = a0.move_q_aft.bias.numel()
+    with torch.no_grad():
+        bq = torch.stack([a.move_q_aft.bias.detach().reshape(C) for a in attns])            # (L, C)
+        bk = torch.stack([a.move_k_aft.bias.detach().reshape(C) for a in attns])
+        eye = _head_mask(H, C // H, bq.device)                                                 # (H, C)
+        ebk, ebq = eye.unsqueeze(0) * bk.unsqueeze(1), eye.unsqueeze(0) * bq.unsqueeze(1)     # (L, H, C): same products as eye * b
+        z = (bq * bk).view(len(attns), H, C // H).sum(2)                                       # (L, H): same sums as .view(H, d).sum(1)
+    for l, a in enumerate(attns):
+        a._plain_pre = (ebk[l], ebq[l], z[l])
+    return attns
+
+
 class QKRScoresFn(torch.autograd.Function):
     """S[b,h,n,m] = sum_c xq[b,n,c] * qkx[b,m,h,c]   (attention.py:207-210), S stored (B,H,N,Np)."""
 
@@ -969,10 +994,15 @@ class ScoresSoftmaxCodesFn(torch.autograd.Function):
         if plain:
             B, N, C = a_carrier.shape
             CK = C // H
-            eye = _head_mask(H, CK, a_carrier.device)
-            u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), eye * aux["bk"])
-            tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), eye * aux["bq"])
-            z = (aux["bq"] * aux["bk"]).view(H, CK).sum(1)
+            pre = aux.get("plain_pre")
+            if pre is not None:                     # (all blocks' offset operands in one batch: all_plain_prep)
+                ebk, ebq, z = pre
+            else:
+                eye = _head_mask(H, CK, a_carrier.device)
+                ebk, ebq = eye * aux["bk"], eye * aux["bq"]
+                z = (aux["bq"] * aux["bk"]).view(H, CK).sum(1)
+            u = ops.rowdot_i8_multi(aux["qcodes"].view(B * N, C), ebk)
+            tq = ops.rowdot_i8_multi(aux["kcodes"].view(B * N, C), ebq)
             ac, bc, sa, ga, sb, gb = aux["qcodes"], aux["kcodes"], aux["sq"], aux["gq"], aux["sk"], aux["gk"]
         else:
             B, N, C = a_carrier.shape

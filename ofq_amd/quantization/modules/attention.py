@@ -146,7 +146,7 @@ def plain_attention_core(self, x, scale, addend=None, pre_quant=None):
             link = {}
             saux = {"qcodes": qc, "kcodes": kc, "sq": self.quan_a_q_fn.s.detach(), "gq": gq.gscale,
                     "sk": self.quan_a_k_fn.s.detach(), "gk": gq.gscale, "bq": self.move_q_aft.bias.detach(),
-                    "bk": self.move_k_aft.bias.detach(), "H": H, "link": link}
+                    "bk": self.move_k_aft.bias.detach(), "H": H, "link": link, "plain_pre": getattr(self, "_plain_pre", None)}
             pv_aux = {"vcodes": vc, "sv": self.quan_a_v_fn.s.detach(), "gv": gv.gscale, "bav": self.move_v_aft.bias.detach()}
             if scores_softmax_fusable(N) and sm.initialized_alpha and sm.s is not None:
                 saux.update(plain=True, alpha=scale, hi=sm.thd_pos, vlink=pv_aux)      # (vlink: dP GEMM + softmax backward fused)

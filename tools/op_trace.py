@@ -12,8 +12,9 @@ from ofq_amd import engine
 from ofq_amd.quantization.utils import KDLossSoftandHard
 
 dev = torch.device("cuda")
-B = int(os.environ.get("B", "128"))
-model = engine.build_student("deit_small_distilled_patch16_224", 2, 2, qk_reparam=True).to(dev)
+B = int(os.environ.get("B", os.environ.get("BATCH", "128")))
+model = engine.build_student(os.environ.get("MODEL", "deit_small_distilled_patch16_224"), int(os.environ.get("BITS", "2")),
+                             int(os.environ.get("BITS", "2")), qk_reparam=os.environ.get("QKR", "1") == "1").to(dev)
 images = torch.randn(B, 3, 224, 224, device=dev)
 target = torch.randint(0, 1000, (B,), device=dev)
 soft = torch.randn(B, 1000, device=dev)
