@@ -98,6 +98,16 @@ int ofq_lsq_bwd(const float* g, const float* x, const float* s, const float* b4,
                 float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
                 int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue, void* ws,
                 size_t ws_bytes, void* amax_out, ofq_stream_t stream);
+/*  Round 6: the image quantiser of the W8A8 patch embedding (qlinear.py:166-174: per-channel step, per-pixel offsets, then a
+ *  stride == kernel convolution) with its output in PATCH (im2col) order -- y / codes are [images * gh * gw][channels * ph * pw], the
+ *  operand layout of the convolution's GEMM -- and its backward reading gy in that order: the reference's unfold / permute copies
+ *  (three per step) are addressing.  x / dx: [images][channels][pixels = H * width]; width, pw multiples of 4. */
+int ofq_lsq_fwd_patch(const float* x, const float* s, const float* b4, const float* baft, float* y, int8_t* codes, int64_t images,
+                      int64_t channels, int64_t pixels, int64_t bias_len, int lo, int hi, float gscale, int width, int ph, int pw,
+                      ofq_stream_t stream);
+int ofq_lsq_bwd_patch(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds, float* db4,
+                      float* dbaft, int64_t images, int64_t channels, int64_t pixels, int64_t bias_len, int lo, int hi, float gscale,
+                      int width, int ph, int pw, void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream);
 
 /* ---- K10  scale + softmax + unsigned LSQ on attention scores:
  *  QAttention*.forward attention.py:96-99 / :213-216.  scores [rows][ld] (ld >= n, row r belongs to

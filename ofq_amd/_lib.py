@@ -44,6 +44,8 @@ SIGNATURES = {
     "ofq_statsq_codes_multi": (i32, [vp, i64, vp]),
     "ofq_lsq_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
     "ofq_lsq_bwd_ws_bytes": (sz, [i64, i64, i64, i64, i32]),
+    "ofq_lsq_fwd_patch": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, f32, i32, i32, i32, vp]),
+    "ofq_lsq_bwd_patch": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, f32, i32, i32, i32, vp, sz, vp, vp]),
     "ofq_lsq_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, f32, i32,
                           vp, sz, vp, vp]),
     "ofq_softmax_lsq_fwd": (i32, [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, f32, vp, vp, vp, i64, vp]),

@@ -71,7 +71,23 @@ struct LsqArgs {
   int64_t R, S, inner, ldx, ldy;
   int k, TX, TY, colmode, prologue, nacc, widek;
   float lo, hi, gscale;
+  // patch layout (round 6; the W8A8 stem, qlinear.py:166-174: image quantiser -> stride == kernel conv): rows are (image, channel),
+  // inner = H * W pixels; the forward's y / codes and the backward's gy live in im2col order instead -- row (image, patch),
+  // column (channel, pixel of the patch) -- so the conv's GEMM operands need no permute copy either way.  im_cin == 0: off.
+  int im_cin, im_w, im_ph, im_pw, im_gw, im_gh;
 };
+
+// offset of pixel `col` (a multiple of 4; W and the patch width are multiples of 4 as well: the four pixels stay together) of row
+// (image b, channel c) in the patch layout, split into the part that depends on the pixel and the part that depends on the row
+__device__ __forceinline__ int64_t lsq_im_pix(const LsqArgs& a, int64_t col) {
+  const int y = (int)(col / a.im_w), x = (int)(col - (int64_t)y * a.im_w);
+  const int64_t K = (int64_t)a.im_cin * a.im_ph * a.im_pw;
+  return ((int64_t)(y / a.im_ph) * a.im_gw + x / a.im_pw) * K + (y % a.im_ph) * a.im_pw + (x % a.im_pw);
+}
+__device__ __forceinline__ int64_t lsq_im_row(const LsqArgs& a, int64_t r) {
+  const int64_t b = r / a.im_cin, c = r - b * a.im_cin;
+  return b * ((int64_t)a.im_gh * a.im_gw * a.im_cin * a.im_ph * a.im_pw) + c * (a.im_ph * a.im_pw);
+}
 
 #ifndef LSQ_WAVES_PER_EU
 #define LSQ_WAVES_PER_EU
@@ -132,13 +148,18 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
     int64_t ccol[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) ccol[j] = cok[j] ? (c4base + tx + (int64_t)j * TX) * 4 : 0;
+    const bool im = a.im_cin != 0;
+    int64_t impix[J];                                   // patch layout: the pixel's part of the offset (constant per lane)
+#pragma unroll
+    for (int j = 0; j < J; ++j) impix[j] = im ? lsq_im_pix(a, ccol[j]) : 0;
     const int smod_step = (int)(rstride % a.S);
     int smod = (int)(r % a.S);                         // r mod S, kept incrementally
     auto issue = [&](int64_t rr, int sm) {
+      const int64_t grow = (BWD && im) ? lsq_im_row(a, rr) : 0;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         xn[j] = *reinterpret_cast<const float4*>(a.x + rr * a.ldx + ccol[j]);
-        if (BWD) gn[j] = *reinterpret_cast<const float4*>(a.g + rr * a.ldy + ccol[j]);
+        if (BWD) gn[j] = *reinterpret_cast<const float4*>(a.g + (im ? grow + impix[j] : rr * a.ldy + ccol[j]));
       }
       if (!COLMODE) sn = a.s[sm];
     };
@@ -180,8 +201,10 @@ __global__ __launch_bounds__(256) LSQ_WAVES_PER_EU void lsq_kernel(LsqArgs a) {
             out[e] = __fadd_rn(__fmul_rn(yi, al), ba[e]);
             cd[e] = (signed char)(int)q;   // low 8 bits: int8 for signed ranges, uint8 for unsigned
           }
-          if (a.y) *reinterpret_cast<float4*>(a.y + r * a.ldy + col) = make_float4(out[0], out[1], out[2], out[3]);
-          if (a.codes) *reinterpret_cast<char4*>(a.codes + r * a.inner + col) = make_char4(cd[0], cd[1], cd[2], cd[3]);
+          const int64_t yo = im ? lsq_im_row(a, r) + impix[j] : r * a.ldy + col;
+          const int64_t co = im ? yo : r * a.inner + col;
+          if (a.y) *reinterpret_cast<float4*>(a.y + yo) = make_float4(out[0], out[1], out[2], out[3]);
+          if (a.codes) *reinterpret_cast<char4*>(a.codes + co) = make_char4(cd[0], cd[1], cd[2], cd[3]);
         } else {
           float ge[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
           float dxo[4];
@@ -288,10 +311,22 @@ static int lsq_launch(const LsqGeom& g, const LsqArgs& a, hipStream_t st) {
   return 0;
 }
 
-extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, const float* baft, float* y,
-                           int8_t* codes, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
-                           int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
-                           ofq_stream_t stream) {
+struct LsqPatch { int width, ph, pw; };        // width 0: off
+
+static int lsq_patch_fill(LsqArgs& a, const LsqPatch& pt, int64_t S, int64_t inner, int64_t ldx, int64_t ldy, int scale_mode) {
+  if (pt.width == 0) return 0;
+  if (pt.width <= 0 || pt.ph <= 0 || pt.pw <= 0 || (pt.width & 3) || (pt.pw & 3) || inner % pt.width || pt.width % pt.pw ||
+      (inner / pt.width) % pt.ph || ldx != inner || ldy != inner || scale_mode != 0 || S >= (1 << 20))
+    return OFQ_EINVAL;
+  a.im_cin = (int)S; a.im_w = pt.width; a.im_ph = pt.ph; a.im_pw = pt.pw;
+  a.im_gw = pt.width / pt.pw; a.im_gh = (int)(inner / pt.width) / pt.ph;
+  return 0;
+}
+
+static int lsq_fwd_impl(const float* x, const float* s, const float* b4, const float* baft, float* y,
+                        int8_t* codes, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
+                        int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue, LsqPatch pt,
+                        ofq_stream_t stream) {
   if (!x || !s || (!y && !codes) || outer <= 0 || S <= 0) return OFQ_EINVAL;
   if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
   if ((b4 || baft) && bias_len <= 0) return OFQ_EINVAL;
@@ -304,7 +339,26 @@ extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, cons
   a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
   a.colmode = scale_mode; a.prologue = prologue; a.nacc = 0;
   a.lo = (float)lo; a.hi = (float)hi; a.gscale = gscale;
+  rc = lsq_patch_fill(a, pt, S, inner, ldx, ldy, scale_mode);
+  if (rc) return rc;
   return lsq_launch<false>(g, a, (hipStream_t)stream);
+}
+extern "C" int ofq_lsq_fwd(const float* x, const float* s, const float* b4, const float* baft, float* y,
+                           int8_t* codes, int64_t outer, int64_t S, int64_t inner, int64_t ldx, int64_t ldy,
+                           int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
+                           ofq_stream_t stream) {
+  return lsq_fwd_impl(x, s, b4, baft, y, codes, outer, S, inner, ldx, ldy, bias_len, scale_mode, lo, hi, gscale, prologue,
+                      LsqPatch{0, 0, 0}, stream);
+}
+// The image quantiser of the W8A8 patch embedding with its output in patch (im2col) order: x is [images][channels][H * W]
+// (outer images, S channels: one step per channel, per-pixel offsets of length H * W), y / codes are [images * gh * gw]
+// [channels * ph * pw] -- the operand layout of the stride == kernel convolution's GEMM (qlinear.py:166-174).
+extern "C" int ofq_lsq_fwd_patch(const float* x, const float* s, const float* b4, const float* baft, float* y, int8_t* codes,
+                                 int64_t images, int64_t channels, int64_t pixels, int64_t bias_len, int lo, int hi, float gscale,
+                                 int width, int ph, int pw, ofq_stream_t stream) {
+  if (width <= 0) return OFQ_EINVAL;
+  return lsq_fwd_impl(x, s, b4, baft, y, codes, images, channels, pixels, pixels, pixels, bias_len, 0, lo, hi, gscale, 0,
+                      LsqPatch{width, ph, pw}, stream);
 }
 
 static void lsq_ws_layout(const LsqGeom& g, int64_t R, int64_t inner, int nacc, size_t* row_floats,
@@ -321,10 +375,10 @@ extern "C" size_t ofq_lsq_bwd_ws_bytes(int64_t outer, int64_t S, int64_t inner, 
   return (rf + cf) * sizeof(float) + 256;
 }
 
-extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds,
-                           float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx,
-                           int64_t ldy, int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
-                           void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
+static int lsq_bwd_impl(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds,
+                        float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx,
+                        int64_t ldy, int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
+                        void* ws, size_t ws_bytes, void* amax_out, LsqPatch pt, ofq_stream_t stream) {
   if (!gy || !x || !s || !dx || !ws || outer <= 0 || S <= 0) return OFQ_EINVAL;
   if (scale_mode == 1 && S != 1) return OFQ_EINVAL;
   if (ldx < inner || ldy < inner || (ldx & 3) || (ldy & 3)) return OFQ_EINVAL;
@@ -341,6 +395,8 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
   a.R = outer * S; a.S = S; a.inner = inner; a.ldx = ldx; a.ldy = ldy; a.k = g.k; a.TX = g.TX; a.TY = g.TY;
   a.colmode = scale_mode; a.prologue = prologue; a.nacc = nacc; a.widek = g.widek;
   a.lo = (float)lo; a.hi = (float)hi; a.gscale = gscale;
+  rc = lsq_patch_fill(a, pt, S, inner, ldx, ldy, scale_mode);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   rc = lsq_launch<true>(g, a, st);
   if (rc) return rc;
@@ -371,4 +427,21 @@ extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, cons
     OFQ_LAUNCH_CHECK();
   }
   return 0;
+}
+extern "C" int ofq_lsq_bwd(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds,
+                           float* db4, float* dbaft, int64_t outer, int64_t S, int64_t inner, int64_t ldx,
+                           int64_t ldy, int64_t bias_len, int scale_mode, int lo, int hi, float gscale, int prologue,
+                           void* ws, size_t ws_bytes, void* amax_out, ofq_stream_t stream) {
+  return lsq_bwd_impl(gy, x, s, b4, dx, ds, db4, dbaft, outer, S, inner, ldx, ldy, bias_len, scale_mode, lo, hi, gscale, prologue,
+                      ws, ws_bytes, amax_out, LsqPatch{0, 0, 0}, stream);
+}
+// Backward of ofq_lsq_fwd_patch: gy in patch order ([images * gh * gw][channels * ph * pw]: the input gradient of the convolution's
+// GEMM as it leaves that GEMM), x / dx in image order.  Workspace: ofq_lsq_bwd_ws_bytes(images, channels, pixels, bias_len, 0).
+extern "C" int ofq_lsq_bwd_patch(const float* gy, const float* x, const float* s, const float* b4, float* dx, float* ds, float* db4,
+                                 float* dbaft, int64_t images, int64_t channels, int64_t pixels, int64_t bias_len, int lo, int hi,
+                                 float gscale, int width, int ph, int pw, void* ws, size_t ws_bytes, void* amax_out,
+                                 ofq_stream_t stream) {
+  if (width <= 0) return OFQ_EINVAL;
+  return lsq_bwd_impl(gy, x, s, b4, dx, ds, db4, dbaft, images, channels, pixels, pixels, pixels, bias_len, 0, lo, hi, gscale, 0, ws,
+                      ws_bytes, amax_out, LsqPatch{width, ph, pw}, stream);
 }

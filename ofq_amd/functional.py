@@ -795,17 +795,18 @@ class QKVSplitLsqFn(torch.autograd.Function):
         qkv2, b4, sq, sk, sv = ctx.saved_tensors
         B, N, C = ctx.shape
         dqkv = torch.empty_like(qkv2)
-        db4s, res = [], []
+        db4_all = torch.empty(3 * C, dtype=torch.float32, device=dqkv.device)       # the three launches write their slice (no cat)
+        res = []
         am = ops.amax_out(dqkv.device)       # ONE maximum word for the three column slices: the qkv projection's backward GEMMs
         for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):     # read dqkv whole
             dy = dy.contiguous()
-            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
-            db4s.append(db4)
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am,
+                                            db4_out=db4_all[i * C:(i + 1) * C])
             res.append((ds, dbaft))
         if am is not None:
             ops.tag_amax(dqkv, am)           # (on the BASE: a consumer's reshape is a view of dqkv, and amax_of looks at t and t._base)
         out = dqkv.view(B, N, 3 * C)
-        return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+        return (out, db4_all, res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
 
@@ -836,17 +837,18 @@ class QKVSplitLsqCodesFn(torch.autograd.Function):
         qkv2, b4, sq, sk, sv = ctx.saved_tensors
         B, N, C = ctx.shape
         dqkv = torch.empty_like(qkv2)
-        db4s, res = [], []
+        db4_all = torch.empty(3 * C, dtype=torch.float32, device=dqkv.device)       # the three launches write their slice (no cat)
+        res = []
         am = ops.amax_out(dqkv.device)       # ONE maximum word for the three column slices: the qkv projection's backward GEMMs
         for i, (s, g, dy) in enumerate(((sq, ctx.geoms[0], dq), (sk, ctx.geoms[1], dk), (sv, ctx.geoms[2], dv))):     # read dqkv whole
             dy = dy.contiguous()
-            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am)
-            db4s.append(db4)
+            _, ds, db4, dbaft = ops.lsq_bwd(dy, qkv2[:, i * C:], s, b4[i * C:(i + 1) * C], g, dx=dqkv[:, i * C:], amax_word=am,
+                                            db4_out=db4_all[i * C:(i + 1) * C])
             res.append((ds, dbaft))
         if am is not None:
             ops.tag_amax(dqkv, am)           # (on the BASE: a consumer's reshape is a view of dqkv, and amax_of looks at t and t._base)
         out = dqkv.view(B, N, 3 * C)
-        return (out, torch.cat(db4s), res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
+        return (out, db4_all, res[0][0], res[1][0], res[2][0], res[0][1], res[1][1],
                 res[2][1], None, None, None)
 
 

@@ -228,7 +228,7 @@ def statsq_codes_multi(items):
 # ------------------------------------------------------------------------------------------------ LSQ
 class LsqGeom:
     """How a tensor maps onto the kernel's [outer][S][inner] view (include/ofq_hip.h, ofq_lsq_fwd)."""
-    __slots__ = ("outer", "S", "inner", "ldx", "ldy", "bias_len", "mode", "lo", "hi", "gscale", "prologue")
+    __slots__ = ("outer", "S", "inner", "ldx", "ldy", "bias_len", "mode", "lo", "hi", "gscale", "prologue", "patch")
 
     def __init__(self, outer, S, inner, bias_len, mode, lo, hi, M, prologue=0, ldx=None, ldy=None):
         self.outer, self.S, self.inner = int(outer), int(S), int(inner)
@@ -238,6 +238,7 @@ class LsqGeom:
         self.mode, self.lo, self.hi = int(mode), int(lo), int(hi)
         self.gscale = 1.0 / math.sqrt(hi * M)          # lsq.py:582-591: 1/sqrt(thd_pos * M), python double
         self.prologue = int(prologue)
+        self.patch = None                              # (width, ph, pw): the image quantiser's output / gradient in im2col order
 
 
 def placeholder(shape, device):
@@ -256,14 +257,24 @@ def lsq_fwd(x, s, b4, baft, g, y=None, want_codes=False, need_values=True):
             y = torch.empty((g.outer * g.S, g.ldy), dtype=torch.float32, device=x.device)
         yptr = y.data_ptr()
     codes = torch.empty((g.outer * g.S, g.inner), dtype=torch.int8, device=x.device) if want_codes else None
+    if g.patch is not None:
+        # ofq_lsq_fwd_patch: the same elements, written in the convolution's im2col order (the callers view y / codes as
+        # [images * gh * gw][channels * ph * pw])
+        if g.mode != 0 or g.prologue != 0 or g.ldx != g.inner or g.ldy != g.inner:
+            raise RuntimeError("ofq_amd: lsq_fwd: the patch layout is the image quantiser's (per-row step, dense rows)")
+        _chk(lib().ofq_lsq_fwd_patch(x.data_ptr(), s.data_ptr(), _p(b4), _p(baft), yptr, _p(codes), g.outer, g.S, g.inner,
+                                     g.bias_len, g.lo, g.hi, g.gscale, g.patch[0], g.patch[1], g.patch[2], _stream()),
+             "ofq_lsq_fwd_patch")
+        return y, codes
     _chk(lib().ofq_lsq_fwd(x.data_ptr(), s.data_ptr(), _p(b4), _p(baft), yptr, _p(codes), g.outer, g.S,
                            g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale, g.prologue, _stream()),
          "ofq_lsq_fwd")
     return y, codes
 
 
-def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True, amax_word=None):
-    """amax_word: raise THIS maximum word instead of a fresh one (the kernels raise it with an atomic max, so several launches that
+def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True, amax_word=None, db4_out=None):
+    """db4_out: write the offset gradient there (a contiguous slice of a larger gradient tensor) instead of a fresh tensor.
+    amax_word: raise THIS maximum word instead of a fresh one (the kernels raise it with an atomic max, so several launches that
     write column slices of one tensor can share the word of the whole tensor; the caller tags the tensor itself)."""
     _dev(gy, "grad")
     dev = x.device
@@ -271,11 +282,18 @@ def lsq_bwd(gy, x, s, b4, g, dx=None, want_bias_grads=True, amax_word=None):
         dx = torch.empty((g.outer * g.S, g.ldx), dtype=torch.float32, device=dev)
     ds = torch.empty_like(s)
     has_bias = g.bias_len > 0 and want_bias_grads
-    db4 = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
+    db4 = (db4_out if db4_out is not None else torch.empty(g.bias_len, dtype=torch.float32, device=dev)) if has_bias else None
     dbaft = torch.empty(g.bias_len, dtype=torch.float32, device=dev) if has_bias else None
     nbytes = lib().ofq_lsq_bwd_ws_bytes(g.outer, g.S, g.inner, g.bias_len, g.mode)
     ws = workspace(nbytes, dev)
     am = amax_word if amax_word is not None else amax_out(dev)
+    if g.patch is not None:
+        _chk(lib().ofq_lsq_bwd_patch(gy.data_ptr(), x.data_ptr(), s.data_ptr(), _p(b4), dx.data_ptr(), ds.data_ptr(), _p(db4),
+                                     _p(dbaft), g.outer, g.S, g.inner, g.bias_len, g.lo, g.hi, g.gscale, g.patch[0], g.patch[1],
+                                     g.patch[2], ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_lsq_bwd_patch")
+        if am is not None and amax_word is None:
+            tag_amax(dx, am)
+        return dx, ds, db4, dbaft
     _chk(lib().ofq_lsq_bwd(gy.data_ptr(), x.data_ptr(), s.data_ptr(), _p(b4), dx.data_ptr(), ds.data_ptr(), _p(db4),
                            _p(dbaft), g.outer, g.S, g.inner, g.ldx, g.ldy, g.bias_len, g.mode, g.lo, g.hi, g.gscale,
                            g.prologue, ws.data_ptr(), ws.numel(), _p(am), _stream()), "ofq_lsq_bwd")

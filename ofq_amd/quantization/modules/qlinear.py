@@ -32,6 +32,8 @@ FUSE_NEXT_CODES_MLP = os.environ.get("OFQ_NO_EPILOGUE_FUSE_MLP") is None
 # (+75 us per GEMM launch vs 51 us for the separate kernel; round 6, two-plane form, both sites of a block: 21.03 -> 22.05 ms per
 # step).  OFQ_LSQ_BWD_FUSE=1 turns it on.
 FUSE_LSQ_BWD = os.environ.get("OFQ_LSQ_BWD_FUSE") is not None
+# the stem's image quantiser writes / reads the convolution's im2col order itself (A/B switch: OFQ_NO_STEM_PATCH_LAYOUT=1)
+STEM_PATCH_LAYOUT = os.environ.get("OFQ_NO_STEM_PATCH_LAYOUT") is None
 # LayerNorm + the per-token LSQ of its single consumer in one kernel each way (A/B switch: OFQ_NO_NORM_QUANT_FUSE=1)
 FUSE_NORM_QUANT = os.environ.get("OFQ_NO_NORM_QUANT_FUSE") is None
 # A GEMM whose epilogue applies its only consumer's quantiser writes that quantiser's codes and nothing else; the
@@ -228,20 +230,31 @@ class LSQ_QConv2d(nn.Conv2d):
         code_dw = (code_dx and xin.initialized_alpha and xin.s is not None and xin.latched() and xin.bit <= 8
                    and K % 384 == 0 and self.out_channels % 4 == 0 and self.weight.requires_grad)
         xcodes = None
-        if code_dw:
-            xq, xcodes, xgeom = xin.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=True)   # :171-173
-        else:
-            xq = xin.quant(input, self.move_b4.bias, self.move_aft.bias)          # :171-173
-        B, Cin, Hh, Ww = xq.shape
+        B, Cin, Hh, Ww = input.shape
         kh, kw = self.kernel_size
         gh, gw = Hh // kh, Ww // kw
-        # im2col of a stride==kernel conv is a pure permutation: (B, gh*gw, Cin*kh*kw)
-        cols = xq.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
+        # im2col of a stride==kernel conv is a pure permutation, (B, gh*gw, Cin*kh*kw): the image quantiser writes its values and
+        # codes in that order itself, and its backward reads the GEMM's input gradient in it (round 6, ofq_lsq_fwd_patch /
+        # _bwd_patch: three permute copies per step gone); STEM_PATCH_LAYOUT False = the copies
+        patch = (Ww, kh, kw) if (STEM_PATCH_LAYOUT and input.is_cuda and input.dtype == torch.float32 and Ww % 4 == 0 and kw % 4 == 0
+                                 and Hh % kh == 0 and Ww % kw == 0 and xin.initialized_alpha and xin.s is not None) else None
+        pkw = dict(patch=patch, out_shape=(B * gh * gw, Cin * kh * kw)) if patch is not None else {}
+        if code_dw:
+            xq, xcodes, xgeom = xin.quant(input, self.move_b4.bias, self.move_aft.bias, want_codes=True, **pkw)   # :171-173
+        else:
+            xq = xin.quant(input, self.move_b4.bias, self.move_aft.bias, **pkw)   # :171-173
+        if patch is not None:
+            cols = xq
+        else:
+            cols = xq.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
         if code_dx:
             steps = ops.lsq_eff_scale_vec(self.lsqw_fn.s.detach(), wgeom.gscale)  # the step VALUE the fake-quant weights carry
             xaux = None
             if xcodes is not None and xin.thd_neg >= -128 and xin.thd_pos <= 127:
-                qx = xcodes.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
+                if patch is not None:
+                    qx = xcodes.view(B * gh * gw, Cin * kh * kw)
+                else:
+                    qx = xcodes.view(B, Cin, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * kh * kw)
                 ax = ops.lsq_eff_scale_vec(xin.s.detach(), xgeom.gscale, kh * kw)                             # step of column k
                 boff = self.move_aft.bias.detach().view(gh, kh, gw, kw).permute(0, 2, 1, 3).reshape(gh * gw, kh * kw).repeat(1, Cin)
                 if getattr(self, "_ones32", None) is None or self._ones32.device != input.device:

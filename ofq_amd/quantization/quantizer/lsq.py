@@ -126,9 +126,10 @@ class _LsqBase(nn.Module):
         return spec
 
     def quant(self, x, b4=None, baft=None, prologue=0, shape=None, ldx=None, ldy=None, out_shape=None,
-              want_codes=False, need_values=True, pre_codes=None, link=None, fused=None):
+              want_codes=False, need_values=True, pre_codes=None, link=None, fused=None, patch=None):
         """Fused (x [+gelu] + b4) -> LSQ -> + baft.  `shape` overrides x.shape for the geometry (used when x
-        is a strided column slice)."""
+        is a strided column slice).  patch = (width, ph, pw): values, codes (and the gradient the backward is given) in the im2col
+        order of a stride == kernel convolution over x = (B, Cin, H, W) -- pass out_shape = (B * gh * gw, Cin * ph * pw)."""
         if not x.is_cuda:
             raise RuntimeError("ofq_amd LSQ: input must be on a HIP device; there is no CPU fallback")
         carrier = x.dim() > 0 and x.stride(-1) == 0          # zero-stride placeholder: the values only exist as codes
@@ -145,6 +146,8 @@ class _LsqBase(nn.Module):
                 xin = self._add_bias_for_init(xin, b4.detach())
             self.init_from(xin)
         geom = self._geom(shp, 0 if b4 is None else b4.numel(), prologue, ldx, ldy)
+        if patch is not None:
+            geom.patch = tuple(int(v) for v in patch)
         if pre_codes is not None and (need_values or not want_codes):
             pre_codes = None
         if link is not None and (need_values or not want_codes or geom.mode != 0 or geom.bias_len not in (0, geom.inner)

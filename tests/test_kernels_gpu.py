@@ -587,6 +587,43 @@ def test_engine_step_surfaces_a_stream_k_timeout(ops):
     assert torch.isfinite(engine.train_step(model, opt, img, tgt, soft))
 
 
+@pytest.mark.parametrize("geo", [(3, 3, 224, 224, 16), (2, 3, 224, 224, 4), (2, 3, 64, 96, 8)])
+def test_image_quantiser_in_patch_layout_equals_the_permute_copies(ops, geo):
+    """ofq_lsq_fwd_patch / _bwd_patch (round 6: the W8A8 stem, qlinear.py:166-174): the image quantiser's values and codes written
+    directly in the im2col order of the stride == kernel convolution, its backward reading the GEMM's input gradient in that order.
+    Against the plain kernels + the unfold / permute copies the reference makes: every output the same bits."""
+    B, Cin, Hh, Ww, p = geo
+    g = torch.Generator(device="cuda").manual_seed(B + p)
+    x = torch.randn(B, Cin, Hh, Ww, device="cuda", generator=g)
+    s = torch.rand(Cin, device="cuda", generator=g) * 0.02 + 0.01
+    b4 = torch.randn(Hh * Ww, device="cuda", generator=g) * 0.01
+    baft = torch.randn(Hh * Ww, device="cuda", generator=g) * 0.01
+    gh, gw, K = Hh // p, Ww // p, Cin * p * p
+    plain = ops.LsqGeom(B, Cin, Hh * Ww, Hh * Ww, 0, -128, 127, B * Hh * Ww)
+    patch = ops.LsqGeom(B, Cin, Hh * Ww, Hh * Ww, 0, -128, 127, B * Hh * Ww)
+    patch.patch = (Ww, p, p)
+    im2col = lambda t: t.view(B, Cin, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, K)      # noqa: E731
+    y0, c0 = ops.lsq_fwd(x.view(B * Cin, -1), s, b4, baft, plain, want_codes=True)
+    y1, c1 = ops.lsq_fwd(x.view(B * Cin, -1), s, b4, baft, patch, want_codes=True)
+    assert torch.equal(y1.view(B * gh * gw, K), im2col(y0)) and torch.equal(c1.view(B * gh * gw, K), im2col(c0))
+    assert len(torch.unique(c1)) > 100
+    _, c2 = ops.lsq_fwd(x.view(B * Cin, -1), s, b4, baft, patch, want_codes=True, need_values=False)
+    assert torch.equal(c2, c1)
+    gy = torch.randn(B * gh * gw, K, device="cuda", generator=g) * 1e-2                                   # as the conv's GEMM hands it over
+    gy_img = gy.view(B, gh, gw, Cin, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B * Cin, Hh * Ww).contiguous()   # the reference's copy back
+    ref = ops.lsq_bwd(gy_img, x.view(B * Cin, -1), s, b4, plain)
+    got = ops.lsq_bwd(gy, x.view(B * Cin, -1), s, b4, patch)
+    for a, b_ in zip(got, ref):
+        assert torch.equal(a, b_)
+    if ops.GRAD_PLANES == 2:
+        assert ops.amax_of(got[0]) is not None
+    # argument checks: widths that are no multiple of 4, a patch that does not tile the image
+    bad = ops.LsqGeom(B, Cin, Hh * Ww, Hh * Ww, 0, -128, 127, B * Hh * Ww)
+    bad.patch = (Ww, p, p + 1)
+    with pytest.raises(RuntimeError):
+        ops.lsq_fwd(x.view(B * Cin, -1), s, b4, baft, bad, want_codes=True)
+
+
 @pytest.mark.parametrize("shift", [0, 3])
 def test_layernorm_lsq_with_token_permutations_equals_the_same_kernel_on_permuted_rows(ops, shift):
     """ofq_layernorm_lsq_fwd_perm / _bwd_perm (round 6: Swin's shifted-window partition and reverse folded into the LayerNorm passes,
